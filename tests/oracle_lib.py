@@ -1,0 +1,204 @@
+"""ctypes binding of the CPU ORACLE (oracle/liboracle.so).  Test infrastructure only:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ERRORS = {
+    0xFFFFFFFF: "VBZ_ZSTD_ERROR",
+    0xFFFFFFFE: "VBZ_INPUT_SIZE_ERROR",
+    0xFFFFFFFD: "VBZ_INTEGER_SIZE_ERROR",
+    0xFFFFFFFC: "VBZ_DESTINATION_SIZE_ERROR",
+    0xFFFFFFFB: "VBZ_STREAMVBYTE_STREAM_ERROR",
+    0xFFFFFFFA: "VBZ_VERSION_ERROR",
+    0xFFFFFFF9: "VBZ_OUT_OF_MEMORY_ERROR",
+}
+FIRST_ERROR = 0xFFFFFFF9
+
+
+class Options(ctypes.Structure):
+    _fields_ = [
+        ("perform_delta_zig_zag", ctypes.c_bool),
+        ("integer_size", ctypes.c_uint),
+        ("zstd_compression_level", ctypes.c_uint),
+        ("vbz_version", ctypes.c_uint),
+    ]
+
+
+def build_oracle():
+    so = os.path.join(ORACLE_DIR, "liboracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vbz_oracle.c", "zstd_restate.c", "vbz_oracle.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = ctypes.CDLL(build_oracle())
+        vp, u32, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t
+        op = ctypes.POINTER(Options)
+        L.vbo_max_streamvbyte_size.restype = u32
+        L.vbo_max_streamvbyte_size.argtypes = [sz, u32]
+        for name in ("vbo_streamvbyte_compress", "vbo_streamvbyte_decompress"):
+            f = getattr(L, name)
+            f.restype = u32
+            f.argtypes = [vp, u32, vp, u32, ctypes.c_int, ctypes.c_bool, ctypes.c_uint]
+        L.vbo_max_compressed_size.restype = u32
+        L.vbo_max_compressed_size.argtypes = [u32, op]
+        for name in ("vbo_compress", "vbo_decompress", "vbo_compress_sized", "vbo_decompress_sized"):
+            f = getattr(L, name)
+            f.restype = u32
+            f.argtypes = [vp, u32, vp, u32, op]
+        L.vbo_decompressed_size.restype = u32
+        L.vbo_decompressed_size.argtypes = [vp, u32, op]
+        L.vbo_error_string.restype = ctypes.c_char_p
+        L.vbo_error_string.argtypes = [u32]
+        L.vbo_is_error.restype = ctypes.c_bool
+        L.vbo_is_error.argtypes = [u32]
+        L.vbo_filter.restype = sz
+        L.vbo_filter.argtypes = [ctypes.c_uint, sz, ctypes.POINTER(ctypes.c_uint), sz, ctypes.POINTER(sz), ctypes.POINTER(vp)]
+        L.vbo_zstd_version.restype = ctypes.c_char_p
+        L.vbo_zstd_compress.restype = sz
+        L.vbo_zstd_compress.argtypes = [vp, sz, vp, sz, ctypes.c_int]
+        L.vbo_zstd_decompress.restype = sz
+        L.vbo_zstd_decompress.argtypes = [vp, sz, vp, sz]
+        L.vbo_zstd_bound.restype = sz
+        L.vbo_zstd_bound.argtypes = [sz]
+        L.vbo_zstd_content_size.restype = ctypes.c_ulonglong
+        L.vbo_zstd_content_size.argtypes = [vp, sz]
+        L.vbo_zstd_restate_decompress.restype = sz
+        L.vbo_zstd_restate_decompress.argtypes = [vp, sz, vp, sz]
+        L.vbo_mix64.restype = ctypes.c_uint64
+        L.vbo_mix64.argtypes = [ctypes.c_uint64]
+        L.vbo_synth_read_length.restype = u32
+        L.vbo_synth_read_length.argtypes = [ctypes.c_uint64, ctypes.c_uint64]
+        L.vbo_synth_signal.restype = None
+        L.vbo_synth_signal.argtypes = [ctypes.c_uint64, ctypes.c_uint64, vp, sz]
+        L.vbo_synth_u32.restype = None
+        L.vbo_synth_u32.argtypes = [ctypes.c_uint64, ctypes.c_uint64, vp, sz]
+        _lib = L
+    return _lib
+
+
+def options(zigzag=True, size=2, level=1, version=0):
+    return Options(bool(zigzag), int(size), int(level), int(version))
+
+
+def _buf(a):
+    a = np.ascontiguousarray(a)
+    return a, (a.ctypes.data if a.size else None), a.nbytes
+
+
+def is_error(v):
+    return v >= FIRST_ERROR
+
+
+def svb_compress(arr, size, zigzag, version=0):
+    a, p, n = _buf(arr)
+    cap = lib().vbo_max_streamvbyte_size(size, n)
+    assert not is_error(cap), ERRORS.get(cap)
+    out = np.zeros(cap + 32, np.uint8)
+    r = lib().vbo_streamvbyte_compress(p, n, out.ctypes.data, cap, size, zigzag, version)
+    if is_error(r):
+        return r
+    return out[:r].copy()
+
+
+def svb_decompress(buf, nbytes, size, zigzag, version=0):
+    a, p, n = _buf(np.frombuffer(bytes(buf), np.uint8) if not isinstance(buf, np.ndarray) else buf)
+    out = np.zeros(max(nbytes, 1), np.uint8)
+    r = lib().vbo_streamvbyte_decompress(p, n, out.ctypes.data, nbytes, size, zigzag, version)
+    if is_error(r):
+        return r
+    return out[:r].copy()
+
+
+def max_compressed_size(nbytes, opts):
+    return lib().vbo_max_compressed_size(nbytes, ctypes.byref(opts))
+
+
+def compress(arr, opts, sized=False):
+    a, p, n = _buf(arr)
+    cap = max_compressed_size(n, opts)
+    if is_error(cap):
+        return cap
+    out = np.zeros(cap + 32, np.uint8)
+    fn = lib().vbo_compress_sized if sized else lib().vbo_compress
+    r = fn(p, n, out.ctypes.data, cap, ctypes.byref(opts))
+    if is_error(r):
+        return r
+    return out[:r].copy()
+
+
+def decompress(buf, nbytes, opts, sized=False):
+    a, p, n = _buf(buf if isinstance(buf, np.ndarray) else np.frombuffer(bytes(buf), np.uint8))
+    out = np.zeros(max(nbytes, 1), np.uint8)
+    fn = lib().vbo_decompress_sized if sized else lib().vbo_decompress
+    r = fn(p, n, out.ctypes.data, nbytes, ctypes.byref(opts))
+    if is_error(r):
+        return r
+    return out[:r].copy()
+
+
+def zstd_compress(data, level=1):
+    a, p, n = _buf(data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), np.uint8))
+    cap = lib().vbo_zstd_bound(n)
+    out = np.zeros(cap + 8, np.uint8)
+    r = lib().vbo_zstd_compress(out.ctypes.data, cap, p, n, level)
+    assert r != 2**64 - 1
+    return out[:r].copy()
+
+
+def zstd_decompress(frame, cap):
+    a, p, n = _buf(frame if isinstance(frame, np.ndarray) else np.frombuffer(bytes(frame), np.uint8))
+    out = np.zeros(max(cap, 1), np.uint8)
+    r = lib().vbo_zstd_decompress(out.ctypes.data, cap, p, n)
+    if r == 2**64 - 1:
+        return None
+    return out[:r].copy()
+
+
+def zstd_restate_decompress(frame, cap):
+    a, p, n = _buf(frame if isinstance(frame, np.ndarray) else np.frombuffer(bytes(frame), np.uint8))
+    out = np.zeros(max(cap, 1), np.uint8)
+    r = lib().vbo_zstd_restate_decompress(out.ctypes.data, cap, p, n)
+    if r == 2**64 - 1:
+        return None
+    return out[:r].copy()
+
+
+def zstd_content_size(frame):
+    a, p, n = _buf(frame if isinstance(frame, np.ndarray) else np.frombuffer(bytes(frame), np.uint8))
+    return lib().vbo_zstd_content_size(p, n)
+
+
+def synth_signal(seed, read_index, n):
+    out = np.zeros(n, np.int16)
+    lib().vbo_synth_signal(seed, read_index, out.ctypes.data, n)
+    return out
+
+
+def synth_u32(seed, read_index, n):
+    out = np.zeros(n, np.uint32)
+    lib().vbo_synth_u32(seed, read_index, out.ctypes.data, n)
+    return out
+
+
+def synth_read_length(seed, read_index):
+    return lib().vbo_synth_read_length(seed, read_index)
+
+
+def fnv1a64(data):
+    h = 0xCBF29CE484222325
+    for b in bytes(data):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
