@@ -1,0 +1,109 @@
+/*
+ * vbz_gpu.h -- batched, device-resident extension of the VBZ C ABI (MI355X / gfx950).
+ *
+ * The reference API (vbz.h) handles one host buffer per call, which cannot feed a GPU
+ * (SURVEY.md section 8b "needed extension").  This header adds the entry points a caller that
+ * already holds many reads in HBM binds instead: one call encodes or decodes a whole batch of
+ * independent reads, each with exactly the semantics of the corresponding single-buffer call
+ *
+ *   vbz_gpu_compress_batch   == n x vbz_compress[_sized]    (reference vbz/vbz.cpp:116-208,302-330)
+ *   vbz_gpu_decompress_batch == n x vbz_decompress[_sized]  (reference vbz/vbz.cpp:210-300,332-366)
+ *
+ * Plain C: pointers and sizes only, no torch / HIP types in the signatures (the stream is passed
+ * as an opaque void* that is a hipStream_t).  All pointers in vbz_gpu_batch are DEVICE pointers.
+ * Calls are asynchronous on the context's stream; results (per-read sizes or vbz error codes) land
+ * in batch->result in stream order.
+ */
+#ifndef VBZ_GPU_H_MI355X
+#define VBZ_GPU_H_MI355X
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "vbz.h"
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+typedef struct vbz_gpu_ctx vbz_gpu_ctx;
+
+typedef struct vbz_gpu_batch
+{
+    uint32_t n_reads;
+    uint32_t reserved;
+    /* inputs: read i occupies src[src_off[i] .. src_off[i]+src_size[i]).  Offsets must not overlap,
+     * should be 16-byte aligned (a slower path handles other alignments), and the arena must be
+     * readable for 16 bytes past the last input (the same slack streamvbyte asks for). */
+    const void* src;
+    const uint64_t* src_off;
+    const uint32_t* src_size;
+    uint64_t src_bytes; /* extent of the src arena covering every read (sizes the scratch) */
+    /* outputs: read i may use dst[dst_off[i] .. dst_off[i]+dst_cap[i]).
+     *   compress:   dst_cap[i] >= vbz_max_compressed_size(src_size[i]) (as for vbz_compress)
+     *   decompress: dst_cap[i] == the exact original byte count      (as for vbz_decompress);
+     *               for the sized variant it is the capacity and the size comes from the header */
+    void* dst;
+    const uint64_t* dst_off;
+    const uint32_t* dst_cap;
+    uint64_t dst_bytes; /* extent of the dst arena covering every slot */
+    /* per read: number of bytes produced, or a vbz error code (vbz_is_error) */
+    uint32_t* result;
+} vbz_gpu_batch;
+
+/* Create a context on HIP device `device`.  `stream` is a hipStream_t to launch on (NULL: the
+ * context creates its own non-blocking stream).  Returns NULL (message on stderr) if no gfx950
+ * device or kernel image is usable. */
+VBZ_EXPORT vbz_gpu_ctx* vbz_gpu_create(int device, void* stream);
+VBZ_EXPORT void vbz_gpu_destroy(vbz_gpu_ctx* ctx);
+VBZ_EXPORT void* vbz_gpu_stream(vbz_gpu_ctx* ctx);
+VBZ_EXPORT const char* vbz_gpu_last_error(vbz_gpu_ctx* ctx);
+/* wait for everything queued on the context's stream; returns 0 or a negative HIP error */
+VBZ_EXPORT int vbz_gpu_synchronize(vbz_gpu_ctx* ctx);
+
+/* Both return 0 when the batch was queued, negative on a launch/allocation failure (see
+ * vbz_gpu_last_error).  Per-read failures are reported in batch->result, not here. */
+VBZ_EXPORT int vbz_gpu_compress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch,
+                                      const struct CompressionOptions* options, int sized);
+VBZ_EXPORT int vbz_gpu_decompress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch,
+                                        const struct CompressionOptions* options, int sized);
+
+/* Stage-level entry points (the two halves of the path, used by tests and stage benchmarks).
+ *   svb:  reference vbz_delta_zig_zag_streamvbyte_{compress,decompress}_v{0,1}
+ *         (vbz/v0/vbz_streamvbyte.cpp:20-108, vbz/v1/vbz_streamvbyte.cpp:22-113)
+ *   zstd: the reference's ZSTD_compress / ZSTD_decompress call sites (vbz/vbz.cpp:194-207,236-273)
+ * For zstd decompress, dst_cap[i] is the capacity and result[i] the frame content size. */
+VBZ_EXPORT int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch, int integer_size,
+                                          int zigzag, int version);
+VBZ_EXPORT int vbz_gpu_svb_decompress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch, int integer_size,
+                                            int zigzag, int version);
+/* key_bytes (device, nullable): length of the control-byte section of each svb stream, which the
+ * encoder codes with its own Huffman table; NULL codes the whole stream as one region. */
+VBZ_EXPORT int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch, const uint32_t* key_bytes);
+VBZ_EXPORT int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch);
+
+/* Synthetic workload of SURVEY.md section 8(d), generated on the device (no host data needed).
+ *   lengths:  out_len[i] = samples of read first_read+i (90 000 + mix(..) % 20 001), i < n_reads
+ *   signal:   int16 samples of read first_read+i written at dst + off[i] (bytes), len[i] samples
+ *   u32:      config-4 values, len[i] elements */
+VBZ_EXPORT int vbz_gpu_synth_lengths(vbz_gpu_ctx* ctx, uint64_t seed, uint64_t first_read, uint32_t n_reads,
+                                     uint32_t* out_len);
+VBZ_EXPORT int vbz_gpu_synth_signal(vbz_gpu_ctx* ctx, uint64_t seed, uint64_t first_read, uint32_t n_reads,
+                                    void* dst, const uint64_t* off, const uint32_t* len);
+VBZ_EXPORT int vbz_gpu_synth_u32(vbz_gpu_ctx* ctx, uint64_t seed, uint64_t first_read, uint32_t n_reads,
+                                 void* dst, const uint64_t* off, const uint32_t* len);
+
+/* Per-kernel timing with HIP events recorded on the context's stream around every launch.
+ * enable=1 starts collecting; vbz_gpu_profile_read synchronizes, copies up to `cap` entries
+ * (kernel name, launches, total milliseconds) and returns the number of distinct kernels. */
+VBZ_EXPORT void vbz_gpu_profile_enable(vbz_gpu_ctx* ctx, int enable);
+VBZ_EXPORT int vbz_gpu_profile_read(vbz_gpu_ctx* ctx, const char** names, uint32_t* launches, double* total_ms, int cap);
+VBZ_EXPORT void vbz_gpu_profile_reset(vbz_gpu_ctx* ctx);
+
+/* Version string of the library: "vbz_hip <semver> gfx950". */
+VBZ_EXPORT const char* vbz_gpu_version(void);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif

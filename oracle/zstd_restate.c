@@ -268,6 +268,18 @@ static int huf_read_table(huf_table* h, const uint8_t* p, size_t n)
     return (int)used;
 }
 
+/* test helper: code length of every symbol described by a Huffman tree description (0 = absent) */
+int vbo_debug_huf_lengths(const uint8_t* p, size_t n, uint8_t* nbits_out /*256*/, int* used_out)
+{
+    static _Thread_local huf_table h;
+    int used = huf_read_table(&h, p, n);
+    if (used < 0) return -1;
+    memset(nbits_out, 0, 256);
+    for (int i = 0; i < (1 << h.log); ++i) nbits_out[h.e[i] & 0xFF] = (uint8_t)(h.e[i] >> 8);
+    if (used_out) *used_out = used;
+    return h.log;
+}
+
 static int huf_decode_stream(const huf_table* h, const uint8_t* p, size_t n, uint8_t* out, size_t count)
 {
     bitr b;

@@ -1,0 +1,65 @@
+"""Build the HIP shared libraries in-tree (so they travel with gpurun snapshots).
+
+    python -m vbz_compression_amd.build            # libvbz_hip.so + libvbz_hdf_plugin.so
+
+hipcc cross-compiles gfx950 code objects without a GPU present.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+SOURCES = ["svb_kernels.hip", "zstd_encode.hip", "zstd_decode.hip", "helpers.hip", "vbz_api.hip"]
+HEADERS = ["vbz_kernels.h", "zstd_entropy.h", "../../include/vbz.h", "../../include/vbz_gpu.h", "../../include/vbz_hdf_plugin.h"]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for name, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed on %s" % name)
+    lib = os.path.join(LIBDIR, "libvbz_hip.so")
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    plugin_src = os.path.join(CSRC, "vbz_plugin.cpp")
+    plugin = os.path.join(LIBDIR, "libvbz_hdf_plugin.so")
+    if os.path.exists(plugin_src) and (force or _stale(plugin, [plugin_src, lib] + hdrs)):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-o", plugin, plugin_src,
+               "-L" + LIBDIR, "-lvbz_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return lib
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print("ok")

@@ -1,0 +1,199 @@
+// helpers.hip -- small bookkeeping kernels around the two stages, and the on-device generator of the
+// synthetic workload.  None of these is on the critical path.
+#include "vbz_kernels.h"
+
+namespace vbzhip {
+
+namespace {
+
+// ---- scratch planning: exclusive scan of per-read slot sizes by ONE 1024-thread workgroup ---------
+// slot(i) = align16(bound(raw_size[i])) + 48, bound = num*size/den + 8 (the worst-case svb size).
+// off[i] = sum of earlier slots; cap[i] = slot - 32 (16 bytes of slack on each side stay unused).
+__global__ __launch_bounds__(1024) void plan_scratch_kernel(uint32_t n, const uint32_t* raw_size, uint32_t mul_num,
+                                                            uint32_t mul_den, uint64_t limit, uint64_t* off, uint32_t* cap,
+                                                            uint32_t* gate, uint32_t gate_is_input)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        uint64_t slot = 0;
+        bool gated = false;
+        if (i < n) {
+            gated = gate_is_input && gate[i] >= E_FIRST;  // already failed: give it an empty slot
+            const uint64_t bound = gated ? 0 : ((uint64_t)raw_size[i] * mul_num + mul_den - 1) / mul_den + 8;
+            slot = ((bound + 15) & ~15ull) + 48;
+        }
+        uint64_t inc = slot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint64_t pre = carry_s;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (i < n) {
+            const uint64_t o = pre + inc - slot;
+            off[i] = o + 16;
+            const uint64_t c = slot - 32;
+            cap[i] = c > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)c;
+            if (!gated) gate[i] = (o + slot > limit) ? E_OOM : 0u;
+        }
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + inc;
+        __syncthreads();
+    }
+}
+
+__global__ void parse_sized_kernel(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
+                                   const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
+                                   uint32_t* gate)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sz = src_size[i];
+    uint32_t g = 0, orig = 0;
+    if (sz < 4) {
+        g = E_INPUT_SIZE;  // vbz/vbz.cpp:345-348
+    } else {
+        const uint8_t* p = src + src_off[i];
+        orig = p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+        if (dst_cap[i] < orig) g = E_DESTINATION_SIZE;  // vbz/vbz.cpp:353-356
+    }
+    pay_off[i] = src_off[i] + 4;
+    pay_size[i] = sz >= 4 ? sz - 4 : 0;
+    orig_size[i] = orig;
+    gate[i] = g;
+}
+
+// integer_size == 0 && level == 0: plain copy (vbz/vbz.cpp:130-133 copy_buffer)
+__global__ __launch_bounds__(256) void copy_bytes_kernel(ReadBatch b, uint32_t hdr)
+{
+    const uint32_t r = blockIdx.x;
+    if (b.gate && b.gate[r] >= E_FIRST) {
+        if (threadIdx.x == 0) b.result[r] = b.gate[r];
+        return;
+    }
+    const uint32_t n = b.src_size[r];
+    if ((uint64_t)n + hdr > b.dst_cap[r]) {
+        if (threadIdx.x == 0) b.result[r] = E_DESTINATION_SIZE;
+        return;
+    }
+    const uint8_t* s = b.src + b.src_off[r];
+    uint8_t* d = b.dst + b.dst_off[r];
+    if (hdr && threadIdx.x < 4) d[threadIdx.x] = (uint8_t)(n >> (8 * threadIdx.x));
+    d += hdr;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+    if (threadIdx.x == 0) b.result[r] = n + hdr;
+}
+
+// ---- synthetic workload -----------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__device__ __forceinline__ uint64_t synth_key(uint64_t seed, uint64_t r) { return mix64(seed * 0x100000001B3ull + r); }
+
+__global__ void synth_lengths_kernel(uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_len[i] = 90000u + (uint32_t)(mix64(synth_key(seed, first + i) ^ 0xC2B2AE3D27D4EB4Full) % 20001u);
+}
+
+__global__ __launch_bounds__(256) void synth_signal_kernel(uint64_t seed, uint64_t first, uint8_t* dst, const uint64_t* off,
+                                                           const uint32_t* len)
+{
+    const uint32_t r = blockIdx.x;
+    const uint64_t key = synth_key(seed, first + r);
+    int16_t* out = reinterpret_cast<int16_t*>(dst + off[r]);
+    const uint32_t n = len[r];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t hs = mix64(key ^ ((uint64_t)(i / 32) * 0xD6E8FEB86659FD93ull));
+        const int32_t level = 200 + (int32_t)(hs % 321u);
+        uint64_t hn = mix64(key ^ ((uint64_t)i * 0xA24BAED4963EE407ull) ^ 0x5555555555555555ull);
+        int32_t noise = -60;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) noise += (int32_t)((hn >> (4 * k)) & 15u);
+        int32_t x = level + noise;
+        x = x < -4096 ? -4096 : (x > 4095 ? 4095 : x);
+        out[i] = (int16_t)x;
+    }
+}
+
+__global__ __launch_bounds__(256) void synth_u32_kernel(uint64_t seed, uint64_t first, uint8_t* dst, const uint64_t* off,
+                                                        const uint32_t* len)
+{
+    const uint32_t r = blockIdx.x;
+    const uint64_t key = synth_key(seed, first + r);
+    uint32_t* out = reinterpret_cast<uint32_t*>(dst + off[r]);
+    const uint32_t n = len[r];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint64_t h = mix64(key ^ ((uint64_t)i * 0xA24BAED4963EE407ull));
+        const uint32_t sel = (uint32_t)(h & 127u);
+        const uint32_t s = sel < 90 ? 24 : (sel < 115 ? 16 : (sel < 125 ? 8 : 0));
+        out[i] = (uint32_t)(h >> 32) >> s;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mul_num, uint32_t mul_den, uint64_t limit,
+                               uint64_t* off, uint32_t* cap, uint32_t* gate, bool gate_is_input, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(plan_scratch_kernel, dim3(1), dim3(1024), 0, s, n, raw_size, mul_num, mul_den, limit, off, cap, gate,
+                       gate_is_input ? 1u : 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
+                              const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
+                              uint32_t* gate, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(parse_sized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, src, src_off, src_size, dst_cap, pay_off,
+                       pay_size, orig_size, gate);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_bytes(const ReadBatch& b, uint32_t hdr, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_bytes_kernel, dim3(b.n_reads), dim3(256), 0, s, b, hdr);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_lengths(uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_lengths_kernel, dim3((n + 255) / 256), dim3(256), 0, s, seed, first, n, out_len);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_signal(uint64_t seed, uint64_t first, uint32_t n, uint8_t* dst, const uint64_t* off, const uint32_t* len,
+                               hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_signal_kernel, dim3(n), dim3(256), 0, s, seed, first, dst, off, len);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_u32(uint64_t seed, uint64_t first, uint32_t n, uint8_t* dst, const uint64_t* off, const uint32_t* len,
+                            hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_u32_kernel, dim3(n), dim3(256), 0, s, seed, first, dst, off, len);
+    return hipGetLastError();
+}
+
+}  // namespace vbzhip

@@ -1,0 +1,396 @@
+// svb_kernels.hip -- delta + zig-zag + streamvbyte stage of the VBZ path as HIP kernels for gfx950.
+//
+// Replaces (reference file:line):
+//   StreamVByteWorkerV0<int16_t,true>::compress / ::decompress   vbz/v0/vbz_streamvbyte_impl_sse3.h:406-466, 468-580
+//   StreamVByteWorkerV0<T,ZigZag>::compress / ::decompress       vbz/v0/vbz_streamvbyte_impl.h:18-73
+//   (dispatch: vbz/v0/vbz_streamvbyte.cpp:20-108, vbz/v1/vbz_streamvbyte.cpp:22-113)
+//
+// Design (MI355X-first, not a translation of the SSSE3 loop):
+//   * one 256-thread workgroup per read; the read is walked in tiles of 256 lanes x VPL values, every
+//     lane loading 16 contiguous bytes (global_load_dwordx4, 1 KiB per wave instruction);
+//   * the variable-length byte scatter/gather is turned into a prefix sum: per-lane byte counts ->
+//     wave scan (cross-lane shuffles) -> workgroup scan through 4 LDS words -> running carry per read;
+//   * data bytes are staged through LDS so that HBM only ever sees 16-byte aligned, coalesced
+//     dwordx4 stores/loads, whatever the byte alignment of the data section;
+//   * the int16 wrap-around delta chain and its inverse (inclusive prefix sum mod 2^16) use the same
+//     scan primitives; the previous sample comes from the neighbouring lane by a shuffle.
+// Algorithmic HBM bytes per int16 sample: encode 2 read + ~1.26 written; decode the reverse.
+#include "vbz_kernels.h"
+
+namespace vbzhip {
+
+namespace {
+
+constexpr int WG = 256;
+
+template <int ELEM>
+struct Vpl
+{
+    static constexpr int value = (ELEM == 4) ? 4 : 8;  // values per lane per tile
+};
+
+__device__ __forceinline__ int32_t load_elem(const uint8_t* p, int elem)
+{
+    if (elem == 1) return (int8_t)p[0];
+    if (elem == 2) {
+        uint16_t v;
+        __builtin_memcpy(&v, p, 2);
+        return (int16_t)v;
+    }
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return (int32_t)v;
+}
+
+__device__ __forceinline__ void store_elem(uint8_t* p, int elem, uint32_t v)
+{
+    if (elem == 1) p[0] = (uint8_t)v;
+    else if (elem == 2) {
+        uint16_t t = (uint16_t)v;
+        __builtin_memcpy(p, &t, 2);
+    } else __builtin_memcpy(p, &v, 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode
+// ------------------------------------------------------------------------------------------------
+template <int ELEM, bool ZZ, bool I16ZZ>
+__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap)
+{
+    constexpr int VPL = Vpl<ELEM>::value;
+    constexpr int TILE = WG * VPL;
+    constexpr int MAXLEN = I16ZZ ? 2 : 4;
+    constexpr int STAGE = TILE * MAXLEN + 32;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
+    __shared__ uint32_t wsum[4];
+
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    if (b.gate && b.gate[r] >= E_FIRST) {
+        if (tid == 0) b.result[r] = b.gate[r];
+        return;
+    }
+    const uint32_t size = b.src_size[r];
+    const uint32_t cap = b.dst_cap[r];
+    if (size % ELEM != 0) {  // vbz/v0/vbz_streamvbyte.cpp:28-31
+        if (tid == 0) b.result[r] = E_INPUT_SIZE;
+        return;
+    }
+    const uint32_t n = size / ELEM;
+    const uint32_t keyLen = (n + 3u) >> 2;
+    {   // the reference requires the destination to hold the worst case (vbz/vbz.cpp:171-174); the
+        // library's own scratch slots (strict_cap == 0) are sized for what this kernel can really emit
+        const uint64_t worst = (uint64_t)keyLen + ((I16ZZ && !strict_cap) ? 2ull : 4ull) * n + hdr;
+        if (worst > cap) {
+            if (tid == 0) b.result[r] = worst > 0xFFFFFFF0ull ? E_INPUT_SIZE : E_DESTINATION_SIZE;
+            return;
+        }
+    }
+    const uint8_t* in = b.src + b.src_off[r];
+    uint8_t* out = b.dst + b.dst_off[r];
+    if (hdr) {
+        if (tid < 4) out[tid] = (uint8_t)(size >> (8 * tid));
+        out += 4;
+    }
+    uint8_t* keys = out;
+    uint8_t* data = out + keyLen;
+    const uint32_t A = (uint32_t)((uintptr_t)data & 15u);
+    uint8_t* gal = data - A;  // 16-byte aligned address space of the data section
+    const bool in_aligned = (((uintptr_t)in) & 15u) == 0;
+
+    uint64_t F = 0;  // bytes of the aligned space already flushed (multiple of 16)
+    uint64_t P = A;  // next byte position in the aligned space; stage[] holds [F, P)
+
+    for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+        const uint32_t i0 = t0 + (uint32_t)tid * VPL;
+        const int valid = i0 >= n ? 0 : (n - i0 >= (uint32_t)VPL ? VPL : (int)(n - i0));
+        int32_t x[VPL];
+        if (valid == VPL && in_aligned) {
+            uint4 q = *reinterpret_cast<const uint4*>(in + (size_t)i0 * ELEM);
+            const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+            if (ELEM == 4) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) x[k] = (int32_t)w[k & 3];
+            } else if (ELEM == 2) {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) x[k] = (int16_t)(w[(k >> 1) & 3] >> (16 * (k & 1)));
+            } else {
+#pragma unroll
+                for (int k = 0; k < VPL; ++k) x[k] = (int8_t)(w[(k >> 2) & 3] >> (8 * (k & 3)));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) x[k] = k < valid ? load_elem(in + (size_t)(i0 + k) * ELEM, ELEM) : 0;
+        }
+        uint32_t u[VPL];
+        if (ZZ) {
+            // previous sample: neighbouring lane's last value; wave lane 0 re-reads it from memory
+            int32_t prev = __shfl_up(x[VPL - 1], 1, 64);
+            if (lane == 0) prev = (i0 == 0 || valid == 0) ? 0 : load_elem(in + (size_t)(i0 - 1) * ELEM, ELEM);
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                if (I16ZZ) {
+                    // wrap-around int16 delta, 16-bit zig-zag (sse3.h:432-440)
+                    uint32_t d = ((uint32_t)x[k] - (uint32_t)prev) & 0xFFFFu;
+                    u[k] = ((d << 1) ^ (0u - (d >> 15))) & 0xFFFFu;
+                } else {
+                    uint32_t d = (uint32_t)x[k] - (uint32_t)prev;  // streamvbyte zigzag_delta_encode
+                    u[k] = (d << 1) ^ (uint32_t)((int32_t)d >> 31);
+                }
+                prev = x[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) u[k] = (uint32_t)x[k];
+        }
+        uint32_t keybits = 0, L = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            uint32_t code = (u[k] > 0xFFu) + (u[k] > 0xFFFFu) + (u[k] > 0xFFFFFFu);
+            if (k < valid) {
+                keybits |= code << (2 * k);
+                L += code + 1;
+            }
+        }
+        // control bytes: VPL/4 per lane, contiguous across the wave
+        if (valid > 0) {
+            uint8_t* kp = keys + (i0 >> 2);
+            if (VPL == 8 && valid > 4) {
+                uint16_t kk = (uint16_t)keybits;
+                __builtin_memcpy(kp, &kk, 2);
+            } else {
+                kp[0] = (uint8_t)keybits;
+            }
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(L, wsum, tot);
+        uint32_t o = (uint32_t)(P - F) + ex;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            if (k < valid) {
+                uint32_t v = u[k];
+                stage[o++] = (uint8_t)v;
+                if (v > 0xFFu) stage[o++] = (uint8_t)(v >> 8);
+                if (!I16ZZ) {
+                    if (v > 0xFFFFu) stage[o++] = (uint8_t)(v >> 16);
+                    if (v > 0xFFFFFFu) stage[o++] = (uint8_t)(v >> 24);
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t endidx = (uint32_t)(P - F) + tot;
+        const uint32_t nch = endidx >> 4;
+        for (uint32_t c = tid; c < nch; c += WG) {
+            uint8_t* g = gal + F + 16ull * c;
+            if (F == 0 && c == 0 && A != 0) {
+                for (uint32_t j = A; j < 16; ++j) g[j] = stage[j];
+            } else {
+                *reinterpret_cast<uint4*>(g) = *reinterpret_cast<const uint4*>(stage + 16u * c);
+            }
+        }
+        const uint32_t rem = endidx & 15u;
+        uint8_t keep = 0;
+        if ((uint32_t)tid < rem) keep = stage[16u * nch + tid];
+        __syncthreads();
+        if (nch > 0 && (uint32_t)tid < rem) stage[tid] = keep;
+        F += 16ull * nch;
+        P += tot;
+        // the scan at the top of the next tile contains the barrier that orders these LDS writes
+    }
+    __syncthreads();
+    {   // tail: bytes [F, P) still in LDS
+        const uint32_t rem = (uint32_t)(P - F);
+        const uint32_t lo = (F == 0) ? A : 0u;
+        if ((uint32_t)tid >= lo && (uint32_t)tid < rem) gal[F + tid] = stage[tid];
+    }
+    if (tid == 0) b.result[r] = hdr + keyLen + (uint32_t)(P - A);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+template <int ELEM, bool ZZ, bool I16ZZ>
+__global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
+{
+    constexpr int VPL = Vpl<ELEM>::value;
+    constexpr int TILE = WG * VPL;
+    constexpr int STAGE = TILE * 4 + 48;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
+    __shared__ uint32_t wsum[4];
+
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (b.gate && b.gate[r] >= E_FIRST) {
+        if (tid == 0) b.result[r] = b.gate[r];
+        return;
+    }
+    const uint32_t in_size = b.src_size[r];
+    if (in_size >= E_FIRST) {  // the previous stage failed for this read
+        if (tid == 0) b.result[r] = in_size;
+        return;
+    }
+    const uint32_t out_size = b.dst_cap[r];  // exact decoded byte count
+    if (out_size % ELEM != 0) {              // vbz/v0/vbz_streamvbyte.cpp:75-78
+        if (tid == 0) b.result[r] = E_DESTINATION_SIZE;
+        return;
+    }
+    const uint32_t count = out_size / ELEM;
+    const uint32_t keyLen = (count + 3u) >> 2;
+    if (I16ZZ) {
+        if (count == 0) {  // sse3.h:472-476
+            if (tid == 0) b.result[r] = 0;
+            return;
+        }
+        if (in_size < keyLen) {  // sse3.h:478-482
+            if (tid == 0) b.result[r] = E_INPUT_SIZE;
+            return;
+        }
+    } else {
+        // streamvbyte_validate_stream (vbz/v0/vbz_streamvbyte_impl.h:49-51)
+        if (in_size == 0 || count == 0) {
+            if (tid == 0) b.result[r] = (in_size == count) ? 0u : E_STREAM;
+            return;
+        }
+        if (keyLen > in_size) {
+            if (tid == 0) b.result[r] = E_STREAM;
+            return;
+        }
+    }
+    const uint8_t* in = b.src + b.src_off[r];
+    const uint8_t* data = in + keyLen;
+    uint8_t* out = b.dst + b.dst_off[r];
+    const uint32_t dataBytes = in_size - keyLen;
+    const bool out_aligned = (((uintptr_t)out) & 15u) == 0;
+    const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
+
+    uint32_t pos = 0;   // data bytes consumed so far
+    uint32_t run = 0;   // running value of the delta chain
+    bool bad = false;
+    for (uint32_t t0 = 0; t0 < count; t0 += TILE) {
+        const uint32_t i0 = t0 + (uint32_t)tid * VPL;
+        const int valid = i0 >= count ? 0 : (count - i0 >= (uint32_t)VPL ? VPL : (int)(count - i0));
+        uint32_t keybits = 0;
+        if (valid > 0) {
+            const uint8_t* kp = in + (i0 >> 2);
+            keybits = kp[0];
+            if (VPL == 8 && valid > 4) keybits |= (uint32_t)kp[1] << 8;
+        }
+        uint32_t L = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+            if (k < valid) L += ((keybits >> (2 * k)) & 3u) + 1u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(L, wsum, tot);
+        if ((uint64_t)pos + tot > dataBytes) {  // stream shorter than its control bytes claim
+            bad = true;
+            break;
+        }
+        // stage the tile's data bytes: aligned 16-byte chunks, coalesced
+        const uint8_t* g0 = data + pos;
+        const uint32_t mis = (uint32_t)((uintptr_t)g0 & 15u);
+        const uint8_t* ga = g0 - mis;
+        const uint32_t nch = (mis + tot + 15u) >> 4;
+        for (uint32_t c = tid; c < nch; c += WG)
+            *reinterpret_cast<uint4*>(stage + 16u * c) = *reinterpret_cast<const uint4*>(ga + 16ull * c);
+        __syncthreads();
+        uint32_t o = mis + ex;
+        // int16 zig-zag path: SIMD body vs scalar tail of the reference (sse3.h:494-540 vs 542-572)
+        const bool body = I16ZZ && ((i0 >> 3) < (count >> 3)) && (dataBytes - (pos + ex) >= 32u);
+        uint32_t s[VPL];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            uint32_t v = 0;
+            if (k < valid) {
+                const uint32_t len = ((keybits >> (2 * k)) & 3u) + 1u;
+                const uint32_t w0 = stage32[o >> 2];
+                const uint32_t w1 = stage32[(o >> 2) + 1];
+                v = (uint32_t)(((uint64_t)w1 << 32 | w0) >> (8u * (o & 3u)));
+                v &= 0xFFFFFFFFu >> (32u - 8u * len);
+                o += len;
+            }
+            if (ZZ) {
+                if (I16ZZ && body) v &= 0xFFFFu;  // keep the low 16 bits (sse3.h:510-514)
+                v = (v >> 1) ^ (0u - (v & 1u));
+                acc += v;
+                s[k] = acc;
+            } else {
+                s[k] = v;
+            }
+        }
+        uint32_t base = 0;
+        if (ZZ) {
+            uint32_t ttot;
+            base = run + block_excl_scan_u32(acc, wsum, ttot);
+            run += ttot;
+        } else {
+            __syncthreads();  // stage is overwritten by the next tile
+        }
+        if (valid == VPL && out_aligned) {
+            uint32_t w[4];
+            if (ELEM == 4) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = base + s[k % VPL];
+            } else if (ELEM == 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    w[k] = ((base + s[(2 * k) % VPL]) & 0xFFFFu) | ((base + s[(2 * k + 1) % VPL]) << 16);
+            } else {
+                w[2] = w[3] = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    w[k] = ((base + s[(4 * k) % VPL]) & 0xFFu) | (((base + s[(4 * k + 1) % VPL]) & 0xFFu) << 8) |
+                           (((base + s[(4 * k + 2) % VPL]) & 0xFFu) << 16) | ((base + s[(4 * k + 3) % VPL]) << 24);
+            }
+            if (ELEM == 1) {
+                *reinterpret_cast<uint2*>(out + (size_t)i0) = make_uint2(w[0], w[1]);
+            } else {
+                *reinterpret_cast<uint4*>(out + (size_t)i0 * ELEM) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k)
+                if (k < valid) store_elem(out + (size_t)(i0 + k) * ELEM, ELEM, base + s[k]);
+        }
+        pos += tot;
+    }
+    if (tid == 0) b.result[r] = (bad || pos != dataBytes) ? E_STREAM : count * ELEM;
+}
+
+template <typename K>
+hipError_t launch1(K kernel, const ReadBatch& b, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(kernel, dim3(b.n_reads), dim3(WG), 0, s, b);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    dim3 g(b.n_reads), t(WG);
+    if (integer_size == 2 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<2, true, true>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
+    else if (integer_size == 2) hipLaunchKernelGGL((svb_encode_kernel<2, false, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
+    else if (integer_size == 4 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<4, true, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
+    else if (integer_size == 4) hipLaunchKernelGGL((svb_encode_kernel<4, false, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
+    else if (integer_size == 1 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<1, true, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
+    else if (integer_size == 1) hipLaunchKernelGGL((svb_encode_kernel<1, false, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, hipStream_t s)
+{
+    if (integer_size == 2 && zigzag) return launch1(svb_decode_kernel<2, true, true>, b, s);
+    if (integer_size == 2) return launch1(svb_decode_kernel<2, false, false>, b, s);
+    if (integer_size == 4 && zigzag) return launch1(svb_decode_kernel<4, true, false>, b, s);
+    if (integer_size == 4) return launch1(svb_decode_kernel<4, false, false>, b, s);
+    if (integer_size == 1 && zigzag) return launch1(svb_decode_kernel<1, true, false>, b, s);
+    if (integer_size == 1) return launch1(svb_decode_kernel<1, false, false>, b, s);
+    return hipErrorInvalidValue;
+}
+
+}  // namespace vbzhip

@@ -1,0 +1,767 @@
+// vbz_api.hip -- the C ABI of libvbz_hip.so (include/vbz.h, include/vbz_gpu.h).
+//
+// Host side of the drop-in boundary.  It mirrors the control flow of the reference's vbz/vbz.cpp
+// (option validation, size rules, stage chaining, error codes -- cited per function) and drives the
+// HIP kernels; there is no CPU implementation of either stage in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vbz.h"
+#include "../../include/vbz_gpu.h"
+#include "vbz_kernels.h"
+
+using namespace vbzhip;
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+struct ProfEntry
+{
+    const char* name;
+    uint32_t launches;
+    double ms;
+};
+
+struct PendingEvent
+{
+    const char* name;
+    hipEvent_t start, stop;
+};
+
+struct DevBuf
+{
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct vbz_gpu_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string error;
+    DevBuf scratch;   // intermediate svb streams of a batch
+    DevBuf meta;      // per-read bookkeeping arrays
+    // single-buffer API staging
+    DevBuf one_in, one_out, one_meta;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    bool profiling = false;
+    std::vector<PendingEvent> pending;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+void set_error(vbz_gpu_ctx* c, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->error = buf;
+    fprintf(stderr, "vbz_hip: %s\n", buf);
+}
+
+bool ensure(vbz_gpu_ctx* c, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return true;
+    if (b.p) {
+        hipStreamSynchronize(c->stream);  // earlier work may still use the old buffer
+        hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        set_error(c, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        b.p = nullptr;
+        return false;
+    }
+    b.cap = want;
+    return true;
+}
+
+hipEvent_t get_event(vbz_gpu_ctx* c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct Timed  // records a pair of events around one kernel launch when profiling is on
+{
+    vbz_gpu_ctx* c;
+    const char* name;
+    hipEvent_t start = nullptr;
+    Timed(vbz_gpu_ctx* ctx, const char* n) : c(ctx), name(n)
+    {
+        if (c->profiling) {
+            start = get_event(c);
+            hipEventRecord(start, c->stream);
+        }
+    }
+    ~Timed()
+    {
+        if (start) {
+            hipEvent_t stop = get_event(c);
+            hipEventRecord(stop, c->stream);
+            c->pending.push_back({ name, start, stop });
+        }
+    }
+};
+
+void drain_profile(vbz_gpu_ctx* c)
+{
+    if (c->pending.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, p.start, p.stop);
+        bool found = false;
+        for (auto& e : c->prof)
+            if (e.name == p.name || strcmp(e.name, p.name) == 0) {
+                e.launches++;
+                e.ms += ms;
+                found = true;
+                break;
+            }
+        if (!found) c->prof.push_back({ p.name, 1, (double)ms });
+        c->event_pool.push_back(p.start);
+        c->event_pool.push_back(p.stop);
+    }
+    c->pending.clear();
+}
+
+bool valid_int_size(const CompressionOptions* o)  // vbz/vbz.cpp:44-50
+{
+    return o->integer_size == 0 || o->integer_size == 1 || o->integer_size == 2 || o->integer_size == 4;
+}
+
+// worst-case svb bytes per raw byte as a fraction, for what the device encoder can really emit
+void svb_factor(unsigned integer_size, bool zigzag, uint32_t* num, uint32_t* den)
+{
+    if (integer_size == 2 && zigzag) { *num = 9; *den = 8; }     // keys n/4 + 2 bytes per value
+    else if (integer_size == 1) { *num = 17; *den = 4; }         // keys n/4 + 4 bytes per value
+    else if (integer_size == 2) { *num = 17; *den = 8; }
+    else { *num = 17; *den = 16; }
+}
+
+size_t zstd_bound(size_t n)  // published ZSTD_COMPRESSBOUND (zstd.h), what vbz/vbz.cpp:109 calls
+{
+    return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+#define HIPCHK(c, expr, what)                                                      \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            set_error((c), "%s failed: %s", (what), hipGetErrorString(e__));      \
+            return -1;                                                             \
+        }                                                                          \
+    } while (0)
+
+// carve n-element arrays out of ctx->meta
+struct MetaCarver
+{
+    uint8_t* p;
+    size_t off = 0;
+    explicit MetaCarver(void* base) : p((uint8_t*)base) {}
+    template <typename T>
+    T* take(size_t n)
+    {
+        off = (off + 15) & ~(size_t)15;
+        T* r = (T*)(p + off);
+        off += n * sizeof(T);
+        return r;
+    }
+};
+
+int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+{
+    const uint32_t n = bt->n_reads;
+    if (n == 0) return 0;
+    const uint32_t hdr = sized ? 4u : 0u;
+    hipStream_t s = c->stream;
+    ReadBatch rb;
+    rb.n_reads = n;
+    rb.src = (const uint8_t*)bt->src;
+    rb.src_off = bt->src_off;
+    rb.src_size = bt->src_size;
+    rb.dst = (uint8_t*)bt->dst;
+    rb.dst_off = bt->dst_off;
+    rb.dst_cap = bt->dst_cap;
+    rb.result = bt->result;
+    rb.gate = nullptr;
+    if (o->integer_size == 0 && o->zstd_compression_level == 0) {  // vbz.cpp:130-133
+        Timed t(c, "copy_bytes");
+        HIPCHK(c, launch_copy_bytes(rb, hdr, s), "copy launch");
+        return 0;
+    }
+    if (o->integer_size != 0 && o->zstd_compression_level == 0) {  // vbz.cpp:171-192: svb straight into dst
+        Timed t(c, "svb_encode");
+        HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, s), "svb_encode launch");
+        return 0;
+    }
+    if (o->integer_size == 0) {  // zstd only
+        Timed t(c, "zstd_encode");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, s), "zstd_encode launch");
+        return 0;
+    }
+    // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
+    uint32_t num, den;
+    svb_factor(o->integer_size, o->perform_delta_zig_zag, &num, &den);
+    const size_t scratch_need = (size_t)(((unsigned __int128)bt->src_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
+    if (!ensure(c, c->scratch, scratch_need)) return -1;
+    if (!ensure(c, c->meta, (size_t)n * 32 + 256)) return -1;
+    MetaCarver mc(c->meta.p);
+    uint64_t* svb_off = mc.take<uint64_t>(n);
+    uint32_t* svb_cap = mc.take<uint32_t>(n);
+    uint32_t* svb_size = mc.take<uint32_t>(n);
+    uint32_t* gate = mc.take<uint32_t>(n);
+    {
+        Timed t(c, "plan_scratch");
+        HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, false, s), "plan launch");
+    }
+    ReadBatch a = rb;
+    a.dst = (uint8_t*)c->scratch.p;
+    a.dst_off = svb_off;
+    a.dst_cap = svb_cap;
+    a.result = svb_size;
+    a.gate = gate;
+    {
+        Timed t(c, "svb_encode");
+        HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, s), "svb_encode launch");
+    }
+    ReadBatch z = rb;
+    z.src = (const uint8_t*)c->scratch.p;
+    z.src_off = svb_off;
+    z.src_size = svb_size;
+    {
+        Timed t(c, "zstd_encode");
+        HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, s), "zstd_encode launch");
+    }
+    return 0;
+}
+
+int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+{
+    const uint32_t n = bt->n_reads;
+    if (n == 0) return 0;
+    hipStream_t s = c->stream;
+    if (!ensure(c, c->meta, (size_t)n * 64 + 512)) return -1;
+    MetaCarver mc(c->meta.p);
+    uint64_t* pay_off = mc.take<uint64_t>(n);
+    uint64_t* svb_off = mc.take<uint64_t>(n);
+    uint32_t* pay_size = mc.take<uint32_t>(n);
+    uint32_t* orig_size = mc.take<uint32_t>(n);
+    uint32_t* gate = mc.take<uint32_t>(n);
+    uint32_t* svb_cap = mc.take<uint32_t>(n);
+    uint32_t* svb_size = mc.take<uint32_t>(n);
+    ReadBatch rb;
+    rb.n_reads = n;
+    rb.src = (const uint8_t*)bt->src;
+    rb.src_off = bt->src_off;
+    rb.src_size = bt->src_size;
+    rb.dst = (uint8_t*)bt->dst;
+    rb.dst_off = bt->dst_off;
+    rb.dst_cap = bt->dst_cap;
+    rb.result = bt->result;
+    rb.gate = nullptr;
+    if (sized) {  // vbz.cpp:332-366: strip the header, the original size becomes the exact destination size
+        Timed t(c, "parse_sized");
+        HIPCHK(c, launch_parse_sized(n, rb.src, bt->src_off, bt->src_size, bt->dst_cap, pay_off, pay_size, orig_size, gate, s),
+               "parse_sized launch");
+        rb.src_off = pay_off;
+        rb.src_size = pay_size;
+        rb.dst_cap = orig_size;
+        rb.gate = gate;
+    }
+    if (o->integer_size == 0 && o->zstd_compression_level == 0) {
+        Timed t(c, "copy_bytes");
+        HIPCHK(c, launch_copy_bytes(rb, 0, s), "copy launch");
+        return 0;
+    }
+    if (o->zstd_compression_level == 0) {
+        Timed t(c, "svb_decode");
+        HIPCHK(c, launch_svb_decode(rb, (int)o->integer_size, o->perform_delta_zig_zag, s), "svb_decode launch");
+        return 0;
+    }
+    if (o->integer_size == 0) {  // vbz.cpp:259-262: content larger than the destination -> DESTINATION_SIZE
+        Timed t(c, "zstd_decode");
+        HIPCHK(c, launch_zstd_decode(rb, E_DESTINATION_SIZE, s), "zstd_decode launch");
+        return 0;
+    }
+    // entropy stage into scratch (sized for the largest svb stream the expected output can have),
+    // then svb decode into dst (vbz.cpp:234-299)
+    uint32_t num, den;
+    svb_factor(o->integer_size, false, &num, &den);  // any code length may appear in a foreign stream
+    const size_t scratch_need = (size_t)(((unsigned __int128)bt->dst_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
+    if (!ensure(c, c->scratch, scratch_need)) return -1;
+    {
+        Timed t(c, "plan_scratch");
+        HIPCHK(c, launch_plan_scratch(n, rb.dst_cap, num, den, c->scratch.cap, svb_off, svb_cap, gate, sized != 0, s), "plan launch");
+    }
+    ReadBatch z = rb;
+    z.dst = (uint8_t*)c->scratch.p;
+    z.dst_off = svb_off;
+    z.dst_cap = svb_cap;
+    z.result = svb_size;
+    z.gate = gate;
+    {
+        Timed t(c, "zstd_decode");
+        // a frame whose content cannot be a valid svb stream of the expected size: the reference would
+        // decode it and then fail in the svb stage with a stream error
+        HIPCHK(c, launch_zstd_decode(z, E_STREAM, s), "zstd_decode launch");
+    }
+    ReadBatch d = rb;
+    d.src = (const uint8_t*)c->scratch.p;
+    d.src_off = svb_off;
+    d.src_size = svb_size;
+    d.gate = gate;
+    {
+        Timed t(c, "svb_decode");
+        HIPCHK(c, launch_svb_decode(d, (int)o->integer_size, o->perform_delta_zig_zag, s), "svb_decode launch");
+    }
+    return 0;
+}
+
+bool device_supported(const CompressionOptions* o)
+{
+    // the v1 nibble codec (1-byte integers only) is not implemented on the device yet
+    return !(o->vbz_version == 1 && o->integer_size == 1);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// vbz_gpu.h
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* vbz_gpu_version(void) { return "vbz_hip 0.1.0 gfx950"; }
+
+vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error(nullptr, "no HIP device available (%s); this library has no CPU path", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        set_error(nullptr, "device %d out of range (%d devices)", device, count);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        set_error(nullptr, "hipSetDevice(%d) failed", device);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            set_error(nullptr, "device %d is %s; this library carries gfx950 (MI355X) code objects only", device, prop.gcnArchName);
+            return nullptr;
+        }
+    }
+    vbz_gpu_ctx* c = new vbz_gpu_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            set_error(nullptr, "hipStreamCreate failed");
+            delete c;
+            return nullptr;
+        }
+        c->own_stream = true;
+    }
+    return c;
+}
+
+void vbz_gpu_destroy(vbz_gpu_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending) {
+        hipEventDestroy(p.start);
+        hipEventDestroy(p.stop);
+    }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta })
+        if (b->p) hipFree(b->p);
+    if (c->pinned) hipHostFree(c->pinned);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void* vbz_gpu_stream(vbz_gpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+const char* vbz_gpu_last_error(vbz_gpu_ctx* c) { return c ? c->error.c_str() : "no context"; }
+
+int vbz_gpu_synchronize(vbz_gpu_ctx* c)
+{
+    if (!c) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->stream), "stream synchronize");
+    return 0;
+}
+
+int vbz_gpu_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+{
+    if (!c || !bt || !o) return -1;
+    hipSetDevice(c->device);
+    if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1) || !device_supported(o)) {
+        set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
+        return -2;
+    }
+    return compress_batch_impl(c, bt, o, sized);
+}
+
+int vbz_gpu_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+{
+    if (!c || !bt || !o) return -1;
+    hipSetDevice(c->device);
+    if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1) || !device_supported(o)) {
+        set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
+        return -2;
+    }
+    return decompress_batch_impl(c, bt, o, sized);
+}
+
+static ReadBatch to_rb(const vbz_gpu_batch* bt)
+{
+    ReadBatch rb;
+    rb.n_reads = bt->n_reads;
+    rb.src = (const uint8_t*)bt->src;
+    rb.src_off = bt->src_off;
+    rb.src_size = bt->src_size;
+    rb.dst = (uint8_t*)bt->dst;
+    rb.dst_off = bt->dst_off;
+    rb.dst_cap = bt->dst_cap;
+    rb.result = bt->result;
+    rb.gate = nullptr;
+    return rb;
+}
+
+int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int integer_size, int zigzag, int version)
+{
+    if (!c || !bt) return -1;
+    hipSetDevice(c->device);
+    if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || (version == 1 && integer_size == 1) || version > 1) return -2;
+    Timed t(c, "svb_encode");
+    HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, c->stream), "svb_encode launch");
+    return 0;
+}
+
+int vbz_gpu_svb_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int integer_size, int zigzag, int version)
+{
+    if (!c || !bt) return -1;
+    hipSetDevice(c->device);
+    if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || (version == 1 && integer_size == 1) || version > 1) return -2;
+    Timed t(c, "svb_decode");
+    HIPCHK(c, launch_svb_decode(to_rb(bt), integer_size, zigzag != 0, c->stream), "svb_decode launch");
+    return 0;
+}
+
+int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const uint32_t* key_bytes)
+{
+    if (!c || !bt) return -1;
+    hipSetDevice(c->device);
+    Timed t(c, "zstd_encode");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, c->stream), "zstd_encode launch");
+    return 0;
+}
+
+int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
+{
+    if (!c || !bt) return -1;
+    hipSetDevice(c->device);
+    Timed t(c, "zstd_decode");
+    HIPCHK(c, launch_zstd_decode(to_rb(bt), E_ZSTD, c->stream), "zstd_decode launch");
+    return 0;
+}
+
+int vbz_gpu_synth_lengths(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len)
+{
+    if (!c) return -1;
+    hipSetDevice(c->device);
+    HIPCHK(c, launch_synth_lengths(seed, first, n, out_len, c->stream), "synth_lengths launch");
+    return 0;
+}
+
+int vbz_gpu_synth_signal(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, void* dst, const uint64_t* off,
+                         const uint32_t* len)
+{
+    if (!c) return -1;
+    hipSetDevice(c->device);
+    HIPCHK(c, launch_synth_signal(seed, first, n, (uint8_t*)dst, off, len, c->stream), "synth_signal launch");
+    return 0;
+}
+
+int vbz_gpu_synth_u32(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, void* dst, const uint64_t* off, const uint32_t* len)
+{
+    if (!c) return -1;
+    hipSetDevice(c->device);
+    HIPCHK(c, launch_synth_u32(seed, first, n, (uint8_t*)dst, off, len, c->stream), "synth_u32 launch");
+    return 0;
+}
+
+void vbz_gpu_profile_enable(vbz_gpu_ctx* c, int enable)
+{
+    if (!c) return;
+    if (!enable) drain_profile(c);
+    c->profiling = enable != 0;
+}
+
+void vbz_gpu_profile_reset(vbz_gpu_ctx* c)
+{
+    if (!c) return;
+    drain_profile(c);
+    c->prof.clear();
+}
+
+int vbz_gpu_profile_read(vbz_gpu_ctx* c, const char** names, uint32_t* launches, double* total_ms, int cap)
+{
+    if (!c) return 0;
+    drain_profile(c);
+    int k = 0;
+    for (auto& e : c->prof) {
+        if (k < cap) {
+            if (names) names[k] = e.name;
+            if (launches) launches[k] = e.launches;
+            if (total_ms) total_ms[k] = e.ms;
+        }
+        ++k;
+    }
+    return k;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// vbz.h : the reference's single-buffer API over host pointers
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+std::mutex g_mutex;
+vbz_gpu_ctx* g_ctx = nullptr;
+bool g_ctx_failed = false;
+
+vbz_gpu_ctx* default_ctx()
+{
+    if (!g_ctx && !g_ctx_failed) {
+        int dev = 0;
+        if (const char* e = getenv("VBZ_HIP_DEVICE")) dev = atoi(e);
+        g_ctx = vbz_gpu_create(dev, nullptr);
+        if (!g_ctx) g_ctx_failed = true;
+    }
+    return g_ctx;
+}
+
+struct OneMeta  // device-side descriptors of a one-read batch
+{
+    uint64_t src_off, dst_off;
+    uint32_t src_size, dst_cap, result, pad;
+};
+
+// run one read through the batch path: host src -> device -> kernels -> host dst
+vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* dst, vbz_size_t dst_cap, vbz_size_t dev_cap,
+                   const CompressionOptions* o, int sized)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    vbz_gpu_ctx* c = default_ctx();
+    if (!c) return VBZ_DEVICE_ERROR;
+    hipSetDevice(c->device);
+    if (!ensure(c, c->one_in, (size_t)src_size + 64) || !ensure(c, c->one_out, (size_t)dev_cap + 64) ||
+        !ensure(c, c->one_meta, sizeof(OneMeta)))
+        return VBZ_OUT_OF_MEMORY_ERROR;
+    if (!c->pinned) {
+        if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) return VBZ_OUT_OF_MEMORY_ERROR;
+        c->pinned_cap = 256;
+    }
+    OneMeta* hm = (OneMeta*)c->pinned;
+    hm->src_off = 0;
+    hm->dst_off = 0;
+    hm->src_size = src_size;
+    hm->dst_cap = dev_cap;
+    hm->result = VBZ_DEVICE_ERROR;
+    hm->pad = 0;
+    hipStream_t s = c->stream;
+    bool ok = true;
+    if (src_size) ok &= hipMemcpyAsync(c->one_in.p, src, src_size, hipMemcpyHostToDevice, s) == hipSuccess;
+    ok &= hipMemcpyAsync(c->one_meta.p, hm, sizeof(OneMeta), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (!ok) {
+        set_error(c, "host to device copy failed");
+        return VBZ_DEVICE_ERROR;
+    }
+    OneMeta* dm = (OneMeta*)c->one_meta.p;
+    vbz_gpu_batch bt;
+    memset(&bt, 0, sizeof bt);
+    bt.n_reads = 1;
+    bt.src = c->one_in.p;
+    bt.src_off = &dm->src_off;
+    bt.src_size = &dm->src_size;
+    bt.src_bytes = src_size;
+    bt.dst = c->one_out.p;
+    bt.dst_off = &dm->dst_off;
+    bt.dst_cap = &dm->dst_cap;
+    bt.dst_bytes = dev_cap;
+    bt.result = &dm->result;
+    int rc = compress ? compress_batch_impl(c, &bt, o, sized) : decompress_batch_impl(c, &bt, o, sized);
+    if (rc != 0) return VBZ_DEVICE_ERROR;
+    uint32_t result = VBZ_DEVICE_ERROR;
+    if (hipMemcpyAsync(&hm->result, &dm->result, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        set_error(c, "kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
+        return VBZ_DEVICE_ERROR;
+    }
+    result = hm->result;
+    if (result >= VBZ_FIRST_ERROR) return result;
+    if (result > dst_cap) return VBZ_DESTINATION_SIZE_ERROR;
+    if (result && hipMemcpy(dst, c->one_out.p, result, hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error(c, "device to host copy failed");
+        return VBZ_DEVICE_ERROR;
+    }
+    return result;
+}
+
+vbz_size_t max_svb_size(unsigned integer_size, vbz_size_t source_size)
+{
+    // vbz/v0/vbz_streamvbyte.cpp:7-18 == vbz/v1/vbz_streamvbyte.cpp:9-20
+    if (source_size % integer_size != 0) return VBZ_INPUT_SIZE_ERROR;
+    const uint32_t count = source_size / integer_size;
+    return (vbz_size_t)((uint64_t)(count + 3) / 4 + 4ull * count);  // truncation to 32 bits as in the reference
+}
+
+}  // namespace
+
+extern "C" {
+
+bool vbz_is_error(vbz_size_t v) { return v >= VBZ_FIRST_ERROR; }
+
+char const* vbz_error_string(vbz_size_t v)
+{
+    switch (v) {
+    case VBZ_ZSTD_ERROR: return "VBZ_ZSTD_ERROR";
+    case VBZ_INPUT_SIZE_ERROR: return "VBZ_INPUT_SIZE_ERROR";
+    case VBZ_INTEGER_SIZE_ERROR: return "VBZ_INTEGER_SIZE_ERROR";
+    case VBZ_DESTINATION_SIZE_ERROR: return "VBZ_DESTINATION_SIZE_ERROR";
+    case VBZ_STREAMVBYTE_STREAM_ERROR: return "VBZ_STREAMVBYTE_STREAM_ERROR";
+    case VBZ_VERSION_ERROR: return "VBZ_VERSION_ERROR";
+    case VBZ_OUT_OF_MEMORY_ERROR: return "VBZ_OUT_OF_MEMORY_ERROR";
+    case VBZ_DEVICE_ERROR: return "VBZ_DEVICE_ERROR";
+    default: return "VBZ_UNKNOWN_ERROR";
+    }
+}
+
+vbz_size_t vbz_max_compressed_size(vbz_size_t source_size, CompressionOptions const* o)
+{
+    if (!valid_int_size(o)) return VBZ_INTEGER_SIZE_ERROR;
+    vbz_size_t max_size = source_size;
+    if (o->integer_size != 0) {
+        if (o->vbz_version > 1) return VBZ_VERSION_ERROR;
+        max_size = max_svb_size(o->integer_size, max_size);
+        if (vbz_is_error(max_size)) return max_size;
+    }
+    if (o->zstd_compression_level != 0) max_size = (vbz_size_t)zstd_bound(max_size);
+    return max_size + 4;  // always room for the sized header (vbz.cpp:112-113)
+}
+
+vbz_size_t vbz_compress(void const* source, vbz_size_t source_size, void* destination, vbz_size_t destination_capacity,
+                        CompressionOptions const* o)
+{
+    if (!valid_int_size(o)) return VBZ_INTEGER_SIZE_ERROR;
+    if (o->integer_size != 0) {
+        if (o->vbz_version > 1) return VBZ_VERSION_ERROR;
+        const vbz_size_t max_svb = max_svb_size(o->integer_size, source_size);
+        if (vbz_is_error(max_svb)) return max_svb;  // vbz.cpp:153-160
+        if (o->zstd_compression_level == 0 && max_svb > destination_capacity) return VBZ_DESTINATION_SIZE_ERROR;
+    } else if (o->zstd_compression_level == 0 && source_size > destination_capacity) {
+        return VBZ_DESTINATION_SIZE_ERROR;
+    }
+    if (!device_supported(o)) {
+        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
+        return VBZ_DEVICE_ERROR;
+    }
+    const vbz_size_t bound = vbz_max_compressed_size(source_size, o);
+    const vbz_size_t dev_cap = destination_capacity < bound ? destination_capacity : bound;
+    return run_one(true, source, source_size, destination, destination_capacity, dev_cap, o, 0);
+}
+
+vbz_size_t vbz_decompress(void const* source, vbz_size_t source_size, void* destination, vbz_size_t destination_size,
+                          CompressionOptions const* o)
+{
+    if (!valid_int_size(o)) return VBZ_INTEGER_SIZE_ERROR;
+    // the reference checks the version only after the zstd stage (vbz.cpp:282-290); an invalid version
+    // can never succeed, so it is reported up front
+    if (o->integer_size != 0 && o->vbz_version > 1) return VBZ_VERSION_ERROR;
+    if (!device_supported(o)) {
+        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
+        return VBZ_DEVICE_ERROR;
+    }
+    return run_one(false, source, source_size, destination, destination_size, destination_size, o, 0);
+}
+
+vbz_size_t vbz_compress_sized(void const* source, vbz_size_t source_size, void* destination, vbz_size_t destination_capacity,
+                              CompressionOptions const* o)
+{
+    if (!valid_int_size(o)) return VBZ_INTEGER_SIZE_ERROR;
+    if (destination_capacity < 4) return VBZ_DESTINATION_SIZE_ERROR;
+    if (o->integer_size != 0) {
+        if (o->vbz_version > 1) return VBZ_VERSION_ERROR;
+        const vbz_size_t max_svb = max_svb_size(o->integer_size, source_size);
+        if (vbz_is_error(max_svb)) return max_svb;  // NOTE: the reference returns this error + 4 (vbz.cpp:321-329)
+        if (o->zstd_compression_level == 0 && max_svb > destination_capacity - 4) return VBZ_DESTINATION_SIZE_ERROR;
+    } else if (o->zstd_compression_level == 0 && source_size > destination_capacity - 4) {
+        return VBZ_DESTINATION_SIZE_ERROR;
+    }
+    if (!device_supported(o)) {
+        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
+        return VBZ_DEVICE_ERROR;
+    }
+    const vbz_size_t bound = vbz_max_compressed_size(source_size, o);
+    const vbz_size_t dev_cap = destination_capacity < bound ? destination_capacity : bound;
+    return run_one(true, source, source_size, destination, destination_capacity, dev_cap, o, 1);
+}
+
+vbz_size_t vbz_decompress_sized(void const* source, vbz_size_t source_size, void* destination, vbz_size_t destination_capacity,
+                                CompressionOptions const* o)
+{
+    if (!valid_int_size(o)) return VBZ_INTEGER_SIZE_ERROR;
+    if (source_size < 4) return VBZ_INPUT_SIZE_ERROR;
+    uint32_t original;
+    memcpy(&original, source, 4);
+    if (destination_capacity < original) return VBZ_DESTINATION_SIZE_ERROR;
+    if (o->integer_size != 0 && o->vbz_version > 1) return VBZ_VERSION_ERROR;
+    if (!device_supported(o)) {
+        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
+        return VBZ_DEVICE_ERROR;
+    }
+    return run_one(false, source, source_size, destination, destination_capacity, destination_capacity, o, 1);
+}
+
+vbz_size_t vbz_decompressed_size(void const* source, vbz_size_t source_size, CompressionOptions const* o)
+{
+    if (!valid_int_size(o)) return VBZ_INTEGER_SIZE_ERROR;
+    if (source_size < 4) return VBZ_INPUT_SIZE_ERROR;
+    uint32_t original;
+    memcpy(&original, source, 4);
+    return original;
+}
+
+}  // extern "C"

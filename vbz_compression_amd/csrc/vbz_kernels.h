@@ -1,0 +1,105 @@
+// vbz_kernels.h -- internal interface between the C ABI (vbz_api.hip) and the HIP kernels.
+// Not installed; the public surface is include/vbz.h and include/vbz_gpu.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vbzhip {
+
+// vbz error codes (include/vbz.h), usable in device code
+constexpr uint32_t E_ZSTD = 0xFFFFFFFFu;
+constexpr uint32_t E_INPUT_SIZE = 0xFFFFFFFEu;
+constexpr uint32_t E_INTEGER_SIZE = 0xFFFFFFFDu;
+constexpr uint32_t E_DESTINATION_SIZE = 0xFFFFFFFCu;
+constexpr uint32_t E_STREAM = 0xFFFFFFFBu;
+constexpr uint32_t E_VERSION = 0xFFFFFFFAu;
+constexpr uint32_t E_OOM = 0xFFFFFFF9u;
+constexpr uint32_t E_DEVICE = 0xFFFFFFF8u;
+constexpr uint32_t E_FIRST = E_DEVICE;
+
+// One batch of independent reads ("reads" in the reference's vocabulary: one HDF5 chunk each).
+// All pointers are device pointers.  `result[i]` receives the bytes produced or an error code.
+// If `gate` is non-null, reads whose gate[i] is an error code are skipped and the error is kept.
+struct ReadBatch
+{
+    uint32_t n_reads;
+    const uint8_t* src;
+    const uint64_t* src_off;
+    const uint32_t* src_size;
+    uint8_t* dst;
+    const uint64_t* dst_off;
+    const uint32_t* dst_cap;
+    uint32_t* result;
+    const uint32_t* gate;
+};
+
+// ---- streamvbyte stage (svb_kernels.hip) -------------------------------------------------------
+// integer_size in {1,2,4}; zigzag; half = v1 nibble codec (not implemented on the device yet).
+// hdr: 0, or 4 to prepend / skip the sized header (u32 LE original size) in front of the svb stream.
+// strict_cap: apply the reference's worst-case capacity rule (keys + 4 bytes per value) to dst_cap.
+hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, hipStream_t s);
+hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, hipStream_t s);
+
+// ---- zstd-format entropy stage (zstd_encode.hip / zstd_decode.hip) -----------------------------
+// encode: frame content = src read; key_elem = integer size whose key section (ceil(n/4) bytes, n
+// derived from `orig_size[i] / key_elem`) is split into its own blocks; 0 = no split.
+// hdr: 0 or 4 (sized header carrying orig_size[i] in front of the frame).
+// key_bytes (nullable) gives the key-section length per read directly and overrides key_elem.
+hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
+                              uint32_t hdr, hipStream_t s);
+// decode: result[i] = frame content size, E_ZSTD for a malformed frame, or `toosmall_code` when the
+// frame's content size exceeds dst_cap[i].
+hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, hipStream_t s);
+
+// ---- helpers (helpers.hip) ---------------------------------------------------------------------
+// scratch slots for the intermediate svb streams: slot(i) = align16(ceil(raw_size[i]*num/den)+8)+48,
+// off[i] = exclusive scan + 16, cap[i] = slot - 32; gate[i] = E_OOM if the slot exceeds `limit` bytes.
+// gate_is_input: gate[] already holds per-read errors; those reads keep their error and get an empty slot.
+hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mul_num, uint32_t mul_den, uint64_t limit,
+                               uint64_t* off, uint32_t* cap, uint32_t* gate, bool gate_is_input, hipStream_t s);
+// sized decode: read the 4-byte headers -> payload offsets/sizes, original sizes, gate errors
+hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
+                              const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
+                              uint32_t* gate, hipStream_t s);
+// integer_size == 0 && level == 0: per-read copy (reference vbz/vbz.cpp:130-133)
+hipError_t launch_copy_bytes(const ReadBatch& b, uint32_t hdr, hipStream_t s);
+hipError_t launch_synth_lengths(uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len, hipStream_t s);
+hipError_t launch_synth_signal(uint64_t seed, uint64_t first, uint32_t n, uint8_t* dst, const uint64_t* off,
+                               const uint32_t* len, hipStream_t s);
+hipError_t launch_synth_u32(uint64_t seed, uint64_t first, uint32_t n, uint8_t* dst, const uint64_t* off,
+                            const uint32_t* len, hipStream_t s);
+
+// ---- wave / workgroup primitives ---------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a 256-thread workgroup; wsum = 4 words of LDS; returns the exclusive prefix,
+// `total` gets the workgroup sum.  Contains two barriers.
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* wsum, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan_u32(v);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t s = wsum[k];
+        base += (k < w) ? s : 0u;
+        tot += s;
+    }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+}  // namespace vbzhip

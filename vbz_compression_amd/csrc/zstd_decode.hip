@@ -1,0 +1,789 @@
+// zstd_decode.hip -- zstd (RFC 8878) frame decoder for gfx950: the inverse entropy stage of VBZ.
+//
+// Replaces the reference's ZSTD_getFrameContentSize + ZSTD_decompress calls (vbz/vbz.cpp:236-273;
+// external libzstd 1.4.8).  It decodes ANY conforming single frame with a content-size field -- the
+// frames the reference wrote with libzstd (block 0 with FSE-coded sequences, 4-stream Huffman
+// literals, treeless blocks, raw blocks: SURVEY.md section 8a "zstd frame features") as well as the
+// frames of zstd_encode.hip.  oracle/zstd_restate.c is its serial CPU mirror.
+//
+// One wavefront per frame.  Parallelism comes from the format's independent Huffman bit streams:
+// the wave walks the block headers (lane 0 parses from an LDS copy of the header bytes), queues every
+// literals stream of literals-only blocks as a "task", and when 64 tasks are pending (or a block with
+// sequences needs its history) all 64 lanes decode one stream each, table look-ups in LDS.  Frames
+// from zstd_encode.hip keep all 64 lanes busy; libzstd frames offer 4 streams per 128 KiB block.
+// Blocks with sequences are executed in order: lane 0 walks the three FSE state machines, the wave
+// copies literals and matches cooperatively.
+// Algorithmic HBM bytes per svb byte: ~0.67 read + 1 written.
+#include "vbz_kernels.h"
+
+namespace vbzhip {
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr uint32_t BLOCK_MAX = 128u << 10;
+constexpr int HBUF = 768;
+
+struct DecLds
+{
+    uint16_t huf[2][2048];   // two Huffman decoding tables: symbol | nbBits << 8 (a 12-bit table spans both)
+    uint32_t fse[3][512];    // LL, OF, ML decoding tables: symbol | nbBits << 8 | base << 16
+    uint32_t wfse[64];       // FSE table of the Huffman weights (accuracy log <= 6)
+    uint8_t hbuf[HBUF];      // staged header bytes of the current block section
+    uint8_t weights[256];
+    int16_t norm[256];
+    uint16_t symnext[256];
+    uint16_t wstart[256];    // table start of each symbol (Huffman fill)
+    uint32_t t_src[WAVE], t_size[WAVE], t_out[WAVE], t_cnt[WAVE], t_tab[WAVE];  // pending stream tasks
+    uint32_t ctl[24];
+};
+
+// ctl slots
+enum { C_ERR = 0, C_A, C_B, C_C, C_D, C_E, C_F, C_G, C_H, C_I, C_J, C_K };
+
+struct BitReader  // backward bit stream (RFC 8878 4.1): bits are consumed from the last byte down
+{
+    const uint8_t* p;
+    uint32_t nextbyte;  // bytes [0, nextbyte) are not yet loaded
+    uint64_t buf;       // unread bits, left aligned
+    int32_t avail;      // number of valid bits in buf
+    bool over;          // tried to read past the beginning
+
+    __device__ __forceinline__ bool init(const uint8_t* ptr, uint32_t n)
+    {
+        over = false;
+        p = ptr;
+        buf = 0;
+        avail = 0;
+        nextbyte = 0;
+        if (n == 0) return false;
+        const uint32_t last = ptr[n - 1];
+        if (last == 0) return false;
+        const int hb = 31 - __clz((int)last);
+        nextbyte = n - 1;
+        buf = hb ? ((uint64_t)(last & ((1u << hb) - 1u)) << (64 - hb)) : 0ull;
+        avail = hb;
+        refill();
+        return true;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (avail <= 32) {
+            if (nextbyte >= 4) {
+                uint32_t w;
+                __builtin_memcpy(&w, p + nextbyte - 4, 4);
+                buf |= (uint64_t)w << (32 - avail);
+                nextbyte -= 4;
+                avail += 32;
+            } else if (nextbyte > 0) {
+                uint32_t w = 0;
+                for (uint32_t k = 0; k < nextbyte; ++k) w |= (uint32_t)p[k] << (8 * k);
+                const int k8 = 8 * (int)nextbyte;
+                buf |= (uint64_t)w << (64 - avail - k8);
+                avail += k8;
+                nextbyte = 0;
+            }
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int nb) const { return nb ? (uint32_t)(buf >> (64 - nb)) : 0u; }
+    __device__ __forceinline__ void skip(int nb)
+    {
+        if (nb > avail) {
+            over = true;
+            buf = 0;
+            avail = 0;
+        } else {
+            buf <<= nb;
+            avail -= nb;
+        }
+    }
+    __device__ __forceinline__ uint32_t read(int nb)  // nb <= 32
+    {
+        refill();
+        const uint32_t v = peek(nb);
+        skip(nb);
+        return v;
+    }
+    __device__ __forceinline__ bool finished() const { return !over && avail == 0 && nextbyte == 0; }
+};
+
+__device__ __forceinline__ int hbit(uint32_t v) { return 31 - __clz((int)v); }
+
+// FSE table description (RFC 8878 4.1.1) read from LDS bytes; lane 0 only.
+// returns bytes consumed or -1; fills L.norm[0..nsym)
+__device__ int read_ncount(DecLds& L, const uint8_t* p, int n, int max_symbol, int max_log, int* out_log, int* out_nsym)
+{
+    if (n < 1) return -1;
+    auto bits = [&](uint32_t bitpos, int k) -> uint32_t {
+        uint32_t v = 0;
+        const uint32_t by = bitpos >> 3;
+        // gather up to 4 bytes (k <= 10 + 7 shift bits)
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t idx = by + (uint32_t)i;
+            v |= (idx < (uint32_t)n ? (uint32_t)p[idx] : 0u) << (8 * i);
+        }
+        return (v >> (bitpos & 7u)) & ((1u << k) - 1u);
+    };
+    const int log = (int)(p[0] & 0xF) + 5;
+    if (log > max_log) return -1;
+    uint32_t bitpos = 4;
+    int remaining = (1 << log) + 1, threshold = 1 << log, nbits = log + 1, sym = 0;
+    bool prev0 = false;
+    while (remaining > 1 && sym <= max_symbol) {
+        if (prev0) {
+            for (;;) {
+                const uint32_t rr = bits(bitpos, 2);
+                bitpos += 2;
+                for (uint32_t k = 0; k < rr; ++k) {
+                    if (sym > max_symbol) return -1;
+                    L.norm[sym++] = 0;
+                }
+                if (rr != 3) break;
+            }
+            prev0 = false;
+            if (sym > max_symbol) break;
+            continue;
+        }
+        const int max = (2 * threshold - 1) - remaining;
+        const uint32_t v = bits(bitpos, nbits);
+        int count;
+        if ((int)(v & (uint32_t)(threshold - 1)) < max) {
+            count = (int)(v & (uint32_t)(threshold - 1));
+            bitpos += (uint32_t)(nbits - 1);
+        } else {
+            count = (int)(v & (uint32_t)(2 * threshold - 1));
+            if (count >= threshold) count -= max;
+            bitpos += (uint32_t)nbits;
+        }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        L.norm[sym++] = (int16_t)count;
+        prev0 = (count == 0);
+        while (remaining < threshold) {
+            nbits--;
+            threshold >>= 1;
+        }
+    }
+    if (remaining != 1) return -1;
+    if (sym > max_symbol + 1) return -1;
+    const int used = (int)((bitpos + 7) >> 3);
+    if (used > n) return -1;
+    *out_log = log;
+    *out_nsym = sym;
+    return used;
+}
+
+// FSE decoding table from L.norm (lane 0 only): RFC 8878 4.1.1
+__device__ int fse_build(DecLds& L, uint32_t* tab, int nsym, int log)
+{
+    const int size = 1 << log;
+    int high = size - 1;
+    for (int s = 0; s < nsym; ++s) {
+        if (L.norm[s] == -1) {
+            tab[high--] = (uint32_t)s;
+            L.symnext[s] = 1;
+        } else {
+            L.symnext[s] = (uint16_t)L.norm[s];
+        }
+    }
+    const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    int pos = 0;
+    for (int s = 0; s < nsym; ++s) {
+        for (int i = 0; i < L.norm[s]; ++i) {
+            tab[pos] = (uint32_t)s;
+            do {
+                pos = (pos + step) & mask;
+            } while (pos > high);
+        }
+    }
+    if (pos != 0) return -1;
+    for (int u = 0; u < size; ++u) {
+        const uint32_t s = tab[u] & 0xFF;
+        const uint32_t ns = L.symnext[s]++;
+        const int nb = log - hbit(ns);
+        tab[u] = s | ((uint32_t)nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFFu) << 16);
+    }
+    return 0;
+}
+
+__device__ const int16_t LL_DEFAULT[36] = { 4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
+                                            2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1 };
+__device__ const int16_t ML_DEFAULT[53] = { 1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                            1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1 };
+__device__ const int16_t OF_DEFAULT[29] = { 1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1 };
+__device__ const uint32_t LL_BASE[36] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
+                                          20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536 };
+__device__ const uint8_t LL_BITS[36] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
+                                         1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
+__device__ const uint32_t ML_BASE[53] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
+                                          21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
+                                          43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539 };
+__device__ const uint8_t ML_BITS[53] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                         0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
+
+// one sequence-table definition (lane 0): mode 0 predefined, 1 RLE, 2 FSE, 3 repeat.
+// returns bytes consumed from p, or -1
+__device__ int seq_table(DecLds& L, uint32_t* tab, int* log_io, bool* have, int mode, const uint8_t* p, int n,
+                         const int16_t* def, int def_n, int def_log, int max_sym, int max_log)
+{
+    if (mode == 0) {
+        for (int i = 0; i < def_n; ++i) L.norm[i] = def[i];
+        if (fse_build(L, tab, def_n, def_log) != 0) return -1;
+        *log_io = def_log;
+        *have = true;
+        return 0;
+    }
+    if (mode == 1) {
+        if (n < 1 || p[0] > max_sym) return -1;
+        tab[0] = p[0];
+        *log_io = 0;
+        *have = true;
+        return 1;
+    }
+    if (mode == 2) {
+        int log, nsym;
+        const int used = read_ncount(L, p, n, max_sym, max_log, &log, &nsym);
+        if (used < 0) return -1;
+        if (fse_build(L, tab, nsym, log) != 0) return -1;
+        *log_io = log;
+        *have = true;
+        return used;
+    }
+    return *have ? 0 : -1;
+}
+
+// Huffman tree description -> weights in L.weights (lane 0). returns bytes consumed or -1; sets nw/log
+__device__ int huf_read_weights(DecLds& L, const uint8_t* p, int n, int* out_nw, int* out_log)
+{
+    if (n < 1) return -1;
+    int nw = 0, used;
+    const int hb = p[0];
+    if (hb >= 128) {
+        nw = hb - 127;
+        used = 1 + (nw + 1) / 2;
+        if (used > n) return -1;
+        for (int i = 0; i < nw; ++i) L.weights[i] = (i & 1) ? (p[1 + i / 2] & 0xF) : (p[1 + i / 2] >> 4);
+    } else {
+        used = 1 + hb;
+        if (hb == 0 || used > n) return -1;
+        int log, nsym;
+        const int hdr = read_ncount(L, p + 1, hb, 255, 6, &log, &nsym);
+        if (hdr < 0) return -1;
+        uint32_t* tab = L.wfse;
+        if (fse_build(L, tab, nsym, log) != 0) return -1;
+        // two interleaved FSE states over an LDS-resident backward bit stream
+        const uint8_t* q = p + 1 + hdr;
+        const int qn = hb - hdr;
+        if (qn < 1 || q[qn - 1] == 0) return -1;
+        int pos = (qn - 1) * 8 + hbit(q[qn - 1]);  // unread bits
+        auto rd = [&](int nb) -> uint32_t {
+            uint32_t v = 0;
+            for (int i = 0; i < nb; ++i) {
+                const int bit = pos - 1 - i;
+                v = (v << 1) | (bit >= 0 ? ((uint32_t)q[bit >> 3] >> (bit & 7)) & 1u : 0u);
+            }
+            pos -= nb;
+            return v;
+        };
+        uint32_t s1 = rd(log), s2 = rd(log);
+        if (pos < 0) return -1;
+        for (;;) {
+            if (nw > 253) return -1;
+            uint32_t e = tab[s1];
+            L.weights[nw++] = (uint8_t)e;
+            s1 = (e >> 16) + rd((int)((e >> 8) & 0xFF));
+            if (pos < 0) { L.weights[nw++] = (uint8_t)tab[s2]; break; }
+            if (nw > 253) return -1;
+            e = tab[s2];
+            L.weights[nw++] = (uint8_t)e;
+            s2 = (e >> 16) + rd((int)((e >> 8) & 0xFF));
+            if (pos < 0) { L.weights[nw++] = (uint8_t)tab[s1]; break; }
+        }
+    }
+    uint32_t total = 0;
+    for (int i = 0; i < nw; ++i) {
+        if (L.weights[i] >= 12) return -1;
+        total += L.weights[i] ? (1u << (L.weights[i] - 1)) : 0u;
+    }
+    if (total == 0) return -1;
+    const int log = hbit(total) + 1;
+    if (log > 12) return -1;
+    const uint32_t rest = (1u << log) - total;
+    if (rest & (rest - 1)) return -1;
+    L.weights[nw++] = (uint8_t)(hbit(rest) + 1);
+    int r1 = 0;
+    for (int i = 0; i < nw; ++i) r1 += (L.weights[i] == 1);
+    if (r1 < 2 || (r1 & 1)) return -1;
+    // table start of every symbol: increasing weight, then increasing symbol value
+    uint32_t idx = 0;
+    for (int wt = 1; wt <= log; ++wt)
+        for (int s = 0; s < nw; ++s)
+            if (L.weights[s] == wt) {
+                L.wstart[s] = (uint16_t)idx;
+                idx += 1u << (wt - 1);
+            }
+    *out_nw = nw;
+    *out_log = log;
+    return used;
+}
+
+// all lanes: decode the queued Huffman streams, one per lane.  Returns true if any stream is corrupt.
+__device__ bool flush_tasks(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
+{
+    bool bad = false;
+    if ((uint32_t)lane < ntask) {
+        const uint8_t* p = src + L.t_src[lane];
+        const uint32_t n = L.t_size[lane];
+        uint8_t* o = dst + L.t_out[lane];
+        uint32_t cnt = L.t_cnt[lane];
+        const uint32_t tab = L.t_tab[lane];
+        const int log = (int)(tab >> 16);
+        const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
+        BitReader br;
+        if (!br.init(p, n)) {
+            bad = true;
+        } else {
+            while (cnt >= 4) {
+                uint32_t e0, e1, e2, e3;
+                br.refill();
+                e0 = T[br.peek(log)]; br.skip((int)(e0 >> 8));
+                e1 = T[br.peek(log)]; br.skip((int)(e1 >> 8));
+                br.refill();
+                e2 = T[br.peek(log)]; br.skip((int)(e2 >> 8));
+                e3 = T[br.peek(log)]; br.skip((int)(e3 >> 8));
+                const uint32_t w = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+                __builtin_memcpy(o, &w, 4);
+                o += 4;
+                cnt -= 4;
+            }
+            while (cnt > 0) {
+                br.refill();
+                const uint32_t e = T[br.peek(log)];
+                br.skip((int)(e >> 8));
+                *o++ = (uint8_t)e;
+                --cnt;
+            }
+            if (!br.finished()) bad = true;
+        }
+    }
+    ntask = 0;
+    __syncthreads();  // also makes the decoded bytes visible to the whole wave (vmcnt drain)
+    return __any(bad);
+}
+
+__device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint32_t n, int lane)
+{
+    for (uint32_t i = lane; i < n; i += WAVE) lds[i] = g[i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code)
+{
+    __shared__ DecLds L;
+    const uint32_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (b.gate && b.gate[r] >= E_FIRST) {
+        if (lane == 0) b.result[r] = b.gate[r];
+        return;
+    }
+    const uint8_t* src = b.src + b.src_off[r];
+    const uint32_t n = b.src_size[r];
+    if (n >= E_FIRST) {
+        if (lane == 0) b.result[r] = n;
+        return;
+    }
+    uint8_t* dst = b.dst + b.dst_off[r];
+    const uint32_t cap = b.dst_cap[r];
+#define FAIL()                                   \
+    do {                                         \
+        if (lane == 0) b.result[r] = E_ZSTD;     \
+        return;                                  \
+    } while (0)
+
+    // ---- frame header (RFC 8878 3.1.1.1)
+    stage_bytes(L.hbuf, src, n < 32 ? n : 32, lane);
+    if (lane == 0) {
+        uint32_t err = 0, pos = 0;
+        uint64_t fcs = 0, window = 0;
+        const uint8_t* h = L.hbuf;
+        if (n < 6) err = 1;
+        if (!err) {
+            const uint32_t magic = h[0] | (h[1] << 8) | (h[2] << 16) | ((uint32_t)h[3] << 24);
+            const uint32_t fhd = h[4];
+            const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+            if (magic != 0xFD2FB528u || (fhd & 0x08) || did != 0) err = 1;
+            pos = 5;
+            if (!single) {
+                const uint32_t wd = h[pos++];
+                const int wlog = 10 + (int)(wd >> 3);
+                if (wlog > 31) err = 1;
+                window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
+            }
+            const int fsz = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
+            if (fsz == 0) err = 1;  // unknown content size: the reference rejects it too (vbz.cpp:236-240)
+            if (pos + fsz > n) err = 1;
+            if (!err) {
+                for (int i = 0; i < fsz; ++i) fcs |= (uint64_t)h[pos + i] << (8 * i);
+                if (fsz == 2) fcs += 256;
+                pos += fsz;
+                if (single) window = fcs;
+                if (!err && fcs > cap) err = 2;  // dstSize_tooSmall
+            }
+            L.ctl[C_A] = pos;
+            L.ctl[C_B] = (uint32_t)fcs;
+            L.ctl[C_C] = (uint32_t)(window < BLOCK_MAX ? window : BLOCK_MAX);
+            L.ctl[C_D] = (fhd >> 2) & 1;
+        }
+        L.ctl[C_ERR] = err;
+    }
+    __syncthreads();
+    if (L.ctl[C_ERR] == 2) {
+        if (lane == 0) b.result[r] = toosmall_code;
+        return;
+    }
+    if (L.ctl[C_ERR]) FAIL();
+    uint32_t pos = L.ctl[C_A];
+    const uint32_t fcs = L.ctl[C_B];
+    const uint32_t block_max = L.ctl[C_C];
+    const uint32_t has_checksum = L.ctl[C_D];
+
+    uint32_t opos = 0, ntask = 0;
+    bool huf_valid = false;
+    int cur_slot = 0, cur_log = 0;      // current Huffman table: slot and table log
+    bool have_ll = false, have_of = false, have_ml = false;
+    int log_ll = 0, log_of = 0, log_ml = 0;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;  // lane 0 only
+
+    for (;;) {
+        if (pos + 3 > n) FAIL();
+        const uint32_t bh = src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+        pos += 3;
+        const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3) FAIL();
+        if (btype == 0) {  // Raw_Block
+            if (bsize > block_max || pos + bsize > n || (uint64_t)opos + bsize > fcs) FAIL();
+            for (uint32_t i = lane; i < bsize; i += WAVE) dst[opos + i] = src[pos + i];
+            opos += bsize;
+            pos += bsize;
+        } else if (btype == 1) {  // RLE_Block
+            if (bsize > block_max || pos + 1 > n || (uint64_t)opos + bsize > fcs) FAIL();
+            const uint8_t v = src[pos];
+            for (uint32_t i = lane; i < bsize; i += WAVE) dst[opos + i] = v;
+            opos += bsize;
+            pos += 1;
+        } else {  // Compressed_Block
+            if (bsize >= BLOCK_MAX || pos + bsize > n || bsize < 2) FAIL();
+            const uint8_t* blk = src + pos;
+            stage_bytes(L.hbuf, blk, bsize < HBUF ? bsize : HBUF, lane);
+            // ---- literals section header (3.1.1.3.1.1) and, for type 2, the tree description
+            if (lane == 0) {
+                uint32_t err = 0;
+                const uint8_t* h = L.hbuf;
+                const uint32_t type = h[0] & 3, fmt = (h[0] >> 2) & 3;
+                uint32_t lh = 0, regen = 0, csize = 0, streams = 1, tree_used = 0, nw = 0, tlog = 0;
+                if (type < 2) {
+                    if (fmt == 0 || fmt == 2) { lh = 1; regen = h[0] >> 3; }
+                    else if (fmt == 1) { lh = 2; regen = (h[0] >> 4) | ((uint32_t)h[1] << 4); }
+                    else { lh = 3; regen = (h[0] >> 4) | ((uint32_t)h[1] << 4) | ((uint32_t)h[2] << 12); }
+                    if (lh > bsize) err = 1;
+                    csize = type == 0 ? regen : 1;
+                } else {
+                    if (bsize < 5) err = 1;  // libzstd: srcSize >= 5 for compressed literals
+                    const uint64_t v = h[0] | ((uint64_t)h[1] << 8) | ((uint64_t)h[2] << 16) | ((uint64_t)h[3] << 24) |
+                                       ((uint64_t)h[4] << 32);
+                    if (fmt < 2) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; streams = fmt == 0 ? 1 : 4; }
+                    else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; streams = 4; }
+                    else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; streams = 4; }
+                    if (regen == 0 || csize == 0) err = 1;
+                }
+                if (regen > BLOCK_MAX) err = 1;
+                if ((uint64_t)lh + csize > bsize) err = 1;
+                if (!err && type == 2) {
+                    int inw = 0, ilog = 0;
+                    const uint32_t avail = csize < (uint32_t)(HBUF - 8) ? csize : (uint32_t)(HBUF - 8);
+                    const int used = huf_read_weights(L, h + lh, (int)avail, &inw, &ilog);
+                    if (used < 0) err = 1;
+                    tree_used = (uint32_t)used;
+                    nw = (uint32_t)inw;
+                    tlog = (uint32_t)ilog;
+                } else if (!err && type == 3 && !huf_valid) {
+                    err = 1;
+                }
+                L.ctl[C_ERR] = err;
+                L.ctl[C_A] = type;
+                L.ctl[C_B] = lh;
+                L.ctl[C_C] = regen;
+                L.ctl[C_D] = csize;
+                L.ctl[C_E] = streams;
+                L.ctl[C_F] = tree_used;
+                L.ctl[C_G] = nw;
+                L.ctl[C_H] = tlog;
+            }
+            __syncthreads();
+            if (L.ctl[C_ERR]) FAIL();
+            const uint32_t ltype = L.ctl[C_A], lh = L.ctl[C_B], regen = L.ctl[C_C], csize = L.ctl[C_D];
+            const uint32_t streams = L.ctl[C_E], tree_used = L.ctl[C_F], nw = L.ctl[C_G], tlog = L.ctl[C_H];
+            if (ltype == 2) {
+                // new Huffman table: pick the slot not used by the current table; pending tasks that
+                // still reference the slot we are about to overwrite must run first
+                int slot = huf_valid ? 1 - cur_slot : 0;
+                bool clash = (tlog == 12) || (huf_valid && cur_log == 12);
+                for (uint32_t t = 0; t < ntask && !clash; ++t)
+                    clash = ((L.t_tab[t] & 0xFFFF) == (uint32_t)slot * 2048u);
+                if (clash && ntask) {
+                    if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+                }
+                if (tlog == 12) slot = 0;
+                uint16_t* T = &L.huf[0][0] + slot * 2048;
+                for (uint32_t s = 0; s < nw; ++s) {  // uniform loop; the wave fills each symbol's range
+                    const uint32_t wt = L.weights[s];
+                    if (wt == 0) continue;
+                    const uint32_t len = 1u << (wt - 1), st = L.wstart[s];
+                    const uint16_t ent = (uint16_t)(s | ((tlog + 1 - wt) << 8));
+                    for (uint32_t i = lane; i < len; i += WAVE) T[st + i] = ent;
+                }
+                __syncthreads();
+                huf_valid = true;
+                cur_slot = slot;
+                cur_log = (int)tlog;
+            }
+            // ---- sequences section header (3.1.1.3.2.1)
+            const uint32_t lit_end = lh + csize;  // offset of the sequences section in the block
+            if (lit_end >= bsize) FAIL();
+            const uint8_t* sq = blk + lit_end;
+            const uint32_t sqn = bsize - lit_end;
+            stage_bytes(L.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
+            if (lane == 0) {
+                uint32_t err = 0, nseq = 0, used = 0;
+                const uint8_t* h = L.hbuf;
+                const int hn = (int)(sqn < HBUF ? sqn : HBUF);
+                nseq = h[0];
+                used = 1;
+                if (nseq >= 128) {
+                    if (nseq == 255) {
+                        if (hn < 3) err = 1; else { nseq = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
+                    } else {
+                        if (hn < 2) err = 1; else { nseq = ((nseq - 128) << 8) + h[1]; used = 2; }
+                    }
+                }
+                if (!err && nseq == 0) {
+                    if (used != sqn) err = 1;
+                } else if (!err) {
+                    if ((int)used >= hn) err = 1;
+                    if (!err) {
+                        const uint32_t modes = h[used++];
+                        if (modes & 3) err = 1;
+                        int u;
+                        if (!err) {
+                            u = seq_table(L, L.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err) {
+                            u = seq_table(L, L.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err) {
+                            u = seq_table(L, L.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err && used >= sqn) err = 1;
+                    }
+                }
+                L.ctl[C_ERR] = err;
+                L.ctl[C_I] = nseq;
+                L.ctl[C_J] = used;
+            }
+            __syncthreads();
+            if (L.ctl[C_ERR]) FAIL();
+            const uint32_t nseq = L.ctl[C_I], sq_used = L.ctl[C_J];
+            if ((uint64_t)opos + regen > fcs) FAIL();
+            // ---- literals: where do they go?
+            //   no sequences : straight to the output (Huffman streams become pending tasks)
+            //   sequences    : Huffman literals are staged right-aligned at the end of the frame's
+            //                  output, where the growing output can never overtake the unread part
+            const uint32_t lit_dst = nseq == 0 ? opos : fcs - regen;
+            const uint8_t* lit_src = blk + lh;  // raw literals are read in place
+            if (ltype >= 2) {
+                const uint8_t* q = blk + lh + tree_used;
+                uint32_t qn = csize - tree_used;
+                if (ntask + streams > WAVE) {
+                    if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+                }
+                const uint32_t tabref = (uint32_t)cur_slot * 2048u | ((uint32_t)cur_log << 16);
+                if (streams == 1) {
+                    if (lane == 0) {
+                        L.t_src[ntask] = (uint32_t)(q - src);
+                        L.t_size[ntask] = qn;
+                        L.t_out[ntask] = lit_dst;
+                        L.t_cnt[ntask] = regen;
+                        L.t_tab[ntask] = tabref;
+                    }
+                    ntask += 1;
+                } else {
+                    if (qn < 10) FAIL();
+                    const uint32_t s1 = q[0] | ((uint32_t)q[1] << 8), s2 = q[2] | ((uint32_t)q[3] << 8), s3 = q[4] | ((uint32_t)q[5] << 8);
+                    q += 6;
+                    qn -= 6;
+                    if (s1 + s2 + s3 > qn) FAIL();
+                    const uint32_t s4 = qn - s1 - s2 - s3;
+                    const uint32_t seg = (regen + 3) >> 2;
+                    if (seg * 3 > regen) FAIL();
+                    if (lane < 4) {
+                        const uint32_t so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
+                        const uint32_t sz = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : s4));
+                        L.t_src[ntask + lane] = (uint32_t)(q - src) + so;
+                        L.t_size[ntask + lane] = sz;
+                        L.t_out[ntask + lane] = lit_dst + (uint32_t)lane * seg;
+                        L.t_cnt[ntask + lane] = lane < 3 ? seg : regen - 3 * seg;
+                        L.t_tab[ntask + lane] = tabref;
+                    }
+                    ntask += 4;
+                }
+                __syncthreads();
+            }
+            if (nseq == 0) {
+                if (ltype == 0) {
+                    for (uint32_t i = lane; i < regen; i += WAVE) dst[opos + i] = lit_src[i];
+                } else if (ltype == 1) {
+                    const uint8_t v = lit_src[0];
+                    for (uint32_t i = lane; i < regen; i += WAVE) dst[opos + i] = v;
+                }
+                if (regen > block_max) FAIL();
+                opos += regen;
+            } else {
+                // everything decoded so far must be in memory before matches can read it
+                if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+                const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
+                const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
+                const uint8_t* bs = sq + sq_used;
+                const uint32_t bsn = sqn - sq_used;
+                BitReader br;
+                uint32_t sl = 0, so = 0, sm = 0;
+                uint32_t err = 0;
+                if (lane == 0) {
+                    if (!br.init(bs, bsn)) err = 1;
+                    if (!err) {
+                        sl = br.read(log_ll);
+                        so = br.read(log_of);
+                        sm = br.read(log_ml);
+                        if (br.over) err = 1;
+                    }
+                }
+                if (__shfl((int)err, 0, 64)) FAIL();
+                uint32_t lpos = 0;
+                const uint32_t block_start = opos;
+                uint32_t safe = opos;  // output below this position is known to be in memory
+                for (uint32_t i = 0; i < nseq; ++i) {
+                    uint32_t llen = 0, mlen = 0, offset = 0;
+                    if (lane == 0) {
+                        const uint32_t el = L.fse[0][sl], eo = L.fse[1][so], em = L.fse[2][sm];
+                        const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
+                        if (lc > 35 || mc > 52 || oc > 31) err = 1;
+                        if (!err) {
+                            const uint32_t ofv = (oc ? (1u << oc) : 1u) + (oc ? br.read((int)oc) : 0u);
+                            mlen = ML_BASE[mc] + (ML_BITS[mc] ? br.read(ML_BITS[mc]) : 0u);
+                            llen = LL_BASE[lc] + (LL_BITS[lc] ? br.read(LL_BITS[lc]) : 0u);
+                            if (ofv > 3) {
+                                offset = ofv - 3;
+                                rep2 = rep1; rep1 = rep0; rep0 = offset;
+                            } else {
+                                const uint32_t idx = ofv - 1 + (llen == 0 ? 1u : 0u);
+                                if (idx == 0) {
+                                    offset = rep0;
+                                } else {
+                                    offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                                    if (offset == 0) offset = 1;  // libzstd forces an invalid 0 to 1
+                                    if (idx > 1) rep2 = rep1;
+                                    rep1 = rep0;
+                                    rep0 = offset;
+                                }
+                            }
+                            if (i + 1 < nseq) {
+                                sl = (el >> 16) + br.read((int)((el >> 8) & 0xFF));
+                                sm = (em >> 16) + br.read((int)((em >> 8) & 0xFF));
+                                so = (eo >> 16) + br.read((int)((eo >> 8) & 0xFF));
+                            }
+                            if (br.over) err = 1;
+                        }
+                    }
+                    llen = (uint32_t)__shfl((int)llen, 0, 64);
+                    mlen = (uint32_t)__shfl((int)mlen, 0, 64);
+                    offset = (uint32_t)__shfl((int)offset, 0, 64);
+                    if (__shfl((int)err, 0, 64)) FAIL();
+                    if (lpos + llen > regen) FAIL();
+                    if ((uint64_t)opos + llen + mlen > fcs) FAIL();
+                    if (ltype == 1) {
+                        for (uint32_t k = lane; k < llen; k += WAVE) dst[opos + k] = rle_byte;
+                    } else {
+                        for (uint32_t k = lane; k < llen; k += WAVE) dst[opos + k] = litp[lpos + k];
+                    }
+                    opos += llen;
+                    lpos += llen;
+                    if (offset > opos) FAIL();
+                    const uint32_t from = opos - offset;
+                    const uint32_t span = offset < mlen ? offset : mlen;
+                    if (from + span > safe) {
+                        __syncthreads();  // drain this wave's stores before reading them back
+                        safe = opos;
+                    }
+                    if (offset >= mlen) {
+                        for (uint32_t k = lane; k < mlen; k += WAVE) dst[opos + k] = dst[from + k];
+                    } else {
+                        for (uint32_t k = lane; k < mlen; k += WAVE) dst[opos + k] = dst[from + (k % offset)];
+                    }
+                    opos += mlen;
+                    if (opos - block_start > BLOCK_MAX) FAIL();
+                }
+                if (lane == 0 && !br.finished()) err = 1;
+                if (__shfl((int)err, 0, 64)) FAIL();
+                // remaining literals
+                const uint32_t rest = regen - lpos;
+                if ((uint64_t)opos + rest > fcs) FAIL();
+                if (ltype == 1) {
+                    for (uint32_t k = lane; k < rest; k += WAVE) dst[opos + k] = rle_byte;
+                } else {
+                    // source and destination may overlap when the staged literals sit at the very end
+                    // of the frame: then they are already in place (from == to) or strictly above
+                    const uint8_t* from = litp + lpos;
+                    uint8_t* to = dst + opos;
+                    if (from != to) {
+                        for (uint32_t k0 = 0; k0 < rest; k0 += WAVE) {
+                            const uint32_t k = k0 + lane;
+                            uint8_t v = 0;
+                            if (k < rest) v = from[k];
+                            __syncthreads();
+                            if (k < rest) to[k] = v;
+                        }
+                    }
+                }
+                opos += rest;
+                if (opos - block_start > BLOCK_MAX || opos - block_start > block_max) FAIL();
+                __syncthreads();
+            }
+            pos += bsize;
+        }
+        if (last) break;
+    }
+    if (ntask) {
+        if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+    }
+    if (has_checksum) {
+        if (pos + 4 > n) FAIL();
+        pos += 4;  // xxh64 of the content: not verified
+    }
+    if (pos != n) FAIL();   // one frame per buffer (what vbz writes)
+    if (opos != fcs) FAIL();
+    if (lane == 0) b.result[r] = fcs;
+#undef FAIL
+}
+
+}  // namespace
+
+hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    hipLaunchKernelGGL(zstd_decode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code);
+    return hipGetLastError();
+}
+
+}  // namespace vbzhip

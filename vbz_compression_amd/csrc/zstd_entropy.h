@@ -1,0 +1,561 @@
+// zstd_entropy.h -- serial table construction for the zstd-format entropy stage.
+//
+// These are the small, inherently serial pieces of the encoder that one lane executes per frame
+// region (a few hundred steps over <= 256 symbols): length-limited Huffman code construction,
+// canonical code assignment, and the Huffman tree description (weights, FSE-compressed or direct).
+// They are plain integer functions over caller-provided workspaces so the same code runs on a
+// gfx950 lane (workspace in LDS) and under g++ in the CPU unit tests (tests/test_entropy_host.py).
+//
+// The zstd format is RFC 8878; the construction below follows the published reference encoder's
+// choices (facebook/zstd lib/compress/huf_compress.c and fse_compress.c, the library the reference
+// links as zstd/1.4.8: CMakeLists.txt:92-93) so that, for the same byte histogram, the code lengths
+// and the tree description are the ones libzstd emits ("T4" in SURVEY.md section 7).
+#pragma once
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define VBZ_HD __host__ __device__ __forceinline__
+#define VBZ_HDN __host__ __device__
+#else
+#define VBZ_HD inline
+#define VBZ_HDN inline
+#endif
+
+namespace vbzhip {
+
+constexpr int HUF_MAX_BITS = 11;      // zstd's HUF_TABLELOG_DEFAULT: literal codes are at most 11 bits
+constexpr int HUF_ABS_MAX_BITS = 12;  // HUF_TABLELOG_MAX
+constexpr uint32_t HUF_NO_SYMBOL = 0xF0F0F0F0u;
+
+VBZ_HD int hb32(uint32_t v)  // index of the highest set bit, v != 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 31 - __clz((int)v);
+#else
+    return 31 - __builtin_clz(v);
+#endif
+}
+
+struct HufNode
+{
+    uint32_t count;
+    uint16_t parent;
+    uint8_t byte;
+    uint8_t nbBits;
+};
+
+// workspace for huf_build: node[0] is the sentinel in front of the 512-entry node table
+struct HufBuildWksp
+{
+    HufNode node[513];
+    uint32_t rankBase[33];
+    uint32_t rankCur[33];
+};
+
+// optimal table log (zstd FSE_optimalTableLog_internal)
+VBZ_HD uint32_t optimal_table_log(uint32_t maxTableLog, uint32_t srcSize, uint32_t maxSymbolValue, uint32_t minus)
+{
+    uint32_t maxBitsSrc = (uint32_t)hb32(srcSize - 1) - minus;
+    uint32_t tableLog = maxTableLog;
+    uint32_t minBitsSrc = (uint32_t)hb32(srcSize) + 1;
+    uint32_t minBitsSymbols = (uint32_t)hb32(maxSymbolValue) + 2;
+    uint32_t minBits = minBitsSrc < minBitsSymbols ? minBitsSrc : minBitsSymbols;
+    if (tableLog == 0) tableLog = 11;
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < 5) tableLog = 5;
+    if (tableLog > 12) tableLog = 12;
+    return tableLog;
+}
+
+// Enforce a maximum code length on a sorted node list (zstd HUF_setMaxHeight).
+VBZ_HDN uint32_t huf_set_max_height(HufNode* huffNode, uint32_t lastNonNull, uint32_t maxNbBits)
+{
+    const uint32_t largestBits = huffNode[lastNonNull].nbBits;
+    if (largestBits <= maxNbBits) return largestBits;
+    int totalCost = 0;
+    const uint32_t baseCost = 1u << (largestBits - maxNbBits);
+    int n = (int)lastNonNull;
+    while (huffNode[n].nbBits > maxNbBits) {
+        totalCost += (int)(baseCost - (1u << (largestBits - huffNode[n].nbBits)));
+        huffNode[n].nbBits = (uint8_t)maxNbBits;
+        n--;
+    }
+    while (huffNode[n].nbBits == maxNbBits) n--;
+    totalCost >>= (largestBits - maxNbBits);
+    uint32_t rankLast[HUF_ABS_MAX_BITS + 2];
+    for (int i = 0; i < HUF_ABS_MAX_BITS + 2; ++i) rankLast[i] = HUF_NO_SYMBOL;
+    {
+        uint32_t currentNbBits = maxNbBits;
+        for (int pos = n; pos >= 0; pos--) {
+            if (huffNode[pos].nbBits >= currentNbBits) continue;
+            currentNbBits = huffNode[pos].nbBits;
+            rankLast[maxNbBits - currentNbBits] = (uint32_t)pos;
+        }
+    }
+    while (totalCost > 0) {
+        uint32_t nBitsToDecrease = (uint32_t)hb32((uint32_t)totalCost) + 1;
+        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+            uint32_t highPos = rankLast[nBitsToDecrease];
+            uint32_t lowPos = rankLast[nBitsToDecrease - 1];
+            if (highPos == HUF_NO_SYMBOL) continue;
+            if (lowPos == HUF_NO_SYMBOL) break;
+            uint32_t highTotal = huffNode[highPos].count;
+            uint32_t lowTotal = 2 * huffNode[lowPos].count;
+            if (highTotal <= lowTotal) break;
+        }
+        while ((nBitsToDecrease <= HUF_ABS_MAX_BITS) && (rankLast[nBitsToDecrease] == HUF_NO_SYMBOL)) nBitsToDecrease++;
+        totalCost -= 1 << (nBitsToDecrease - 1);
+        if (rankLast[nBitsToDecrease - 1] == HUF_NO_SYMBOL) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+        huffNode[rankLast[nBitsToDecrease]].nbBits++;
+        if (rankLast[nBitsToDecrease] == 0) {
+            rankLast[nBitsToDecrease] = HUF_NO_SYMBOL;
+        } else {
+            rankLast[nBitsToDecrease]--;
+            if (huffNode[rankLast[nBitsToDecrease]].nbBits != maxNbBits - nBitsToDecrease)
+                rankLast[nBitsToDecrease] = HUF_NO_SYMBOL;
+        }
+    }
+    while (totalCost < 0) {
+        if (rankLast[1] == HUF_NO_SYMBOL) {
+            while (huffNode[n].nbBits == maxNbBits) n--;
+            huffNode[n + 1].nbBits--;
+            rankLast[1] = (uint32_t)(n + 1);
+            totalCost++;
+            continue;
+        }
+        huffNode[rankLast[1] + 1].nbBits--;
+        rankLast[1]++;
+        totalCost++;
+    }
+    return maxNbBits;
+}
+
+// Build a length-limited canonical Huffman code from a histogram (zstd HUF_buildCTable_wksp).
+//   count[0..maxSymbolValue], count[maxSymbolValue] != 0, at least two non-zero counts.
+//   nbBits[s] / code[s] for s <= maxSymbolValue (0 bits = symbol absent).  Returns the table log.
+VBZ_HDN uint32_t huf_build(const uint32_t* count, uint32_t maxSymbolValue, uint32_t maxNbBits, uint8_t* nbBits,
+                           uint16_t* code, HufBuildWksp* w)
+{
+    HufNode* const huffNode0 = w->node;
+    HufNode* const huffNode = huffNode0 + 1;
+    for (int i = 0; i < 513; ++i) {
+        huffNode0[i].count = 0;
+        huffNode0[i].parent = 0;
+        huffNode0[i].byte = 0;
+        huffNode0[i].nbBits = 0;
+    }
+    // sort by decreasing count (bucketed by log2, insertion inside a bucket; ties keep symbol order)
+    for (int i = 0; i < 33; ++i) w->rankBase[i] = 0;
+    for (uint32_t n = 0; n <= maxSymbolValue; n++) w->rankBase[hb32(count[n] + 1)]++;
+    for (int n = 30; n > 0; n--) w->rankBase[n - 1] += w->rankBase[n];
+    for (int n = 0; n < 32; n++) w->rankCur[n] = w->rankBase[n];
+    for (uint32_t n = 0; n <= maxSymbolValue; n++) {
+        const uint32_t c = count[n];
+        const uint32_t r = (uint32_t)hb32(c + 1) + 1;
+        uint32_t pos = w->rankCur[r]++;
+        while ((pos > w->rankBase[r]) && (c > huffNode[pos - 1].count)) {
+            huffNode[pos] = huffNode[pos - 1];
+            pos--;
+        }
+        huffNode[pos].count = c;
+        huffNode[pos].byte = (uint8_t)n;
+    }
+    int nonNullRank = (int)maxSymbolValue;
+    while (huffNode[nonNullRank].count == 0) nonNullRank--;
+    int lowS = nonNullRank;
+    int nodeNb = 256;
+    const int nodeRoot = nodeNb + lowS - 1;
+    int lowN = nodeNb;
+    huffNode[nodeNb].count = huffNode[lowS].count + huffNode[lowS - 1].count;
+    huffNode[lowS].parent = huffNode[lowS - 1].parent = (uint16_t)nodeNb;
+    nodeNb++;
+    lowS -= 2;
+    for (int n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = 1u << 30;
+    huffNode0[0].count = 1u << 31;  // sentinel in front of the list
+    while (nodeNb <= nodeRoot) {
+        const int n1 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        const int n2 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        huffNode[nodeNb].count = huffNode[n1].count + huffNode[n2].count;
+        huffNode[n1].parent = huffNode[n2].parent = (uint16_t)nodeNb;
+        nodeNb++;
+    }
+    huffNode[nodeRoot].nbBits = 0;
+    for (int n = nodeRoot - 1; n >= 256; n--) huffNode[n].nbBits = (uint8_t)(huffNode[huffNode[n].parent].nbBits + 1);
+    for (int n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = (uint8_t)(huffNode[huffNode[n].parent].nbBits + 1);
+    maxNbBits = huf_set_max_height(huffNode, (uint32_t)nonNullRank, maxNbBits);
+    uint16_t nbPerRank[HUF_ABS_MAX_BITS + 2];
+    uint16_t valPerRank[HUF_ABS_MAX_BITS + 2];
+    for (int i = 0; i < HUF_ABS_MAX_BITS + 2; ++i) nbPerRank[i] = valPerRank[i] = 0;
+    for (int n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+    {
+        uint16_t min = 0;
+        for (int n = (int)maxNbBits; n > 0; n--) {
+            valPerRank[n] = min;
+            min = (uint16_t)(min + nbPerRank[n]);
+            min >>= 1;
+        }
+    }
+    for (uint32_t n = 0; n <= maxSymbolValue; n++) nbBits[n] = 0;
+    for (int n = 0; n <= nonNullRank; n++) nbBits[huffNode[n].byte] = huffNode[n].nbBits;
+    for (uint32_t n = 0; n <= maxSymbolValue; n++) code[n] = nbBits[n] ? valPerRank[nbBits[n]]++ : 0;
+    return maxNbBits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// FSE compression of the Huffman weights (zstd HUF_compressWeights / FSE_normalizeCount /
+// FSE_writeNCount / FSE_buildCTable / FSE_compress_usingCTable) -- alphabet <= 13, tableLog <= 6
+// ------------------------------------------------------------------------------------------------
+struct FseWeightWksp
+{
+    uint32_t count[16];
+    int16_t norm[16];
+    uint16_t stateTable[64];
+    uint8_t tableSymbol[64];
+    uint32_t cumul[18];
+    int32_t deltaFindState[16];
+    uint32_t deltaNbBits[16];
+};
+
+struct BitW  // forward bit writer (little-endian), zstd BIT_CStream_t
+{
+    uint64_t acc;
+    uint32_t nbits;
+    uint8_t* p;
+    uint8_t* end;
+};
+
+VBZ_HD void bitw_add(BitW& b, uint32_t v, uint32_t n)
+{
+    b.acc |= (uint64_t)(v & ((1u << n) - 1u)) << b.nbits;
+    b.nbits += n;
+}
+
+VBZ_HD void bitw_flush(BitW& b)
+{
+    while (b.nbits >= 8 && b.p < b.end) {
+        *b.p++ = (uint8_t)b.acc;
+        b.acc >>= 8;
+        b.nbits -= 8;
+    }
+}
+
+VBZ_HDN int fse_normalize_m2(int16_t* norm, uint32_t tableLog, const uint32_t* count, uint32_t total, uint32_t maxSymbolValue,
+                            int16_t lowProbCount)
+{
+    const int16_t NOT_YET_ASSIGNED = -2;
+    uint32_t s, distributed = 0, ToDistribute;
+    const uint32_t lowThreshold = total >> tableLog;
+    uint32_t lowOne = (total * 3) >> (tableLog + 1);
+    for (s = 0; s <= maxSymbolValue; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NOT_YET_ASSIGNED;
+    }
+    ToDistribute = (1u << tableLog) - distributed;
+    if (ToDistribute == 0) return 0;
+    if ((total / ToDistribute) > lowOne) {
+        lowOne = (total * 3) / (ToDistribute * 2);
+        for (s = 0; s <= maxSymbolValue; s++) {
+            if ((norm[s] == NOT_YET_ASSIGNED) && (count[s] <= lowOne)) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        }
+        ToDistribute = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSymbolValue + 1) {
+        uint32_t maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSymbolValue; s++)
+            if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] = (int16_t)(norm[maxV] + (int16_t)ToDistribute);
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; ToDistribute > 0; s = (s + 1) % (maxSymbolValue + 1))
+            if (norm[s] > 0) { ToDistribute--; norm[s]++; }
+        return 0;
+    }
+    {
+        const uint64_t vStepLog = 62 - tableLog;
+        const uint64_t mid = (1ull << (vStepLog - 1)) - 1;
+        const uint64_t rStep = ((((uint64_t)1 << vStepLog) * ToDistribute) + mid) / total;
+        uint64_t tmpTotal = mid;
+        for (s = 0; s <= maxSymbolValue; s++) {
+            if (norm[s] == NOT_YET_ASSIGNED) {
+                const uint64_t end = tmpTotal + ((uint64_t)count[s] * rStep);
+                const uint32_t sStart = (uint32_t)(tmpTotal >> vStepLog);
+                const uint32_t sEnd = (uint32_t)(end >> vStepLog);
+                const uint32_t weight = sEnd - sStart;
+                if (weight < 1) return -1;
+                norm[s] = (int16_t)weight;
+                tmpTotal = end;
+            }
+        }
+    }
+    return 0;
+}
+
+// returns tableLog, 0 for "rle" (one symbol holds everything), -1 on failure.
+// lowProbCount: -1 ("less than one" cells) or 1; zstd >= 1.4.7 uses 1 for Huffman weights.
+VBZ_HDN int fse_normalize(int16_t* norm, uint32_t tableLog, const uint32_t* count, uint32_t total, uint32_t maxSymbolValue,
+                         int16_t lowProbCount)
+{
+    const uint32_t rtbTable[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+    const uint64_t scale = 62 - tableLog;
+    const uint64_t step = ((uint64_t)1 << 62) / total;
+    const uint64_t vStep = 1ull << (scale - 20);
+    int stillToDistribute = 1 << tableLog;
+    uint32_t s, largest = 0;
+    int16_t largestP = 0;
+    const uint32_t lowThreshold = total >> tableLog;
+    for (s = 0; s <= maxSymbolValue; s++) {
+        if (count[s] == total) return 0;
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) {
+            norm[s] = lowProbCount;
+            stillToDistribute--;
+        } else {
+            int16_t proba = (int16_t)((count[s] * step) >> scale);
+            if (proba < 8) {
+                uint64_t restToBeat = vStep * rtbTable[proba];
+                proba = (int16_t)(proba + (((count[s] * step) - ((uint64_t)proba << scale)) > restToBeat));
+            }
+            if (proba > largestP) { largestP = proba; largest = s; }
+            norm[s] = proba;
+            stillToDistribute -= proba;
+        }
+    }
+    if (-stillToDistribute >= (norm[largest] >> 1)) {
+        if (fse_normalize_m2(norm, tableLog, count, total, maxSymbolValue, lowProbCount) != 0) return -1;
+    } else {
+        norm[largest] = (int16_t)(norm[largest] + (int16_t)stillToDistribute);
+    }
+    return (int)tableLog;
+}
+
+// FSE table description (zstd FSE_writeNCount); returns bytes written or -1
+VBZ_HDN int fse_write_ncount(uint8_t* out, int cap, const int16_t* norm, uint32_t maxSymbolValue, uint32_t tableLog)
+{
+    uint8_t* const ostart = out;
+    uint8_t* const oend = out + cap;
+    const int tableSize = 1 << tableLog;
+    uint32_t bitStream = 0;
+    int bitCount = 0;
+    uint32_t symbol = 0;
+    const uint32_t alphabetSize = maxSymbolValue + 1;
+    int previousIs0 = 0;
+    bitStream += (tableLog - 5) << bitCount;
+    bitCount += 4;
+    int remaining = tableSize + 1;
+    int threshold = tableSize;
+    int nbBits = (int)tableLog + 1;
+    while ((symbol < alphabetSize) && (remaining > 1)) {
+        if (previousIs0) {
+            uint32_t start = symbol;
+            while ((symbol < alphabetSize) && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) {
+                start += 24;
+                bitStream += 0xFFFFu << bitCount;
+                if (out + 2 > oend) return -1;
+                out[0] = (uint8_t)bitStream;
+                out[1] = (uint8_t)(bitStream >> 8);
+                out += 2;
+                bitStream >>= 16;
+            }
+            while (symbol >= start + 3) {
+                start += 3;
+                bitStream += 3u << bitCount;
+                bitCount += 2;
+            }
+            bitStream += (symbol - start) << bitCount;
+            bitCount += 2;
+            if (bitCount > 16) {
+                if (out + 2 > oend) return -1;
+                out[0] = (uint8_t)bitStream;
+                out[1] = (uint8_t)(bitStream >> 8);
+                out += 2;
+                bitStream >>= 16;
+                bitCount -= 16;
+            }
+        }
+        {
+            int count = norm[symbol++];
+            const int max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (uint32_t)count << bitCount;
+            bitCount += nbBits;
+            bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return -1;
+            while (remaining < threshold) {
+                nbBits--;
+                threshold >>= 1;
+            }
+        }
+        if (bitCount > 16) {
+            if (out + 2 > oend) return -1;
+            out[0] = (uint8_t)bitStream;
+            out[1] = (uint8_t)(bitStream >> 8);
+            out += 2;
+            bitStream >>= 16;
+            bitCount -= 16;
+        }
+    }
+    if (remaining != 1) return -1;
+    if (out + 2 > oend) return -1;
+    out[0] = (uint8_t)bitStream;
+    out[1] = (uint8_t)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (int)(out - ostart);
+}
+
+// FSE-compress the weight list (zstd HUF_compressWeights). Returns bytes, 0 = not compressible,
+// 1 = single repeated weight (caller falls back), -1 = error.
+VBZ_HDN int huf_compress_weights(uint8_t* dst, int cap, const uint8_t* weights, uint32_t wtSize, FseWeightWksp* w)
+{
+    uint8_t* op = dst;
+    uint8_t* const oend = dst + cap;
+    uint32_t maxSymbolValue = HUF_ABS_MAX_BITS;
+    if (wtSize <= 1) return 0;
+    for (int i = 0; i < 16; ++i) w->count[i] = 0;
+    uint32_t maxCount = 0;
+    for (uint32_t i = 0; i < wtSize; ++i) w->count[weights[i]]++;
+    while (w->count[maxSymbolValue] == 0) maxSymbolValue--;
+    for (uint32_t s = 0; s <= maxSymbolValue; ++s)
+        if (w->count[s] > maxCount) maxCount = w->count[s];
+    if (maxCount == wtSize) return 1;
+    if (maxCount == 1) return 0;
+    uint32_t tableLog = optimal_table_log(6, wtSize, maxSymbolValue, 2);
+    if (fse_normalize(w->norm, tableLog, w->count, wtSize, maxSymbolValue, 1) <= 0) return -1;
+    {
+        int h = fse_write_ncount(op, (int)(oend - op), w->norm, maxSymbolValue, tableLog);
+        if (h < 0) return -1;
+        op += h;
+    }
+    // FSE_buildCTable
+    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1;
+    const uint32_t step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    uint32_t highThreshold = tableSize - 1;
+    w->cumul[0] = 0;
+    for (uint32_t u = 1; u <= maxSymbolValue + 1; u++) {
+        if (w->norm[u - 1] == -1) {
+            w->cumul[u] = w->cumul[u - 1] + 1;
+            w->tableSymbol[highThreshold--] = (uint8_t)(u - 1);
+        } else {
+            w->cumul[u] = w->cumul[u - 1] + (uint32_t)w->norm[u - 1];
+        }
+    }
+    w->cumul[maxSymbolValue + 1] = tableSize + 1;
+    {
+        uint32_t position = 0;
+        for (uint32_t symbol = 0; symbol <= maxSymbolValue; symbol++) {
+            const int freq = w->norm[symbol];
+            for (int occ = 0; occ < freq; occ++) {
+                w->tableSymbol[position] = (uint8_t)symbol;
+                position = (position + step) & tableMask;
+                while (position > highThreshold) position = (position + step) & tableMask;
+            }
+        }
+    }
+    for (uint32_t u = 0; u < tableSize; u++) {
+        uint8_t s = w->tableSymbol[u];
+        w->stateTable[w->cumul[s]++] = (uint16_t)(tableSize + u);
+    }
+    {
+        uint32_t total = 0;
+        for (uint32_t s = 0; s <= maxSymbolValue; s++) {
+            const int nc = w->norm[s];
+            if (nc == 0) {
+                w->deltaNbBits[s] = ((tableLog + 1) << 16) - (1u << tableLog);
+                w->deltaFindState[s] = 0;
+            } else if (nc == -1 || nc == 1) {
+                w->deltaNbBits[s] = (tableLog << 16) - (1u << tableLog);
+                w->deltaFindState[s] = (int32_t)total - 1;
+                total++;
+            } else {
+                const uint32_t maxBitsOut = tableLog - (uint32_t)hb32((uint32_t)nc - 1);
+                const uint32_t minStatePlus = (uint32_t)nc << maxBitsOut;
+                w->deltaNbBits[s] = (maxBitsOut << 16) - minStatePlus;
+                w->deltaFindState[s] = (int32_t)total - nc;
+                total += (uint32_t)nc;
+            }
+        }
+    }
+    // FSE_compress_usingCTable: two interleaved states, symbols consumed from the end
+    BitW bw;
+    bw.acc = 0;
+    bw.nbits = 0;
+    bw.p = op;
+    bw.end = oend;
+    const uint8_t* ip = weights + wtSize;
+    uint32_t st1, st2;
+#define FSE_INIT2(st, sym)                                                              \
+    do {                                                                                \
+        uint32_t nbo = (w->deltaNbBits[sym] + (1u << 15)) >> 16;                        \
+        uint32_t v = (nbo << 16) - w->deltaNbBits[sym];                                 \
+        st = w->stateTable[(int32_t)(v >> nbo) + w->deltaFindState[sym]];               \
+    } while (0)
+#define FSE_ENC(st, sym)                                                                \
+    do {                                                                                \
+        uint32_t nbo = (st + w->deltaNbBits[sym]) >> 16;                                \
+        bitw_add(bw, st, nbo);                                                          \
+        st = w->stateTable[(int32_t)(st >> nbo) + w->deltaFindState[sym]];              \
+    } while (0)
+    if (wtSize & 1) {
+        --ip; FSE_INIT2(st1, *ip);
+        --ip; FSE_INIT2(st2, *ip);
+        --ip; FSE_ENC(st1, *ip);
+        bitw_flush(bw);
+    } else {
+        --ip; FSE_INIT2(st2, *ip);
+        --ip; FSE_INIT2(st1, *ip);
+    }
+    while (ip > weights) {
+        --ip; FSE_ENC(st2, *ip);
+        --ip; FSE_ENC(st1, *ip);
+        bitw_flush(bw);
+    }
+#undef FSE_INIT2
+#undef FSE_ENC
+    bitw_add(bw, st2, tableLog);
+    bitw_flush(bw);
+    bitw_add(bw, st1, tableLog);
+    bitw_flush(bw);
+    bitw_add(bw, 1, 1);  // end mark
+    bitw_flush(bw);
+    if (bw.nbits > 0) {
+        if (bw.p >= bw.end) return -1;
+        *bw.p++ = (uint8_t)bw.acc;
+    }
+    if (bw.p >= bw.end) return -1;  // zstd: BIT_closeCStream reports overflow when the buffer filled up
+    op = bw.p;
+    return (int)(op - dst);
+}
+
+// Huffman tree description (zstd HUF_writeCTable). nbBits[0..maxSymbolValue], huffLog = table log.
+// Returns bytes written (<= 129) or -1.  `weights` is a 256-byte scratch.
+VBZ_HDN int huf_write_tree(uint8_t* dst, int cap, const uint8_t* nbBits, uint32_t maxSymbolValue, uint32_t huffLog,
+                           uint8_t* weights, FseWeightWksp* w)
+{
+    if (cap < 1) return -1;
+    for (uint32_t n = 0; n < maxSymbolValue; n++) weights[n] = nbBits[n] ? (uint8_t)(huffLog + 1 - nbBits[n]) : 0;
+    {
+        int hSize = huf_compress_weights(dst + 1, cap - 1, weights, maxSymbolValue, w);
+        if (hSize < 0) return -1;
+        if ((hSize > 1) && ((uint32_t)hSize < maxSymbolValue / 2)) {
+            dst[0] = (uint8_t)hSize;
+            return hSize + 1;
+        }
+    }
+    if (maxSymbolValue > 128) return -1;  // cannot be described raw: caller stores the block uncompressed
+    if ((int)((maxSymbolValue + 1) / 2) + 1 > cap) return -1;
+    dst[0] = (uint8_t)(128 + (maxSymbolValue - 1));
+    weights[maxSymbolValue] = 0;
+    for (uint32_t n = 0; n < maxSymbolValue; n += 2) dst[(n / 2) + 1] = (uint8_t)((weights[n] << 4) + weights[n + 1]);
+    return (int)((maxSymbolValue + 1) / 2) + 1;
+}
+
+}  // namespace vbzhip
