@@ -31,7 +31,7 @@ class Options(ctypes.Structure):
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vbz_oracle.c", "zstd_restate.c", "vbz_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vbz_oracle.c", "zstd_restate.c", "vbz_oracle_bench.c", "vbz_oracle.h", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
@@ -85,6 +85,8 @@ def lib():
         L.vbo_synth_signal.argtypes = [ctypes.c_uint64, ctypes.c_uint64, vp, sz]
         L.vbo_synth_u32.restype = None
         L.vbo_synth_u32.argtypes = [ctypes.c_uint64, ctypes.c_uint64, vp, sz]
+        L.vbo_bench_roundtrip.restype = ctypes.c_int
+        L.vbo_bench_roundtrip.argtypes = [u32, ctypes.c_int, ctypes.c_double, op, ctypes.POINTER(ctypes.c_double)]
         _lib = L
     return _lib
 
@@ -202,3 +204,12 @@ def fnv1a64(data):
     for b in bytes(data):
         h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
     return "%016x" % h
+
+
+def bench_roundtrip(n_reads, threads, min_seconds, opts):
+    """Threaded CPU timing of encode+decode over reads [0, n_reads) of the synthetic workload."""
+    out = (ctypes.c_double * 6)()
+    rc = lib().vbo_bench_roundtrip(n_reads, threads, min_seconds, ctypes.byref(opts), out)
+    if rc != 0:
+        raise RuntimeError("oracle bench failed (%d)" % rc)
+    return dict(raw_bytes=out[0], comp_bytes=out[1], best_s=out[2], enc_thread_s=out[3], dec_thread_s=out[4], passes=int(out[5]))

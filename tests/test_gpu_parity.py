@@ -404,3 +404,30 @@ def test_full_size_device_round_trip_properties():
         assert (a == O.synth_signal(5, i, s // 2)).all()                 # device generator == oracle generator
         f = hcomp[int(coff[i]) : int(coff[i]) + int(csize[i])]
         assert O.decompress(f, s, O.options(True, 2, 1, 1)).tobytes() == a.tobytes()
+
+
+def test_zstd_encoder_tables_match_libzstd_construction():
+    """The wave-parallel table construction on the device must give the tree description that the serial
+    host statement (zstd_entropy.h, itself checked byte-for-byte against libzstd) gives for the same bytes."""
+    import entropy_host as E
+    import gpu_util as G
+
+    rng = np.random.default_rng(77)
+    regions = []
+    for i, n in enumerate([300, 5000, 40000, 100000, 131072, 7777, 65536, 2000]):
+        a = O.synth_signal(5, i, n)
+        regions.append(O.svb_compress(a, 2, True, 0)[(n + 3) // 4 :].copy())           # data bytes of a signal
+    regions.append(np.minimum(rng.geometric(0.05, 90000), 255).astype(np.uint8))
+    regions.append(np.clip(rng.normal(128, 4, 50000), 0, 255).astype(np.uint8))
+    regions.append((rng.integers(0, 100, 30000) < 4).astype(np.uint8) * 16)               # two symbols
+    frames = G.zstd_compress(regions)
+    checked = 0
+    for data, f in zip(regions, frames):
+        assert not isinstance(f, int)
+        lit = E.parse_first_block_literals(f)
+        if lit is None or lit[0] != 2:
+            continue   # the encoder stored this region raw (too small to pay for a table)
+        log, nb, tree = E.tree_description(data)
+        assert lit[3] == tree, len(data)
+        checked += 1
+    assert checked >= 8

@@ -17,18 +17,32 @@ def _u32(t):
 
 
 class GpuCodec:
-    """One context (one HIP stream) on one GPU; launches on torch's current stream by default."""
+    """One context on one GPU.  The codec owns a torch stream (`self.stream`) and the C library
+    launches every kernel on it; each call first makes that stream wait for torch's current stream
+    and afterwards makes the current stream wait for the codec, so tensors produced or consumed by
+    ordinary torch code need no extra synchronisation.  Under `with torch.cuda.stream(codec.stream)`
+    both waits are no-ops."""
 
-    def __init__(self, device=None, use_torch_stream=True):
+    def __init__(self, device=None):
         self.L = _lib.load()
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device if isinstance(device, int) else torch.device(device).index or 0)
         with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream().cuda_stream if use_torch_stream else None
-            self.ctx = self.L.vbz_gpu_create(self.device.index, ctypes.c_void_p(stream) if stream else None)
+            self.stream = torch.cuda.Stream(self.device)
+            self.ctx = self.L.vbz_gpu_create(self.device.index, ctypes.c_void_p(self.stream.cuda_stream))
         if not self.ctx:
             raise RuntimeError("vbz_gpu_create failed: no usable gfx950 device (the codec has no CPU path)")
+
+    def _enter(self):
+        cur = torch.cuda.current_stream(self.device)
+        if cur != self.stream:
+            self.stream.wait_stream(cur)
+        return cur
+
+    def _exit(self, cur):
+        if cur != self.stream:
+            cur.wait_stream(self.stream)
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -71,41 +85,77 @@ class GpuCodec:
     # -- full path -------------------------------------------------------------------------------
     def compress(self, src, src_off, src_size, dst, dst_off, dst_cap, result, opts, sized=False):
         b = self._batch(src, src_off, src_size, dst, dst_off, dst_cap, result)
-        self._rc(self.L.vbz_gpu_compress_batch(self.ctx, ctypes.byref(b), ctypes.byref(opts), int(sized)), "compress_batch")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_compress_batch(self.ctx, ctypes.byref(b), ctypes.byref(opts), int(sized)), "compress_batch")
+        finally:
+            self._exit(cur)
 
     def decompress(self, src, src_off, src_size, dst, dst_off, dst_cap, result, opts, sized=False):
         b = self._batch(src, src_off, src_size, dst, dst_off, dst_cap, result)
-        self._rc(self.L.vbz_gpu_decompress_batch(self.ctx, ctypes.byref(b), ctypes.byref(opts), int(sized)), "decompress_batch")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_decompress_batch(self.ctx, ctypes.byref(b), ctypes.byref(opts), int(sized)), "decompress_batch")
+        finally:
+            self._exit(cur)
 
     # -- stages ----------------------------------------------------------------------------------
     def svb_compress(self, src, src_off, src_size, dst, dst_off, dst_cap, result, size=2, zigzag=True, version=0):
         b = self._batch(src, src_off, src_size, dst, dst_off, dst_cap, result)
-        self._rc(self.L.vbz_gpu_svb_compress_batch(self.ctx, ctypes.byref(b), size, int(zigzag), version), "svb_compress_batch")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_svb_compress_batch(self.ctx, ctypes.byref(b), size, int(zigzag), version), "svb_compress_batch")
+        finally:
+            self._exit(cur)
 
     def svb_decompress(self, src, src_off, src_size, dst, dst_off, dst_cap, result, size=2, zigzag=True, version=0):
         b = self._batch(src, src_off, src_size, dst, dst_off, dst_cap, result)
-        self._rc(self.L.vbz_gpu_svb_decompress_batch(self.ctx, ctypes.byref(b), size, int(zigzag), version), "svb_decompress_batch")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_svb_decompress_batch(self.ctx, ctypes.byref(b), size, int(zigzag), version), "svb_decompress_batch")
+        finally:
+            self._exit(cur)
 
     def zstd_compress(self, src, src_off, src_size, dst, dst_off, dst_cap, result, key_bytes=None):
         b = self._batch(src, src_off, src_size, dst, dst_off, dst_cap, result)
         kb = key_bytes.data_ptr() if key_bytes is not None else None
-        self._rc(self.L.vbz_gpu_zstd_compress_batch(self.ctx, ctypes.byref(b), kb), "zstd_compress_batch")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_zstd_compress_batch(self.ctx, ctypes.byref(b), kb), "zstd_compress_batch")
+        finally:
+            self._exit(cur)
 
     def zstd_decompress(self, src, src_off, src_size, dst, dst_off, dst_cap, result):
         b = self._batch(src, src_off, src_size, dst, dst_off, dst_cap, result)
-        self._rc(self.L.vbz_gpu_zstd_decompress_batch(self.ctx, ctypes.byref(b)), "zstd_decompress_batch")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_zstd_decompress_batch(self.ctx, ctypes.byref(b)), "zstd_decompress_batch")
+        finally:
+            self._exit(cur)
 
     # -- synthetic workload ----------------------------------------------------------
     def synth_lengths(self, seed, first_read, n_reads):
         out = torch.empty(n_reads, dtype=torch.int32, device=self.device)
-        self._rc(self.L.vbz_gpu_synth_lengths(self.ctx, seed, first_read, n_reads, out.data_ptr()), "synth_lengths")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_synth_lengths(self.ctx, seed, first_read, n_reads, out.data_ptr()), "synth_lengths")
+        finally:
+            self._exit(cur)
         return out
 
     def synth_signal(self, seed, first_read, dst, off, length):
-        self._rc(self.L.vbz_gpu_synth_signal(self.ctx, seed, first_read, int(off.numel()), dst.data_ptr(), off.data_ptr(), length.data_ptr()), "synth_signal")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_synth_signal(self.ctx, seed, first_read, int(off.numel()), dst.data_ptr(), off.data_ptr(), length.data_ptr()), "synth_signal")
+        finally:
+            self._exit(cur)
 
     def synth_u32(self, seed, first_read, dst, off, length):
-        self._rc(self.L.vbz_gpu_synth_u32(self.ctx, seed, first_read, int(off.numel()), dst.data_ptr(), off.data_ptr(), length.data_ptr()), "synth_u32")
+        cur = self._enter()
+        try:
+            self._rc(self.L.vbz_gpu_synth_u32(self.ctx, seed, first_read, int(off.numel()), dst.data_ptr(), off.data_ptr(), length.data_ptr()), "synth_u32")
+        finally:
+            self._exit(cur)
 
     # -- profiling -------------------------------------------------------------------------------
     def profile(self, enable=True):

@@ -51,6 +51,8 @@ struct vbz_gpu_ctx
     DevBuf meta;      // per-read bookkeeping arrays
     // single-buffer API staging
     DevBuf one_in, one_out, one_meta;
+    DevBuf dbg;       // per-read phase timers (VBZ_HIP_PHASE_TIMING=1)
+    bool phase_timing = false;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     bool profiling = false;
@@ -148,6 +150,29 @@ void drain_profile(vbz_gpu_ctx* c)
     c->pending.clear();
 }
 
+// debug aid: per-phase shader-clock cycles of the entropy kernels, averaged over the batch, on stderr
+unsigned long long* dbg_begin(vbz_gpu_ctx* c, uint32_t n)
+{
+    if (!c->phase_timing) return nullptr;
+    if (!ensure(c, c->dbg, (size_t)n * 64)) return nullptr;
+    hipMemsetAsync(c->dbg.p, 0, (size_t)n * 64, c->stream);
+    return (unsigned long long*)c->dbg.p;
+}
+
+void dbg_end(vbz_gpu_ctx* c, uint32_t n, const char* what, unsigned long long* d)
+{
+    if (!d) return;
+    std::vector<unsigned long long> h((size_t)n * 8);
+    hipStreamSynchronize(c->stream);
+    hipMemcpy(h.data(), d, (size_t)n * 64, hipMemcpyDeviceToHost);
+    double sum[6] = { 0, 0, 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < n; ++i)
+        for (int k = 0; k < 6; ++k) sum[k] += (double)h[(size_t)i * 8 + k];
+    fprintf(stderr, "vbz_hip phase cycles/read (%s, n=%u):", what, n);
+    for (int k = 0; k < 6; ++k) fprintf(stderr, " p%d=%.0f", k, sum[k] / n);
+    fprintf(stderr, "\n");
+}
+
 bool valid_int_size(const CompressionOptions* o)  // vbz/vbz.cpp:44-50
 {
     return o->integer_size == 0 || o->integer_size == 1 || o->integer_size == 2 || o->integer_size == 4;
@@ -220,7 +245,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
@@ -252,10 +277,12 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     z.src = (const uint8_t*)c->scratch.p;
     z.src_off = svb_off;
     z.src_size = svb_size;
+    unsigned long long* dbg = dbg_begin(c, n);
     {
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, s), "zstd_encode launch");
     }
+    dbg_end(c, n, "zstd_encode: setup hist plan size hdr encode", dbg);
     return 0;
 }
 
@@ -304,7 +331,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     }
     if (o->integer_size == 0) {  // vbz.cpp:259-262: content larger than the destination -> DESTINATION_SIZE
         Timed t(c, "zstd_decode");
-        HIPCHK(c, launch_zstd_decode(rb, E_DESTINATION_SIZE, s), "zstd_decode launch");
+        HIPCHK(c, launch_zstd_decode(rb, E_DESTINATION_SIZE, nullptr, s), "zstd_decode launch");
         return 0;
     }
     // entropy stage into scratch (sized for the largest svb stream the expected output can have),
@@ -323,12 +350,14 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     z.dst_cap = svb_cap;
     z.result = svb_size;
     z.gate = gate;
+    unsigned long long* dbg = dbg_begin(c, n);
     {
         Timed t(c, "zstd_decode");
         // a frame whose content cannot be a valid svb stream of the expected size: the reference would
         // decode it and then fail in the svb stage with a stream error
-        HIPCHK(c, launch_zstd_decode(z, E_STREAM, s), "zstd_decode launch");
+        HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, s), "zstd_decode launch");
     }
+    dbg_end(c, n, "zstd_decode: parse flush", dbg);
     ReadBatch d = rb;
     d.src = (const uint8_t*)c->scratch.p;
     d.src_off = svb_off;
@@ -381,6 +410,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     }
     vbz_gpu_ctx* c = new vbz_gpu_ctx();
     c->device = device;
+    if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
@@ -397,14 +427,14 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
 void vbz_gpu_destroy(vbz_gpu_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) {
         hipEventDestroy(p.start);
         hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg })
         if (b->p) hipFree(b->p);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -424,7 +454,7 @@ int vbz_gpu_synchronize(vbz_gpu_ctx* c)
 int vbz_gpu_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
 {
     if (!c || !bt || !o) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1) || !device_supported(o)) {
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
@@ -435,7 +465,7 @@ int vbz_gpu_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compre
 int vbz_gpu_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
 {
     if (!c || !bt || !o) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1) || !device_supported(o)) {
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
@@ -461,7 +491,7 @@ static ReadBatch to_rb(const vbz_gpu_batch* bt)
 int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int integer_size, int zigzag, int version)
 {
     if (!c || !bt) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || (version == 1 && integer_size == 1) || version > 1) return -2;
     Timed t(c, "svb_encode");
     HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, c->stream), "svb_encode launch");
@@ -471,7 +501,7 @@ int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int inte
 int vbz_gpu_svb_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int integer_size, int zigzag, int version)
 {
     if (!c || !bt) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || (version == 1 && integer_size == 1) || version > 1) return -2;
     Timed t(c, "svb_decode");
     HIPCHK(c, launch_svb_decode(to_rb(bt), integer_size, zigzag != 0, c->stream), "svb_decode launch");
@@ -481,25 +511,25 @@ int vbz_gpu_svb_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int in
 int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const uint32_t* key_bytes)
 {
     if (!c || !bt) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, c->stream), "zstd_encode launch");
     return 0;
 }
 
 int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
 {
     if (!c || !bt) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     Timed t(c, "zstd_decode");
-    HIPCHK(c, launch_zstd_decode(to_rb(bt), E_ZSTD, c->stream), "zstd_decode launch");
+    HIPCHK(c, launch_zstd_decode(to_rb(bt), E_ZSTD, nullptr, c->stream), "zstd_decode launch");
     return 0;
 }
 
 int vbz_gpu_synth_lengths(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len)
 {
     if (!c) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     HIPCHK(c, launch_synth_lengths(seed, first, n, out_len, c->stream), "synth_lengths launch");
     return 0;
 }
@@ -508,7 +538,7 @@ int vbz_gpu_synth_signal(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t
                          const uint32_t* len)
 {
     if (!c) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     HIPCHK(c, launch_synth_signal(seed, first, n, (uint8_t*)dst, off, len, c->stream), "synth_signal launch");
     return 0;
 }
@@ -516,7 +546,7 @@ int vbz_gpu_synth_signal(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t
 int vbz_gpu_synth_u32(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, void* dst, const uint64_t* off, const uint32_t* len)
 {
     if (!c) return -1;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     HIPCHK(c, launch_synth_u32(seed, first, n, (uint8_t*)dst, off, len, c->stream), "synth_u32 launch");
     return 0;
 }
@@ -586,7 +616,7 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     std::lock_guard<std::mutex> lock(g_mutex);
     vbz_gpu_ctx* c = default_ctx();
     if (!c) return VBZ_DEVICE_ERROR;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     if (!ensure(c, c->one_in, (size_t)src_size + 64) || !ensure(c, c->one_out, (size_t)dev_cap + 64) ||
         !ensure(c, c->one_meta, sizeof(OneMeta)))
         return VBZ_OUT_OF_MEMORY_ERROR;

@@ -46,11 +46,12 @@ hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, 
 // derived from `orig_size[i] / key_elem`) is split into its own blocks; 0 = no split.
 // hdr: 0 or 4 (sized header carrying orig_size[i] in front of the frame).
 // key_bytes (nullable) gives the key-section length per read directly and overrides key_elem.
+// dbg (nullable): 8 x u64 per read, shader-clock cycles spent per phase (debug aid, VBZ_HIP_PHASE_TIMING=1)
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                              uint32_t hdr, hipStream_t s);
+                              uint32_t hdr, unsigned long long* dbg, hipStream_t s);
 // decode: result[i] = frame content size, E_ZSTD for a malformed frame, or `toosmall_code` when the
 // frame's content size exceeds dst_cap[i].
-hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, hipStream_t s);
+hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, hipStream_t s);
 
 // ---- helpers (helpers.hip) ---------------------------------------------------------------------
 // scratch slots for the intermediate svb streams: slot(i) = align16(ceil(raw_size[i]*num/den)+8)+48,

@@ -33,8 +33,8 @@ struct DecLds
     uint8_t weights[256];
     int16_t norm[256];
     uint16_t symnext[256];
-    uint16_t wstart[256];    // table start of each symbol (Huffman fill)
     uint32_t t_src[WAVE], t_size[WAVE], t_out[WAVE], t_cnt[WAVE], t_tab[WAVE];  // pending stream tasks
+    uint32_t inbuf[32][WAVE]; // per-lane rings of compressed input for the stream decoders
     uint32_t ctl[24];
 };
 
@@ -271,101 +271,290 @@ __device__ int huf_read_weights(DecLds& L, const uint8_t* p, int n, int* out_nw,
         if (hdr < 0) return -1;
         uint32_t* tab = L.wfse;
         if (fse_build(L, tab, nsym, log) != 0) return -1;
-        // two interleaved FSE states over an LDS-resident backward bit stream
+        // two interleaved FSE states over an LDS-resident backward bit stream (at most 127 bytes)
         const uint8_t* q = p + 1 + hdr;
         const int qn = hb - hdr;
         if (qn < 1 || q[qn - 1] == 0) return -1;
-        int pos = (qn - 1) * 8 + hbit(q[qn - 1]);  // unread bits
+        const int top = hbit(q[qn - 1]);
+        int left = (qn - 1) * 8 + top;  // unread bits of the stream
+        uint64_t buf = top ? ((uint64_t)(q[qn - 1] & ((1u << top) - 1u)) << (64 - top)) : 0ull;
+        int avail = top, nextb = qn - 1;
         auto rd = [&](int nb) -> uint32_t {
-            uint32_t v = 0;
-            for (int i = 0; i < nb; ++i) {
-                const int bit = pos - 1 - i;
-                v = (v << 1) | (bit >= 0 ? ((uint32_t)q[bit >> 3] >> (bit & 7)) & 1u : 0u);
+            while (avail <= 56 && nextb > 0) {
+                --nextb;
+                buf |= (uint64_t)q[nextb] << (56 - avail);
+                avail += 8;
             }
-            pos -= nb;
+            const uint32_t v = nb ? (uint32_t)(buf >> (64 - nb)) : 0u;
+            buf <<= nb;
+            avail = avail > nb ? avail - nb : 0;
+            left -= nb;
             return v;
         };
         uint32_t s1 = rd(log), s2 = rd(log);
-        if (pos < 0) return -1;
+        if (left < 0) return -1;
         for (;;) {
             if (nw > 253) return -1;
             uint32_t e = tab[s1];
             L.weights[nw++] = (uint8_t)e;
             s1 = (e >> 16) + rd((int)((e >> 8) & 0xFF));
-            if (pos < 0) { L.weights[nw++] = (uint8_t)tab[s2]; break; }
+            if (left < 0) { L.weights[nw++] = (uint8_t)tab[s2]; break; }
             if (nw > 253) return -1;
             e = tab[s2];
             L.weights[nw++] = (uint8_t)e;
             s2 = (e >> 16) + rd((int)((e >> 8) & 0xFF));
-            if (pos < 0) { L.weights[nw++] = (uint8_t)tab[s1]; break; }
+            if (left < 0) { L.weights[nw++] = (uint8_t)tab[s1]; break; }
         }
     }
     uint32_t total = 0;
+    int r1 = 0;
     for (int i = 0; i < nw; ++i) {
-        if (L.weights[i] >= 12) return -1;
-        total += L.weights[i] ? (1u << (L.weights[i] - 1)) : 0u;
+        const uint32_t wt = L.weights[i];
+        if (wt >= 12) return -1;
+        total += wt ? (1u << (wt - 1)) : 0u;
+        r1 += (wt == 1);
     }
     if (total == 0) return -1;
     const int log = hbit(total) + 1;
     if (log > 12) return -1;
     const uint32_t rest = (1u << log) - total;
     if (rest & (rest - 1)) return -1;
-    L.weights[nw++] = (uint8_t)(hbit(rest) + 1);
-    int r1 = 0;
-    for (int i = 0; i < nw; ++i) r1 += (L.weights[i] == 1);
+    const uint32_t lastw = (uint32_t)hbit(rest) + 1;
+    L.weights[nw++] = (uint8_t)lastw;
+    r1 += (lastw == 1);
     if (r1 < 2 || (r1 & 1)) return -1;
-    // table start of every symbol: increasing weight, then increasing symbol value
-    uint32_t idx = 0;
-    for (int wt = 1; wt <= log; ++wt)
-        for (int s = 0; s < nw; ++s)
-            if (L.weights[s] == wt) {
-                L.wstart[s] = (uint16_t)idx;
-                idx += 1u << (wt - 1);
-            }
     *out_nw = nw;
     *out_log = log;
     return used;
+}
+
+// all lanes: fill a Huffman decoding table from L.weights[0..nw) (RFC 8878 4.2.1: increasing weight, then
+// increasing symbol value).  Table start of a symbol = cells of all lighter symbols + cells of the equally
+// heavy symbols before it, found with ballots in symbol order; short runs are written by the owning lane,
+// long ones by the whole wave.
+__device__ void huf_fill_table(DecLds& L, uint16_t* T, uint32_t nw, uint32_t tlog, int lane)
+{
+    if (lane < 16) L.ctl[8 + lane] = 0;  // cells per weight live in ctl[8..23]
+    __syncthreads();
+    uint32_t wt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        wt[j] = s < nw ? L.weights[s] : 0u;
+        if (wt[j]) atomicAdd(&L.ctl[8 + wt[j]], 1u);
+    }
+    __syncthreads();
+    uint32_t base[13];
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int v = 1; v <= 12; ++v) {
+            base[v] = acc;
+            acc += L.ctl[8 + v] << (v - 1);
+        }
+        base[0] = 0;
+    }
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t st[4], len[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        st[j] = 0;
+        len[j] = wt[j] ? 1u << (wt[j] - 1) : 0u;
+#pragma unroll
+        for (int v = 1; v <= 12; ++v) {
+            const uint64_t m = __ballot(wt[j] == (uint32_t)v);
+            if (wt[j] == (uint32_t)v) st[j] = base[v] + ((uint32_t)__popcll(m & below) << (v - 1));
+            base[v] += (uint32_t)__popcll(m) << (v - 1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        const uint16_t ent = (uint16_t)(s | ((tlog + 1 - wt[j]) << 8));
+        if (len[j] && len[j] < 64)
+            for (uint32_t i = 0; i < len[j]; ++i) T[st[j] + i] = ent;
+        uint64_t big = __ballot(len[j] >= 64);
+        while (big) {
+            const int src_lane = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bst = (uint32_t)__shfl((int)st[j], src_lane, 64);
+            const uint32_t blen = (uint32_t)__shfl((int)len[j], src_lane, 64);
+            const uint32_t bent = (uint32_t)__shfl((int)ent, src_lane, 64);
+            for (uint32_t i = lane; i < blen; i += WAVE) T[bst + i] = (uint16_t)bent;
+        }
+    }
+    __syncthreads();
+}
+
+// ---- per-lane Huffman stream decoding -----------------------------------------------------------------
+// Every lane walks its own bit stream, so its loads are scattered by nature.  To keep them wide and
+// off the critical path each lane owns a ring of RING dwords in LDS (layout [dword][lane]: conflict
+// free when the lanes advance together) that is topped up with 64-byte batches fetched one period
+// ahead: at every uniform point (each PERIOD symbols) a lane whose ring has room commits the batch it
+// requested a period ago and requests the next one.  A period consumes at most 11 dwords (32 symbols x
+// 11 bits), so a ring that holds more than 16 dwords can always skip a top-up: no lane ever runs dry,
+// and all ring traffic happens at wave-uniform points (no divergent refill code).
+constexpr int RING = 32;
+constexpr int BATCH = 16;
+constexpr int PERIOD = 32;
+
+// next BATCH dwords below `nextbyte`, in consumption order (w[0] holds the highest bytes)
+__device__ __forceinline__ void fetch_batch(const uint8_t* p, uint32_t& nextbyte, uint32_t (&w)[BATCH])
+{
+    if (nextbyte >= 64) {
+        const uint8_t* q = p + nextbyte - 64;
+        uint4 a, b, c, d;
+        __builtin_memcpy(&a, q, 16);
+        __builtin_memcpy(&b, q + 16, 16);
+        __builtin_memcpy(&c, q + 32, 16);
+        __builtin_memcpy(&d, q + 48, 16);
+        w[0] = d.w; w[1] = d.z; w[2] = d.y; w[3] = d.x;
+        w[4] = c.w; w[5] = c.z; w[6] = c.y; w[7] = c.x;
+        w[8] = b.w; w[9] = b.z; w[10] = b.y; w[11] = b.x;
+        w[12] = a.w; w[13] = a.z; w[14] = a.y; w[15] = a.x;
+        nextbyte -= 64;
+    } else {
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) {
+            uint32_t v = 0;
+            if (nextbyte >= 4) {
+                __builtin_memcpy(&v, p + nextbyte - 4, 4);
+                nextbyte -= 4;
+            } else if (nextbyte > 0) {
+                for (uint32_t j = 0; j < nextbyte; ++j) v |= (uint32_t)p[j] << (8 * (j + 4 - nextbyte));
+                nextbyte = 0;
+            }
+            w[k] = v;
+        }
+    }
 }
 
 // all lanes: decode the queued Huffman streams, one per lane.  Returns true if any stream is corrupt.
 __device__ bool flush_tasks(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
 {
     bool bad = false;
-    if ((uint32_t)lane < ntask) {
-        const uint8_t* p = src + L.t_src[lane];
-        const uint32_t n = L.t_size[lane];
-        uint8_t* o = dst + L.t_out[lane];
-        uint32_t cnt = L.t_cnt[lane];
-        const uint32_t tab = L.t_tab[lane];
-        const int log = (int)(tab >> 16);
-        const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
-        BitReader br;
-        if (!br.init(p, n)) {
+    const bool mine = (uint32_t)lane < ntask;
+    const uint8_t* p = src;
+    uint32_t n = 0, cnt = 0, tab = 0;
+    uint8_t* o = dst;
+    if (mine) {
+        p = src + L.t_src[lane];
+        n = L.t_size[lane];
+        o = dst + L.t_out[lane];
+        cnt = L.t_cnt[lane];
+        tab = L.t_tab[lane];
+    }
+    const int log = (int)(tab >> 16);
+    const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
+    uint32_t* ring = &L.inbuf[0][0] + lane;  // ring[k * WAVE]
+
+    uint64_t buf = 0;
+    int32_t avail = 0, bits_left = 0;
+    uint32_t nextbyte = 0, ridx = 0, widx = 0, occ = 0;
+    uint32_t pend[BATCH];
+    bool have_pend = false;
+    if (mine) {
+        const uint32_t last = n ? p[n - 1] : 0;
+        if (last == 0) {
             bad = true;
+            cnt = 0;
         } else {
-            while (cnt >= 4) {
-                uint32_t e0, e1, e2, e3;
-                br.refill();
-                e0 = T[br.peek(log)]; br.skip((int)(e0 >> 8));
-                e1 = T[br.peek(log)]; br.skip((int)(e1 >> 8));
-                br.refill();
-                e2 = T[br.peek(log)]; br.skip((int)(e2 >> 8));
-                e3 = T[br.peek(log)]; br.skip((int)(e3 >> 8));
-                const uint32_t w = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
-                __builtin_memcpy(o, &w, 4);
-                o += 4;
-                cnt -= 4;
-            }
-            while (cnt > 0) {
-                br.refill();
-                const uint32_t e = T[br.peek(log)];
-                br.skip((int)(e >> 8));
-                *o++ = (uint8_t)e;
-                --cnt;
-            }
-            if (!br.finished()) bad = true;
+            const int hb = 31 - __clz((int)last);
+            buf = hb ? ((uint64_t)(last & ((1u << hb) - 1u)) << (64 - hb)) : 0ull;
+            avail = hb;
+            bits_left = (int32_t)((n - 1) * 8u) + hb;
+            nextbyte = n - 1;
         }
     }
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) pend[k] = 0;
+    // initial fill: two batches into the ring, a third one in flight
+    for (int f = 0; f < 2; ++f) {
+        if (nextbyte > 0) fetch_batch(p, nextbyte, pend);
+        else {
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) pend[k] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < BATCH; ++k) ring[((widx + k) & (RING - 1)) * WAVE] = pend[k];
+        widx += BATCH;
+        occ += BATCH;
+    }
+    if (nextbyte > 0) {
+        fetch_batch(p, nextbyte, pend);
+        have_pend = true;
+    }
+
+#define HUF_REFILL()                                                   \
+    do {                                                               \
+        if (avail <= 32) {                                             \
+            uint32_t w__ = 0;                                          \
+            if (occ) {                                                 \
+                w__ = ring[(ridx & (RING - 1)) * WAVE];                \
+                ++ridx;                                                \
+                --occ;                                                 \
+            }                                                          \
+            buf |= (uint64_t)w__ << (32 - avail);                      \
+            avail += 32;                                               \
+        }                                                              \
+    } while (0)
+#define HUF_SYM(dstvar)                                                \
+    do {                                                               \
+        const uint32_t e__ = T[(uint32_t)(buf >> (64 - log))];         \
+        const int nb__ = (int)(e__ >> 8);                              \
+        buf <<= nb__;                                                  \
+        avail -= nb__;                                                 \
+        bits_left -= nb__;                                             \
+        dstvar = e__ & 0xFFu;                                          \
+    } while (0)
+
+    while (__any(cnt > 0)) {
+        // ---- uniform top-up point
+        if (have_pend && occ <= (uint32_t)(RING - BATCH)) {
+#pragma unroll
+            for (int k = 0; k < BATCH; ++k) ring[((widx + k) & (RING - 1)) * WAVE] = pend[k];
+            widx += BATCH;
+            occ += BATCH;
+            have_pend = false;
+        }
+        if (!have_pend && nextbyte > 0) {
+            fetch_batch(p, nextbyte, pend);
+            have_pend = true;
+        }
+        // ---- one period: two groups of 16 symbols, each stored with one 16-byte write
+#pragma unroll
+        for (int g = 0; g < PERIOD / 16; ++g) {
+            if (cnt >= 16) {
+                uint32_t ow[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint32_t s0, s1, s2, s3;
+                    HUF_REFILL();
+                    HUF_SYM(s0);
+                    HUF_SYM(s1);
+                    HUF_REFILL();
+                    HUF_SYM(s2);
+                    HUF_SYM(s3);
+                    ow[q] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+                }
+                const uint4 v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+                __builtin_memcpy(o, &v, 16);
+                o += 16;
+                cnt -= 16;
+            } else if (cnt > 0) {
+                while (cnt > 0) {
+                    uint32_t s0;
+                    HUF_REFILL();
+                    HUF_SYM(s0);
+                    *o++ = (uint8_t)s0;
+                    --cnt;
+                }
+            }
+        }
+    }
+#undef HUF_REFILL
+#undef HUF_SYM
+    if (mine && bits_left != 0) bad = true;  // every bit of the stream must be consumed, none beyond
     ntask = 0;
     __syncthreads();  // also makes the decoded bytes visible to the whole wave (vmcnt drain)
     return __any(bad);
@@ -377,9 +566,12 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
     __syncthreads();
 }
 
-__global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code)
+__global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg)
 {
     __shared__ DecLds L;
+    unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long tlast = dbg ? __builtin_readcyclecounter() : 0;
+#define PHASE(k) do { if (dbg) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
     const int lane = threadIdx.x;
     if (b.gate && b.gate[r] >= E_FIRST) {
@@ -456,7 +648,9 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
 
     for (;;) {
         if (pos + 3 > n) FAIL();
-        const uint32_t bh = src[pos] | ((uint32_t)src[pos + 1] << 8) | ((uint32_t)src[pos + 2] << 16);
+        // one staged read covers the block header, the literals header and (treeless blocks) the jump table
+        stage_bytes(L.hbuf, src + pos, (n - pos) < 24 ? (n - pos) : 24, lane);
+        const uint32_t bh = L.hbuf[0] | ((uint32_t)L.hbuf[1] << 8) | ((uint32_t)L.hbuf[2] << 16);
         pos += 3;
         const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
         if (btype == 3) FAIL();
@@ -474,56 +668,55 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
         } else {  // Compressed_Block
             if (bsize >= BLOCK_MAX || pos + bsize > n || bsize < 2) FAIL();
             const uint8_t* blk = src + pos;
-            stage_bytes(L.hbuf, blk, bsize < HBUF ? bsize : HBUF, lane);
-            // ---- literals section header (3.1.1.3.1.1) and, for type 2, the tree description
-            if (lane == 0) {
-                uint32_t err = 0;
-                const uint8_t* h = L.hbuf;
-                const uint32_t type = h[0] & 3, fmt = (h[0] >> 2) & 3;
-                uint32_t lh = 0, regen = 0, csize = 0, streams = 1, tree_used = 0, nw = 0, tlog = 0;
-                if (type < 2) {
+            // ---- literals section header (3.1.1.3.1.1), parsed by every lane from the staged bytes
+            uint32_t ltype, lh = 0, regen = 0, csize = 0, streams = 1, tree_used = 0, nw = 0, tlog = 0;
+            uint32_t jt[3] = { 0, 0, 0 };  // jump table when it sits right behind the header (treeless blocks)
+            {
+                const uint8_t* h = L.hbuf + 3;
+                const uint32_t fmt = (h[0] >> 2) & 3;
+                ltype = h[0] & 3;
+                if (ltype < 2) {
                     if (fmt == 0 || fmt == 2) { lh = 1; regen = h[0] >> 3; }
                     else if (fmt == 1) { lh = 2; regen = (h[0] >> 4) | ((uint32_t)h[1] << 4); }
                     else { lh = 3; regen = (h[0] >> 4) | ((uint32_t)h[1] << 4) | ((uint32_t)h[2] << 12); }
-                    if (lh > bsize) err = 1;
-                    csize = type == 0 ? regen : 1;
+                    if (lh > bsize) FAIL();
+                    csize = ltype == 0 ? regen : 1;
                 } else {
-                    if (bsize < 5) err = 1;  // libzstd: srcSize >= 5 for compressed literals
+                    if (bsize < 5) FAIL();  // libzstd: srcSize >= 5 for compressed literals
                     const uint64_t v = h[0] | ((uint64_t)h[1] << 8) | ((uint64_t)h[2] << 16) | ((uint64_t)h[3] << 24) |
                                        ((uint64_t)h[4] << 32);
                     if (fmt < 2) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; streams = fmt == 0 ? 1 : 4; }
                     else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; streams = 4; }
                     else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; streams = 4; }
-                    if (regen == 0 || csize == 0) err = 1;
+                    if (regen == 0 || csize == 0) FAIL();
                 }
-                if (regen > BLOCK_MAX) err = 1;
-                if ((uint64_t)lh + csize > bsize) err = 1;
-                if (!err && type == 2) {
-                    int inw = 0, ilog = 0;
-                    const uint32_t avail = csize < (uint32_t)(HBUF - 8) ? csize : (uint32_t)(HBUF - 8);
-                    const int used = huf_read_weights(L, h + lh, (int)avail, &inw, &ilog);
-                    if (used < 0) err = 1;
-                    tree_used = (uint32_t)used;
-                    nw = (uint32_t)inw;
-                    tlog = (uint32_t)ilog;
-                } else if (!err && type == 3 && !huf_valid) {
-                    err = 1;
+                if (regen > BLOCK_MAX) FAIL();
+                if ((uint64_t)lh + csize > bsize) FAIL();
+                if (ltype == 3 && !huf_valid) FAIL();
+                if (ltype == 3) {
+                    jt[0] = h[lh] | ((uint32_t)h[lh + 1] << 8);
+                    jt[1] = h[lh + 2] | ((uint32_t)h[lh + 3] << 8);
+                    jt[2] = h[lh + 4] | ((uint32_t)h[lh + 5] << 8);
                 }
-                L.ctl[C_ERR] = err;
-                L.ctl[C_A] = type;
-                L.ctl[C_B] = lh;
-                L.ctl[C_C] = regen;
-                L.ctl[C_D] = csize;
-                L.ctl[C_E] = streams;
-                L.ctl[C_F] = tree_used;
-                L.ctl[C_G] = nw;
-                L.ctl[C_H] = tlog;
             }
             __syncthreads();
-            if (L.ctl[C_ERR]) FAIL();
-            const uint32_t ltype = L.ctl[C_A], lh = L.ctl[C_B], regen = L.ctl[C_C], csize = L.ctl[C_D];
-            const uint32_t streams = L.ctl[C_E], tree_used = L.ctl[C_F], nw = L.ctl[C_G], tlog = L.ctl[C_H];
             if (ltype == 2) {
+                // tree description: at most 129 bytes; lane 0 decodes the weights, the wave fills the table
+                const uint32_t tn = csize < 160 ? csize : 160;
+                stage_bytes(L.hbuf, blk + lh, tn, lane);
+                if (lane == 0) {
+                    int inw = 0, ilog = 0;
+                    const int used = huf_read_weights(L, L.hbuf, (int)tn, &inw, &ilog);
+                    L.ctl[C_ERR] = used < 0;
+                    L.ctl[C_F] = (uint32_t)used;
+                    L.ctl[C_G] = (uint32_t)inw;
+                    L.ctl[C_H] = (uint32_t)ilog;
+                }
+                __syncthreads();
+                if (L.ctl[C_ERR]) FAIL();
+                tree_used = L.ctl[C_F];
+                nw = L.ctl[C_G];
+                tlog = L.ctl[C_H];
                 // new Huffman table: pick the slot not used by the current table; pending tasks that
                 // still reference the slot we are about to overwrite must run first
                 int slot = huf_valid ? 1 - cur_slot : 0;
@@ -534,15 +727,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                     if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
                 }
                 if (tlog == 12) slot = 0;
-                uint16_t* T = &L.huf[0][0] + slot * 2048;
-                for (uint32_t s = 0; s < nw; ++s) {  // uniform loop; the wave fills each symbol's range
-                    const uint32_t wt = L.weights[s];
-                    if (wt == 0) continue;
-                    const uint32_t len = 1u << (wt - 1), st = L.wstart[s];
-                    const uint16_t ent = (uint16_t)(s | ((tlog + 1 - wt) << 8));
-                    for (uint32_t i = lane; i < len; i += WAVE) T[st + i] = ent;
-                }
-                __syncthreads();
+                huf_fill_table(L, &L.huf[0][0] + slot * 2048, nw, tlog, lane);
                 huf_valid = true;
                 cur_slot = slot;
                 cur_log = (int)tlog;
@@ -552,24 +737,23 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
             if (lit_end >= bsize) FAIL();
             const uint8_t* sq = blk + lit_end;
             const uint32_t sqn = bsize - lit_end;
-            stage_bytes(L.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
-            if (lane == 0) {
-                uint32_t err = 0, nseq = 0, used = 0;
-                const uint8_t* h = L.hbuf;
-                const int hn = (int)(sqn < HBUF ? sqn : HBUF);
-                nseq = h[0];
-                used = 1;
-                if (nseq >= 128) {
-                    if (nseq == 255) {
-                        if (hn < 3) err = 1; else { nseq = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
-                    } else {
-                        if (hn < 2) err = 1; else { nseq = ((nseq - 128) << 8) + h[1]; used = 2; }
+            uint32_t nseq = sq[0], sq_used = 1;
+            if (nseq == 0) {
+                if (sqn != 1) FAIL();
+            } else {
+                stage_bytes(L.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
+                if (lane == 0) {
+                    uint32_t err = 0, used = 1, ns = nseq;
+                    const uint8_t* h = L.hbuf;
+                    const int hn = (int)(sqn < HBUF ? sqn : HBUF);
+                    if (ns >= 128) {
+                        if (ns == 255) {
+                            if (hn < 3) err = 1; else { ns = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
+                        } else {
+                            if (hn < 2) err = 1; else { ns = ((ns - 128) << 8) + h[1]; used = 2; }
+                        }
                     }
-                }
-                if (!err && nseq == 0) {
-                    if (used != sqn) err = 1;
-                } else if (!err) {
-                    if ((int)used >= hn) err = 1;
+                    if (!err && (int)used >= hn) err = 1;
                     if (!err) {
                         const uint32_t modes = h[used++];
                         if (modes & 3) err = 1;
@@ -588,14 +772,15 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                         }
                         if (!err && used >= sqn) err = 1;
                     }
+                    L.ctl[C_ERR] = err;
+                    L.ctl[C_I] = ns;
+                    L.ctl[C_J] = used;
                 }
-                L.ctl[C_ERR] = err;
-                L.ctl[C_I] = nseq;
-                L.ctl[C_J] = used;
+                __syncthreads();
+                if (L.ctl[C_ERR]) FAIL();
+                nseq = L.ctl[C_I];
+                sq_used = L.ctl[C_J];
             }
-            __syncthreads();
-            if (L.ctl[C_ERR]) FAIL();
-            const uint32_t nseq = L.ctl[C_I], sq_used = L.ctl[C_J];
             if ((uint64_t)opos + regen > fcs) FAIL();
             // ---- literals: where do they go?
             //   no sequences : straight to the output (Huffman streams become pending tasks)
@@ -621,7 +806,12 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                     ntask += 1;
                 } else {
                     if (qn < 10) FAIL();
-                    const uint32_t s1 = q[0] | ((uint32_t)q[1] << 8), s2 = q[2] | ((uint32_t)q[3] << 8), s3 = q[4] | ((uint32_t)q[5] << 8);
+                    uint32_t s1 = jt[0], s2 = jt[1], s3 = jt[2];
+                    if (ltype == 2) {  // the jump table follows the tree description
+                        s1 = q[0] | ((uint32_t)q[1] << 8);
+                        s2 = q[2] | ((uint32_t)q[3] << 8);
+                        s3 = q[4] | ((uint32_t)q[5] << 8);
+                    }
                     q += 6;
                     qn -= 6;
                     if (s1 + s2 + s3 > qn) FAIL();
@@ -764,9 +954,11 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
         }
         if (last) break;
     }
+    PHASE(0);
     if (ntask) {
         if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
     }
+    PHASE(1);
     if (has_checksum) {
         if (pos + 4 > n) FAIL();
         pos += 4;  // xxh64 of the content: not verified
@@ -774,15 +966,18 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
     if (pos != n) FAIL();   // one frame per buffer (what vbz writes)
     if (opos != fcs) FAIL();
     if (lane == 0) b.result[r] = fcs;
+    if (dbg && lane == 0)
+        for (int k = 0; k < 6; ++k) dbg[(size_t)r * 8 + k] = tph[k];
+#undef PHASE
 #undef FAIL
 }
 
 }  // namespace
 
-hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, hipStream_t s)
+hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(zstd_decode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code);
+    hipLaunchKernelGGL(zstd_decode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg);
     return hipGetLastError();
 }
 

@@ -34,6 +34,7 @@ constexpr uint32_t BLOCK_MAX = 128u << 10;
 constexpr uint32_t MIN_BLOCK = 4096;      // target block size is at least this
 constexpr uint32_t SPLIT_MIN = 2048;      // frames smaller than this are one region
 constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams = 64 lanes)
+constexpr int OBUF_WORDS = (WAVE * 16 * 11) / 32 + 8;  // one step packs at most 1024 symbols of 11 bits
 
 struct EncLds
 {
@@ -48,7 +49,13 @@ struct EncLds
     int32_t treeSize;
     uint32_t mode;      // 0 raw, 1 rle, 2 huffman
     uint32_t huffLog;
+    uint32_t rankcnt[16];   // symbols per code length
     uint32_t ssize[WAVE];   // compressed bytes of each stream of the current pass
+    uint32_t sbeg[WAVE];    // first byte (region offset) of each stream of the current pass
+    uint32_t scnt[WAVE];    // symbols in each stream
+    uint32_t sbits[WAVE];   // sum of code lengths of each stream
+    uint32_t sout[WAVE];    // output offset of each stream
+    uint32_t obuf[OBUF_WORDS]; // bit buffer of the stream being packed
     uint32_t bopos[MAXBLK]; // output offset of each block of the current pass
     uint32_t passBytes;
 };
@@ -96,46 +103,230 @@ __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int l
     __syncthreads();
 }
 
-// lane 0: choose the coding mode of a region from its histogram and, for Huffman, build the table
-__device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk)
+// ---- table construction, wave-cooperative ---------------------------------------------------------------
+// Same result as huf_build()/huf_write_tree() of zstd_entropy.h (the serial statement of libzstd's
+// construction, checked against libzstd on the host), but every loop without a loop-carried dependency
+// runs across the 64 lanes: the sort becomes a rank computation (rank = number of symbols with a larger
+// (count, -symbol) key), code lengths come from each leaf walking its parent chain, canonical codes from
+// ballots in symbol order.  Lane 0 keeps only what is inherently serial: the two-queue tree merge, the
+// length-limit repair and the FSE coding of the weights.
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-    uint32_t maxSym = 255, maxCount = 0;
-    while (maxSym > 0 && L.hist[maxSym] == 0) maxSym--;
-    for (uint32_t s = 0; s <= maxSym; ++s) maxCount = L.hist[s] > maxCount ? L.hist[s] : maxCount;
-    L.treeSize = 0;
-    if (maxCount == S) { L.mode = 1; return; }
-    L.mode = 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// all lanes.  L.hist[0..maxSym] -> L.nbBits / L.code; returns the table log (uniform).
+__device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBits, int lane)
+{
+    HufNode* const node0 = L.hw.node;
+    HufNode* const node = node0 + 1;
+    {
+        uint2* z = reinterpret_cast<uint2*>(node0);
+        for (int i = lane; i < 513; i += WAVE) z[i] = make_uint2(0u, 0u);
+    }
+    __syncthreads();
+    uint32_t c[4], rank[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        c[j] = s <= maxSym ? L.hist[s] : 0u;
+        rank[j] = 0;
+    }
+    for (uint32_t t = 0; t <= maxSym; ++t) {
+        const uint32_t ct = L.hist[t];  // same address in every lane: an LDS broadcast
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s = (uint32_t)lane + 64u * j;
+            rank[j] += (ct > c[j]) || (ct == c[j] && t < s);
+        }
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        if (s <= maxSym) {
+            node[rank[j]].count = c[j];
+            node[rank[j]].byte = (uint8_t)s;
+            mine += c[j] != 0;
+        }
+    }
+    const uint32_t nleaf = wave_sum_u32(mine);
+    __syncthreads();
+    const int nonNullRank = (int)nleaf - 1;
+    const int nodeRoot = 256 + nonNullRank - 1;
+    if (lane == 0) {  // two-queue merge (zstd HUF_buildCTable_wksp), the only serial part of the tree
+        int lowS = nonNullRank, nodeNb = 256, lowN = 256;
+        node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
+        node[lowS].parent = node[lowS - 1].parent = (uint16_t)nodeNb;
+        nodeNb++;
+        lowS -= 2;
+        for (int n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
+        node0[0].count = 1u << 31;
+        uint32_t cS = node[lowS].count, cN = node[lowN].count;
+        while (nodeNb <= nodeRoot) {
+            int n1, n2;
+            uint32_t a, bcount;
+            if (cS < cN) { n1 = lowS--; a = cS; cS = node[lowS].count; } else { n1 = lowN++; a = cN; cN = node[lowN].count; }
+            if (cS < cN) { n2 = lowS--; bcount = cS; cS = node[lowS].count; } else { n2 = lowN++; bcount = cN; cN = node[lowN].count; }
+            node[nodeNb].count = a + bcount;
+            if (lowN == nodeNb) cN = a + bcount;  // the node just created is the next internal candidate
+            node[n1].parent = node[n2].parent = (uint16_t)nodeNb;
+            nodeNb++;
+        }
+    }
+    __syncthreads();
+    // code length of a leaf = length of its parent chain
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = lane + 64 * j;
+        if (rr <= nonNullRank) {
+            int n = node[rr].parent, d = 1;
+            while (n != nodeRoot) {
+                n = node[n].parent;
+                ++d;
+            }
+            node[rr].nbBits = (uint8_t)d;
+        }
+    }
+    __syncthreads();
+    if (lane == 0) L.huffLog = huf_set_max_height(node, (uint32_t)nonNullRank, maxNbBits);
+    for (int i = lane; i < 256; i += WAVE) L.nbBits[i] = 0;
+    if (lane < 16) L.rankcnt[lane] = 0;
+    __syncthreads();
+    maxNbBits = L.huffLog;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rr = lane + 64 * j;
+        if (rr <= nonNullRank) {
+            const uint32_t nb = node[rr].nbBits;
+            L.nbBits[node[rr].byte] = (uint8_t)nb;
+            atomicAdd(&L.rankcnt[nb], 1u);
+        }
+    }
+    __syncthreads();
+    // first code of every length (zstd: longest codes get the smallest values)
+    uint32_t val[HUF_ABS_MAX_BITS + 1];
+    {
+        uint32_t minv = 0;
+#pragma unroll
+        for (int n = HUF_ABS_MAX_BITS; n > 0; --n) {
+            const uint32_t cnt = (uint32_t)n <= maxNbBits ? L.rankcnt[n] : 0u;
+            val[n] = minv;
+            minv = (uint32_t)n <= maxNbBits ? ((minv + cnt) >> 1) : 0u;
+        }
+        val[0] = 0;
+    }
+    // codes in symbol order: within one length, consecutive values by increasing symbol
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        const uint32_t nb = L.nbBits[s];
+        uint32_t code = 0;
+#pragma unroll
+        for (int l = 1; l <= HUF_ABS_MAX_BITS; ++l) {
+            const uint64_t m = __ballot(nb == (uint32_t)l);
+            if (nb == (uint32_t)l) code = val[l] + (uint32_t)__popcll(m & below);
+            val[l] += (uint32_t)__popcll(m);
+        }
+        L.code[s] = (uint16_t)code;
+    }
+    __syncthreads();
+    return maxNbBits;
+}
+
+// all lanes: choose the coding mode of a region from its histogram and, for Huffman, build the table
+__device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
+{
+    uint32_t mx = 0, msym = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        const uint32_t h = L.hist[s];
+        mx = h > mx ? h : mx;
+        msym = h ? s : msym;
+    }
+    const uint32_t maxCount = wave_max_u32(mx);
+    const uint32_t maxSym = wave_max_u32(msym);
+    if (lane == 0) {
+        L.treeSize = 0;
+        L.mode = maxCount == S ? 1u : 0u;
+    }
+    __syncthreads();
+    if (maxCount == S) return;
     if (S <= 63) return;                       // libzstd stores such literals raw (minLitSize)
     if (maxCount <= (S >> 7) + 4) return;      // libzstd's "probably not compressible" heuristic
     // counts above 2^28 would overflow the node sums: scale the histogram down (still a valid code)
     uint32_t shift = 0;
     while ((S >> shift) >= (1u << 28)) shift++;
     if (shift) {
-        for (uint32_t s = 0; s <= maxSym; ++s)
-            if (L.hist[s]) { uint32_t c = L.hist[s] >> shift; L.hist[s] = c ? c : 1; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t s = (uint32_t)lane + 64u * j;
+            const uint32_t h = L.hist[s];
+            if (h) { const uint32_t cc = h >> shift; L.hist[s] = cc ? cc : 1u; }
+        }
+        __syncthreads();
     }
     const uint32_t logSrc = S < BLOCK_MAX ? S : BLOCK_MAX;
     uint32_t huffLog = optimal_table_log(HUF_MAX_BITS, logSrc, maxSym, 1);
-    huffLog = huf_build(L.hist, maxSym, huffLog, L.nbBits, L.code, &L.hw);
-    int ts = huf_write_tree(L.tree, 134, L.nbBits, maxSym, huffLog, L.weights, &L.fw);
-    if (ts < 0) return;
-    uint64_t bits = 0;
-    for (uint32_t s = 0; s <= maxSym; ++s) bits += (uint64_t)L.hist[s] * L.nbBits[s];
-    bits <<= shift;
-    const uint64_t est = (bits >> 3) + (uint64_t)ts + 14ull * nblk;
-    const uint64_t minGain = (S >> 6) + 2;     // ZSTD_minGain
-    if (est + minGain >= S) return;
-    for (uint32_t s = 0; s < 256; ++s)
-        L.ctable[s] = s <= maxSym ? ((uint32_t)L.code[s] | ((uint32_t)L.nbBits[s] << 16)) : 0u;
-    L.treeSize = ts;
-    L.huffLog = huffLog;
-    L.mode = 2;
+    huffLog = huf_build_wave(L, maxSym, huffLog, lane);
+    // weights (all but the last symbol's) and their histogram, in parallel
+    if (lane < 16) L.fw.count[lane] = 0;
+    __syncthreads();
+    uint64_t mybits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        const uint32_t nb = L.nbBits[s];
+        if (s < maxSym) {
+            const uint32_t wt = nb ? huffLog + 1 - nb : 0u;
+            L.weights[s] = (uint8_t)wt;
+            atomicAdd(&L.fw.count[wt], 1u);
+        }
+        mybits += (uint64_t)L.hist[s] * nb;
+        L.ctable[s] = s <= maxSym ? ((uint32_t)L.code[s] | (nb << 16)) : 0u;
+    }
+    uint64_t bits = mybits;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d, 64);
+    __syncthreads();
+    if (lane == 0) {
+        const int ts = huf_write_tree(L.tree, 134, L.nbBits, maxSym, huffLog, L.weights, &L.fw, true);
+        bool ok = ts >= 0;
+        if (ok) {
+            const uint64_t est = ((bits << shift) >> 3) + (uint64_t)ts + 14ull * nblk;
+            const uint64_t minGain = (S >> 6) + 2;  // ZSTD_minGain
+            ok = est + minGain < S;
+        }
+        if (ok) {
+            L.treeSize = ts;
+            L.huffLog = huffLog;
+            L.mode = 2;
+        }
+    }
+    __syncthreads();
 }
 
-__global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
-                                                           const uint32_t* key_bytes, uint32_t hdr)
+__global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
+                                                           const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg)
 {
     __shared__ EncLds L;
+    unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long tlast = dbg ? __builtin_readcyclecounter() : 0;
+#define PHASE(k) do { if (dbg) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
     const int lane = threadIdx.x;
     if (b.gate && b.gate[r] >= E_FIRST) {
@@ -189,9 +380,12 @@ __global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const ui
         const bool lastRegion = (r1 == N);
         const uint8_t* rin = in + r0;
         uint32_t nblk = (S + T - 1) / T;
+        PHASE(0);
         region_histogram(L, rin, S, lane);
-        if (lane == 0) region_plan(L, S, nblk);
+        PHASE(1);
+        region_plan(L, S, nblk, lane);
         __syncthreads();
+        PHASE(2);
         const uint32_t mode = L.mode;
         if (mode == 1) {
             // RLE blocks (Block_Type 1): Block_Size = run length, one byte of content
@@ -231,9 +425,9 @@ __global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const ui
         const uint32_t treeSize = (uint32_t)L.treeSize;
         for (uint32_t b0 = 0; b0 < nblk; b0 += MAXBLK) {
             const uint32_t nb = (nblk - b0) < (uint32_t)MAXBLK ? (nblk - b0) : (uint32_t)MAXBLK;
-            const uint32_t bj = b0 + (uint32_t)(lane >> 2);   // this lane's block
-            const int q = lane & 3;                           // and its stream within the block
-            bool active = (uint32_t)(lane >> 2) < nb;
+            const uint32_t bj = b0 + (uint32_t)(lane >> 2);   // this lane describes stream q of block bj
+            const int q = lane & 3;
+            const bool active = (uint32_t)(lane >> 2) < nb;
             uint32_t bs = 0, boff = 0;
             if (active) {
                 bs = base + (bj < extra ? 1u : 0u);
@@ -242,25 +436,60 @@ __global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const ui
             const bool single = bs < 256;
             const uint32_t seg = single ? bs : (bs + 3) >> 2;
             uint32_t cnt = 0;
-            const uint8_t* sp = rin + boff + (uint32_t)q * seg;
             if (active) {
                 if (single) cnt = q == 0 ? bs : 0;
                 else cnt = q < 3 ? seg : bs - 3 * seg;
             }
-            // --- size pass: bytes of this lane's stream
-            uint32_t bits = 0;
+            // byte range of the pass inside the region, and every stream's [begin, begin+count)
+            const uint32_t pb0 = b0 * base + (b0 < extra ? b0 : extra);
+            const uint32_t pbe = (b0 + nb) * base + ((b0 + nb) < extra ? (b0 + nb) : extra);
+            // empty streams (single-stream blocks, lanes past the last block) sit at the end of their block
+            L.sbeg[lane] = active ? (cnt ? boff + (uint32_t)q * seg : boff + bs) : pbe;
+            L.scnt[lane] = cnt;
+            L.sbits[lane] = 0;
+            __syncthreads();
+            // --- size sweep: the wave reads the pass's bytes once, coalesced, and sums the code lengths
+            // of every stream (a lane keeps a running sum while it stays inside one stream)
             {
-                uint32_t i = cnt;
-                while (i >= 4) {
-                    uint32_t w;
-                    __builtin_memcpy(&w, sp + i - 4, 4);
-                    bits += (L.ctable[w & 0xFF] >> 16) + (L.ctable[(w >> 8) & 0xFF] >> 16) +
-                            (L.ctable[(w >> 16) & 0xFF] >> 16) + (L.ctable[w >> 24] >> 16);
-                    i -= 4;
+                uint32_t sid = 0, acc = 0;
+                uint32_t cur_end = L.sbeg[0] + L.scnt[0];
+                for (uint32_t pos0 = pb0; pos0 < pbe; pos0 += WAVE * 16) {
+                    const uint32_t pos = pos0 + (uint32_t)lane * 16;
+                    if (pos >= pbe) break;
+                    uint4 v;
+                    __builtin_memcpy(&v, rin + pos, 16);
+                    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+                    // advance to the stream that holds `pos` (streams are contiguous and ordered)
+                    while (pos >= cur_end && sid < WAVE - 1) {
+                        if (acc) atomicAdd(&L.sbits[sid], acc);
+                        acc = 0;
+                        ++sid;
+                        cur_end = L.sbeg[sid] + L.scnt[sid];
+                    }
+                    if (pos + 16 <= cur_end) {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const uint32_t pk = pos + (uint32_t)k;
+                            if (pk < pbe) {
+                                while (pk >= cur_end && sid < WAVE - 1) {
+                                    if (acc) atomicAdd(&L.sbits[sid], acc);
+                                    acc = 0;
+                                    ++sid;
+                                    cur_end = L.sbeg[sid] + L.scnt[sid];
+                                }
+                                acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
+                            }
+                        }
+                    }
                 }
-                while (i > 0) { bits += L.ctable[sp[i - 1]] >> 16; --i; }
+                if (acc) atomicAdd(&L.sbits[sid], acc);
             }
-            const uint32_t sbytes = (active && cnt) ? (bits >> 3) + 1 : 0;
+            __syncthreads();
+            PHASE(3);
+            const uint32_t sbytes = (active && cnt) ? (L.sbits[lane] >> 3) + 1 : 0;
             L.ssize[lane] = sbytes;
             __syncthreads();
             // --- block layout (lane 0), then headers (first lane of each block)
@@ -281,7 +510,6 @@ __global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const ui
             __syncthreads();
             const uint32_t passBytes = L.passBytes;
             NEED(passBytes);
-            uint8_t* sop = nullptr;  // where this lane's stream goes
             if (active) {
                 const uint32_t j = (uint32_t)(lane >> 2);
                 const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
@@ -306,53 +534,110 @@ __global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const ui
                     }
                     bp[3 + lh + lit] = 0;  // Number_of_Sequences = 0
                 }
-                sop = bp + 3 + lh + tsz + (single ? 0 : 6) + (q > 0 ? s0 : 0) + (q > 1 ? s1 : 0) + (q > 2 ? s2 : 0);
+                // where this lane's stream starts in the output (offset from `out`)
+                L.sout[lane] = L.bopos[j] + 3 + lh + tsz + (single ? 0 : 6) + (q > 0 ? s0 : 0) + (q > 1 ? s1 : 0) + (q > 2 ? s2 : 0);
             }
-            // --- encode pass: symbols from the end of the stream to its start (RFC 8878 4.2.2)
-            if (active && cnt) {
-                uint64_t acc = 0;
-                uint32_t nbit = 0;
-                uint8_t* op = sop;
-                uint32_t i = cnt;
-                while (i >= 4) {
-                    uint32_t w;
-                    __builtin_memcpy(&w, sp + i - 4, 4);
-                    const uint32_t e3 = L.ctable[w >> 24], e2 = L.ctable[(w >> 16) & 0xFF];
-                    const uint32_t e1 = L.ctable[(w >> 8) & 0xFF], e0 = L.ctable[w & 0xFF];
-                    acc |= (uint64_t)(e3 & 0xFFFF) << nbit; nbit += e3 >> 16;
-                    acc |= (uint64_t)(e2 & 0xFFFF) << nbit; nbit += e2 >> 16;
-                    if (nbit >= 32) { uint32_t lo = (uint32_t)acc; __builtin_memcpy(op, &lo, 4); op += 4; acc >>= 32; nbit -= 32; }
-                    acc |= (uint64_t)(e1 & 0xFFFF) << nbit; nbit += e1 >> 16;
-                    acc |= (uint64_t)(e0 & 0xFFFF) << nbit; nbit += e0 >> 16;
-                    if (nbit >= 32) { uint32_t lo = (uint32_t)acc; __builtin_memcpy(op, &lo, 4); op += 4; acc >>= 32; nbit -= 32; }
-                    i -= 4;
+            __syncthreads();
+            PHASE(4);
+            // --- encode: the wave packs one stream at a time, 1024 symbols per step, from the end of the
+            // stream to its start (RFC 8878 4.2.2: the last symbol is written first).  Lane l takes the 16
+            // symbols that end 16*l before the step's end; a wave prefix sum of the lanes' bit counts gives
+            // every lane its bit offset; the bits are OR-ed into an LDS buffer that is written out as
+            // coalesced dwords.
+            for (uint32_t st = 0; st < 4 * nb; ++st) {
+                const uint32_t scnt = L.scnt[st];
+                if (scnt == 0) continue;
+                const uint32_t sb = L.sbeg[st];
+                uint8_t* sop = out + L.sout[st];
+                for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;
+                __syncthreads();
+                uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
+                uint32_t flushed = 0;     // bytes of the stream already written to memory
+                for (uint32_t done = 0; done < scnt; done += WAVE * 16) {
+                    // chunk of this lane: positions [lo, hi) of the region, consumed from hi-1 down to lo
+                    const int64_t hi = (int64_t)sb + scnt - done - 16 * (int64_t)lane;
+                    const int64_t lo = hi - 16;
+                    uint32_t w[4] = { 0, 0, 0, 0 };
+                    if (hi > (int64_t)sb) {
+                        if ((int64_t)r0 + lo >= 0) {
+                            uint4 v;
+                            __builtin_memcpy(&v, rin + lo, 16);  // may start before the stream: those bytes are masked below
+                            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                        } else {  // never read in front of the input buffer
+                            for (int k = 0; k < 16; ++k)
+                                if (lo + k >= (int64_t)sb) w[k >> 2] |= (uint32_t)rin[lo + k] << (8 * (k & 3));
+                        }
+                    }
+                    uint32_t e[16];
+                    uint32_t T = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const bool ok = (lo + k >= (int64_t)sb) && (hi > (int64_t)sb);
+                        const uint32_t ent = L.ctable[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
+                        e[k] = ok ? ent : 0u;
+                        T += e[k] >> 16;
+                    }
+                    const uint32_t incl = wave_incl_scan_u32(T);
+                    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+                    uint32_t pos = base_bits + incl - T;
+                    uint32_t word = pos >> 5;
+                    uint32_t accbits = pos & 31;
+                    uint64_t acc = 0;
+#pragma unroll
+                    for (int k = 15; k >= 0; --k) {
+                        acc |= (uint64_t)(e[k] & 0xFFFF) << accbits;
+                        accbits += e[k] >> 16;
+                        if (accbits >= 32) {
+                            atomicOr(&L.obuf[word], (uint32_t)acc);
+                            acc >>= 32;
+                            accbits -= 32;
+                            ++word;
+                        }
+                    }
+                    if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
+                    __syncthreads();
+                    const uint32_t allbits = base_bits + total;
+                    const uint32_t full = allbits >> 5;
+                    for (uint32_t i = lane; i < full; i += WAVE) {
+                        const uint32_t v = L.obuf[i];
+                        __builtin_memcpy(sop + flushed + 4 * i, &v, 4);
+                    }
+                    const uint32_t carry = L.obuf[full];
+                    __syncthreads();
+                    for (uint32_t i = lane; i <= full; i += WAVE) L.obuf[i] = 0;
+                    __syncthreads();
+                    if (lane == 0) L.obuf[0] = carry;
+                    flushed += 4 * full;
+                    base_bits = allbits & 31;
+                    __syncthreads();
                 }
-                while (i > 0) {
-                    const uint32_t e = L.ctable[sp[i - 1]];
-                    acc |= (uint64_t)(e & 0xFFFF) << nbit; nbit += e >> 16;
-                    if (nbit >= 32) { uint32_t lo = (uint32_t)acc; __builtin_memcpy(op, &lo, 4); op += 4; acc >>= 32; nbit -= 32; }
-                    --i;
+                // end mark and the last partial word
+                if (lane == 0) {
+                    const uint32_t v = L.obuf[0] | (1u << base_bits);
+                    const uint32_t nbytes = (base_bits + 1 + 7) >> 3;
+                    for (uint32_t k = 0; k < nbytes; ++k) sop[flushed + k] = (uint8_t)(v >> (8 * k));
                 }
-                acc |= 1ull << nbit;  // end mark
-                nbit += 1;
-                const uint32_t nbytes = (nbit + 7) >> 3;
-                for (uint32_t k = 0; k < nbytes; ++k) op[k] = (uint8_t)(acc >> (8 * k));
+                __syncthreads();
             }
             opos += passBytes;
             __syncthreads();
+            PHASE(5);
         }
     }
     if (lane == 0) b.result[r] = opos;
+    if (dbg && lane == 0)
+        for (int k = 0; k < 6; ++k) dbg[(size_t)r * 8 + k] = tph[k];
+#undef PHASE
 #undef NEED
 }
 
 }  // namespace
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                              uint32_t hdr, hipStream_t s)
+                              uint32_t hdr, unsigned long long* dbg, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(zstd_encode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr);
+    hipLaunchKernelGGL(zstd_encode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg);
     return hipGetLastError();
 }
 

@@ -414,15 +414,19 @@ VBZ_HDN int fse_write_ncount(uint8_t* out, int cap, const int16_t* norm, uint32_
 
 // FSE-compress the weight list (zstd HUF_compressWeights). Returns bytes, 0 = not compressible,
 // 1 = single repeated weight (caller falls back), -1 = error.
-VBZ_HDN int huf_compress_weights(uint8_t* dst, int cap, const uint8_t* weights, uint32_t wtSize, FseWeightWksp* w)
+// `counted`: w->count[0..12] already holds the histogram of the weights (the wave fills it in parallel)
+VBZ_HDN int huf_compress_weights(uint8_t* dst, int cap, const uint8_t* weights, uint32_t wtSize, FseWeightWksp* w,
+                                 bool counted = false)
 {
     uint8_t* op = dst;
     uint8_t* const oend = dst + cap;
     uint32_t maxSymbolValue = HUF_ABS_MAX_BITS;
     if (wtSize <= 1) return 0;
-    for (int i = 0; i < 16; ++i) w->count[i] = 0;
     uint32_t maxCount = 0;
-    for (uint32_t i = 0; i < wtSize; ++i) w->count[weights[i]]++;
+    if (!counted) {
+        for (int i = 0; i < 16; ++i) w->count[i] = 0;
+        for (uint32_t i = 0; i < wtSize; ++i) w->count[weights[i]]++;
+    }
     while (w->count[maxSymbolValue] == 0) maxSymbolValue--;
     for (uint32_t s = 0; s <= maxSymbolValue; ++s)
         if (w->count[s] > maxCount) maxCount = w->count[s];
@@ -537,13 +541,15 @@ VBZ_HDN int huf_compress_weights(uint8_t* dst, int cap, const uint8_t* weights, 
 
 // Huffman tree description (zstd HUF_writeCTable). nbBits[0..maxSymbolValue], huffLog = table log.
 // Returns bytes written (<= 129) or -1.  `weights` is a 256-byte scratch.
+// `prepared`: weights[0..maxSymbolValue) and w->count[] were already filled by the caller.
 VBZ_HDN int huf_write_tree(uint8_t* dst, int cap, const uint8_t* nbBits, uint32_t maxSymbolValue, uint32_t huffLog,
-                           uint8_t* weights, FseWeightWksp* w)
+                           uint8_t* weights, FseWeightWksp* w, bool prepared = false)
 {
     if (cap < 1) return -1;
-    for (uint32_t n = 0; n < maxSymbolValue; n++) weights[n] = nbBits[n] ? (uint8_t)(huffLog + 1 - nbBits[n]) : 0;
+    if (!prepared)
+        for (uint32_t n = 0; n < maxSymbolValue; n++) weights[n] = nbBits[n] ? (uint8_t)(huffLog + 1 - nbBits[n]) : 0;
     {
-        int hSize = huf_compress_weights(dst + 1, cap - 1, weights, maxSymbolValue, w);
+        int hSize = huf_compress_weights(dst + 1, cap - 1, weights, maxSymbolValue, w, prepared);
         if (hSize < 0) return -1;
         if ((hSize > 1) && ((uint32_t)hSize < maxSymbolValue / 2)) {
             dst[0] = (uint8_t)hSize;
