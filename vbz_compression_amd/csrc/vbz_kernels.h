@@ -72,6 +72,16 @@ hipError_t launch_synth_u32(uint64_t seed, uint64_t first, uint32_t n, uint8_t* 
                             const uint32_t* len, hipStream_t s);
 
 // ---- wave / workgroup primitives ---------------------------------------------------------------
+// For single-wave workgroups.  The LDS operations of one wave execute in issue order, so lanes of the same
+// wave can hand data to each other through LDS without an s_barrier -- and, unlike __syncthreads(), without
+// waiting for the wave's outstanding global stores.  This only pins the program order for the compiler.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
     const int lane = threadIdx.x & 63;

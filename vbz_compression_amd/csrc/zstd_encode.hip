@@ -34,7 +34,9 @@ constexpr uint32_t BLOCK_MAX = 128u << 10;
 constexpr uint32_t MIN_BLOCK = 4096;      // target block size is at least this
 constexpr uint32_t SPLIT_MIN = 2048;      // frames smaller than this are one region
 constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams = 64 lanes)
-constexpr int OBUF_WORDS = (WAVE * 16 * 11) / 32 + 8;  // one step packs at most 1024 symbols of 11 bits
+constexpr int STEP_LANE = 32;               // symbols packed per lane per step
+constexpr int STEP_SYMS = WAVE * STEP_LANE; // symbols packed per wave step
+constexpr int OBUF_WORDS = (STEP_SYMS * 11) / 32 + 8;  // one step packs at most 2048 symbols of 11 bits
 
 struct EncLds
 {
@@ -69,7 +71,7 @@ __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
 __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane)
 {
     for (int i = lane; i < 256; i += WAVE) L.hist[i] = 0;
-    __syncthreads();
+    wave_lds_sync();
     uint32_t zeros = 0;
     const uint32_t head = (uint32_t)((16u - ((uintptr_t)in & 15u)) & 15u);
     const uint32_t h = head < n ? head : n;
@@ -79,15 +81,26 @@ __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int l
     }
     const uint32_t nvec = (n - h) >> 4;
     const uint4* vp = reinterpret_cast<const uint4*>(in + h);
-    for (uint32_t c = lane; c < nvec; c += WAVE) {
-        uint4 q = vp[c];
-        const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+    for (uint32_t c0 = 0; c0 < nvec; c0 += 4 * WAVE) {
+        uint4 q[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int u = 0; u < 4; ++u) {  // four independent 16-byte loads in flight per lane
+            const uint32_t c = c0 + (uint32_t)u * WAVE + (uint32_t)lane;
+            q[u] = c < nvec ? vp[c] : make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t v = (w[k] >> (8 * j)) & 0xFFu;
-                if (v) atomicAdd(&L.hist[v], 1u); else zeros++;
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t c = c0 + (uint32_t)u * WAVE + (uint32_t)lane;
+            if (c < nvec) {
+                const uint32_t w[4] = { q[u].x, q[u].y, q[u].z, q[u].w };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        uint32_t v = (w[k] >> (8 * j)) & 0xFFu;
+                        if (v) atomicAdd(&L.hist[v], 1u); else zeros++;
+                    }
+                }
             }
         }
     }
@@ -98,9 +111,9 @@ __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int l
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) zeros += __shfl_xor(zeros, d, 64);
-    __syncthreads();
+    wave_lds_sync();
     if (lane == 0) L.hist[0] += zeros;
-    __syncthreads();
+    wave_lds_sync();
 }
 
 // ---- table construction, wave-cooperative ---------------------------------------------------------------
@@ -136,7 +149,7 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
         uint2* z = reinterpret_cast<uint2*>(node0);
         for (int i = lane; i < 513; i += WAVE) z[i] = make_uint2(0u, 0u);
     }
-    __syncthreads();
+    wave_lds_sync();
     uint32_t c[4], rank[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -163,7 +176,7 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
         }
     }
     const uint32_t nleaf = wave_sum_u32(mine);
-    __syncthreads();
+    wave_lds_sync();
     const int nonNullRank = (int)nleaf - 1;
     const int nodeRoot = 256 + nonNullRank - 1;
     if (lane == 0) {  // two-queue merge (zstd HUF_buildCTable_wksp), the only serial part of the tree
@@ -186,7 +199,7 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
             nodeNb++;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     // code length of a leaf = length of its parent chain
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -200,11 +213,11 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
             node[rr].nbBits = (uint8_t)d;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     if (lane == 0) L.huffLog = huf_set_max_height(node, (uint32_t)nonNullRank, maxNbBits);
     for (int i = lane; i < 256; i += WAVE) L.nbBits[i] = 0;
     if (lane < 16) L.rankcnt[lane] = 0;
-    __syncthreads();
+    wave_lds_sync();
     maxNbBits = L.huffLog;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -215,7 +228,7 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
             atomicAdd(&L.rankcnt[nb], 1u);
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     // first code of every length (zstd: longest codes get the smallest values)
     uint32_t val[HUF_ABS_MAX_BITS + 1];
     {
@@ -243,7 +256,7 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
         }
         L.code[s] = (uint16_t)code;
     }
-    __syncthreads();
+    wave_lds_sync();
     return maxNbBits;
 }
 
@@ -264,7 +277,7 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
         L.treeSize = 0;
         L.mode = maxCount == S ? 1u : 0u;
     }
-    __syncthreads();
+    wave_lds_sync();
     if (maxCount == S) return;
     if (S <= 63) return;                       // libzstd stores such literals raw (minLitSize)
     if (maxCount <= (S >> 7) + 4) return;      // libzstd's "probably not compressible" heuristic
@@ -278,14 +291,14 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
             const uint32_t h = L.hist[s];
             if (h) { const uint32_t cc = h >> shift; L.hist[s] = cc ? cc : 1u; }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
     const uint32_t logSrc = S < BLOCK_MAX ? S : BLOCK_MAX;
     uint32_t huffLog = optimal_table_log(HUF_MAX_BITS, logSrc, maxSym, 1);
     huffLog = huf_build_wave(L, maxSym, huffLog, lane);
     // weights (all but the last symbol's) and their histogram, in parallel
     if (lane < 16) L.fw.count[lane] = 0;
-    __syncthreads();
+    wave_lds_sync();
     uint64_t mybits = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -302,7 +315,7 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
     uint64_t bits = mybits;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d, 64);
-    __syncthreads();
+    wave_lds_sync();
     if (lane == 0) {
         const int ts = huf_write_tree(L.tree, 134, L.nbBits, maxSym, huffLog, L.weights, &L.fw, true);
         bool ok = ts >= 0;
@@ -317,10 +330,10 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
             L.mode = 2;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 }
 
-__global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
+__global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg)
 {
     __shared__ EncLds L;
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const
         region_histogram(L, rin, S, lane);
         PHASE(1);
         region_plan(L, S, nblk, lane);
-        __syncthreads();
+        wave_lds_sync();
         PHASE(2);
         const uint32_t mode = L.mode;
         if (mode == 1) {
@@ -447,51 +460,59 @@ __global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const
             L.sbeg[lane] = active ? (cnt ? boff + (uint32_t)q * seg : boff + bs) : pbe;
             L.scnt[lane] = cnt;
             L.sbits[lane] = 0;
-            __syncthreads();
+            wave_lds_sync();
             // --- size sweep: the wave reads the pass's bytes once, coalesced, and sums the code lengths
             // of every stream (a lane keeps a running sum while it stays inside one stream)
             {
                 uint32_t sid = 0, acc = 0;
                 uint32_t cur_end = L.sbeg[0] + L.scnt[0];
-                for (uint32_t pos0 = pb0; pos0 < pbe; pos0 += WAVE * 16) {
-                    const uint32_t pos = pos0 + (uint32_t)lane * 16;
-                    if (pos >= pbe) break;
-                    uint4 v;
-                    __builtin_memcpy(&v, rin + pos, 16);
-                    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-                    // advance to the stream that holds `pos` (streams are contiguous and ordered)
-                    while (pos >= cur_end && sid < WAVE - 1) {
-                        if (acc) atomicAdd(&L.sbits[sid], acc);
-                        acc = 0;
-                        ++sid;
-                        cur_end = L.sbeg[sid] + L.scnt[sid];
+                for (uint32_t pos0 = pb0; pos0 < pbe; pos0 += 4 * WAVE * 16) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {  // four independent 16-byte loads in flight per lane
+                        const uint32_t pos = pos0 + (uint32_t)u * WAVE * 16 + (uint32_t)lane * 16;
+                        v[u] = make_uint4(0u, 0u, 0u, 0u);
+                        if (pos < pbe) __builtin_memcpy(&v[u], rin + pos, 16);
                     }
-                    if (pos + 16 <= cur_end) {
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                    } else {
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t pos = pos0 + (uint32_t)u * WAVE * 16 + (uint32_t)lane * 16;
+                        if (pos >= pbe) continue;
+                        const uint32_t w[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
+                        // advance to the stream that holds `pos` (streams are contiguous and ordered)
+                        while (pos >= cur_end && sid < WAVE - 1) {
+                            if (acc) atomicAdd(&L.sbits[sid], acc);
+                            acc = 0;
+                            ++sid;
+                            cur_end = L.sbeg[sid] + L.scnt[sid];
+                        }
+                        if (pos + 16 <= cur_end) {
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const uint32_t pk = pos + (uint32_t)k;
-                            if (pk < pbe) {
-                                while (pk >= cur_end && sid < WAVE - 1) {
-                                    if (acc) atomicAdd(&L.sbits[sid], acc);
-                                    acc = 0;
-                                    ++sid;
-                                    cur_end = L.sbeg[sid] + L.scnt[sid];
+                            for (int k = 0; k < 16; ++k) acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                const uint32_t pk = pos + (uint32_t)k;
+                                if (pk < pbe) {
+                                    while (pk >= cur_end && sid < WAVE - 1) {
+                                        if (acc) atomicAdd(&L.sbits[sid], acc);
+                                        acc = 0;
+                                        ++sid;
+                                        cur_end = L.sbeg[sid] + L.scnt[sid];
+                                    }
+                                    acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
                                 }
-                                acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
                             }
                         }
                     }
                 }
                 if (acc) atomicAdd(&L.sbits[sid], acc);
             }
-            __syncthreads();
+            wave_lds_sync();
             PHASE(3);
             const uint32_t sbytes = (active && cnt) ? (L.sbits[lane] >> 3) + 1 : 0;
             L.ssize[lane] = sbytes;
-            __syncthreads();
+            wave_lds_sync();
             // --- block layout (lane 0), then headers (first lane of each block)
             if (lane == 0) {
                 uint32_t o = opos;
@@ -507,7 +528,7 @@ __global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const
                 }
                 L.passBytes = o - opos;
             }
-            __syncthreads();
+            wave_lds_sync();
             const uint32_t passBytes = L.passBytes;
             NEED(passBytes);
             if (active) {
@@ -537,56 +558,85 @@ __global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const
                 // where this lane's stream starts in the output (offset from `out`)
                 L.sout[lane] = L.bopos[j] + 3 + lh + tsz + (single ? 0 : 6) + (q > 0 ? s0 : 0) + (q > 1 ? s1 : 0) + (q > 2 ? s2 : 0);
             }
-            __syncthreads();
+            wave_lds_sync();
             PHASE(4);
             // --- encode: the wave packs one stream at a time, 1024 symbols per step, from the end of the
             // stream to its start (RFC 8878 4.2.2: the last symbol is written first).  Lane l takes the 16
             // symbols that end 16*l before the step's end; a wave prefix sum of the lanes' bit counts gives
             // every lane its bit offset; the bits are OR-ed into an LDS buffer that is written out as
             // coalesced dwords.
-            for (uint32_t st = 0; st < 4 * nb; ++st) {
-                const uint32_t scnt = L.scnt[st];
-                if (scnt == 0) continue;
-                const uint32_t sb = L.sbeg[st];
-                uint8_t* sop = out + L.sout[st];
+            {
                 for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;
-                __syncthreads();
-                uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
-                uint32_t flushed = 0;     // bytes of the stream already written to memory
-                for (uint32_t done = 0; done < scnt; done += WAVE * 16) {
-                    // chunk of this lane: positions [lo, hi) of the region, consumed from hi-1 down to lo
-                    const int64_t hi = (int64_t)sb + scnt - done - 16 * (int64_t)lane;
-                    const int64_t lo = hi - 16;
-                    uint32_t w[4] = { 0, 0, 0, 0 };
-                    if (hi > (int64_t)sb) {
+                wave_lds_sync();
+                // work items = (stream, step) pairs in order; the chunk of the next item is requested
+                // before the current one is packed, so its latency is hidden behind the packing
+                uint32_t st = 0;
+                while (st < 4 * nb && L.scnt[st] == 0) ++st;
+                uint32_t done = 0;
+                uint32_t cur[8], nxt[8];
+                auto load_chunk = [&](uint32_t sbeg, uint32_t scount, uint32_t dn, uint32_t (&w)[8]) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) w[k] = 0;
+                    const int64_t hi = (int64_t)sbeg + scount - dn - STEP_LANE * (int64_t)lane;
+                    const int64_t lo = hi - STEP_LANE;
+                    if (hi > (int64_t)sbeg) {
                         if ((int64_t)r0 + lo >= 0) {
-                            uint4 v;
-                            __builtin_memcpy(&v, rin + lo, 16);  // may start before the stream: those bytes are masked below
-                            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+                            uint4 v0, v1;
+                            __builtin_memcpy(&v0, rin + lo, 16);       // may start before the stream:
+                            __builtin_memcpy(&v1, rin + lo + 16, 16);  // those bytes are masked when used
+                            w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+                            w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
                         } else {  // never read in front of the input buffer
-                            for (int k = 0; k < 16; ++k)
-                                if (lo + k >= (int64_t)sb) w[k >> 2] |= (uint32_t)rin[lo + k] << (8 * (k & 3));
+#pragma unroll
+                            for (int k = 0; k < STEP_LANE; ++k) {
+                                const uint32_t byte = (lo + k >= (int64_t)sbeg) ? (uint32_t)rin[lo + k] : 0u;
+                                w[k >> 2] |= byte << (8 * (k & 3));
+                            }
                         }
                     }
-                    uint32_t e[16];
+                };
+                if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
+                uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
+                uint32_t flushed = 0;     // bytes of the stream already written to memory
+                while (st < 4 * nb) {
+                    const uint32_t scnt = L.scnt[st];
+                    const uint32_t sb = L.sbeg[st];
+                    uint8_t* sop = out + L.sout[st];
+                    // next work item
+                    uint32_t nst = st, ndone = done + STEP_SYMS;
+                    if (ndone >= scnt) {
+                        ndone = 0;
+                        ++nst;
+                        while (nst < 4 * nb && L.scnt[nst] == 0) ++nst;
+                    }
+                    if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, nxt);
+                    // this lane's symbols: positions [lo, hi) of the region, packed from hi-1 down to lo;
+                    // the first `skip` of its 32 bytes lie before the stream (or the lane is past its start)
+                    const int64_t hi = (int64_t)sb + scnt - done - STEP_LANE * (int64_t)lane;
+                    const int64_t room = hi - (int64_t)sb;
+                    const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
+                    uint32_t ent[STEP_LANE];
                     uint32_t T = 0;
 #pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        const bool ok = (lo + k >= (int64_t)sb) && (hi > (int64_t)sb);
-                        const uint32_t ent = L.ctable[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                        e[k] = ok ? ent : 0u;
-                        T += e[k] >> 16;
+                    for (int k = 0; k < STEP_LANE; ++k) {
+                        const uint32_t e = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
+                        ent[k] = k >= skip ? e : 0u;
+                        T += ent[k] >> 16;
                     }
                     const uint32_t incl = wave_incl_scan_u32(T);
                     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-                    uint32_t pos = base_bits + incl - T;
+                    const uint32_t pos = base_bits + incl - T;
                     uint32_t word = pos >> 5;
                     uint32_t accbits = pos & 31;
                     uint64_t acc = 0;
 #pragma unroll
-                    for (int k = 15; k >= 0; --k) {
-                        acc |= (uint64_t)(e[k] & 0xFFFF) << accbits;
-                        accbits += e[k] >> 16;
+                    for (int k = STEP_LANE - 1; k >= 0; k -= 2) {
+                        // two symbols (at most 22 bits) per flush check: accbits < 32 before, < 54 after
+                        const uint32_t e1 = ent[k], e0 = ent[k - 1];
+                        const uint32_t l1 = e1 >> 16;
+                        const uint64_t pair = (uint64_t)((e1 & 0xFFFF) | ((e0 & 0xFFFF) << l1));
+                        acc |= pair << accbits;
+                        accbits += l1 + (e0 >> 16);
                         if (accbits >= 32) {
                             atomicOr(&L.obuf[word], (uint32_t)acc);
                             acc >>= 32;
@@ -595,7 +645,7 @@ __global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const
                         }
                     }
                     if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
-                    __syncthreads();
+                    wave_lds_sync();
                     const uint32_t allbits = base_bits + total;
                     const uint32_t full = allbits >> 5;
                     for (uint32_t i = lane; i < full; i += WAVE) {
@@ -603,24 +653,32 @@ __global__ __launch_bounds__(WAVE, 4) void zstd_encode_kernel(ReadBatch b, const
                         __builtin_memcpy(sop + flushed + 4 * i, &v, 4);
                     }
                     const uint32_t carry = L.obuf[full];
-                    __syncthreads();
+                    wave_lds_sync();
                     for (uint32_t i = lane; i <= full; i += WAVE) L.obuf[i] = 0;
-                    __syncthreads();
-                    if (lane == 0) L.obuf[0] = carry;
                     flushed += 4 * full;
                     base_bits = allbits & 31;
-                    __syncthreads();
+                    wave_lds_sync();
+                    if (nst != st) {
+                        // stream finished: end mark and the last partial word
+                        if (lane == 0) {
+                            const uint32_t v = carry | (1u << base_bits);
+                            const uint32_t nbytes = (base_bits + 1 + 7) >> 3;
+                            for (uint32_t k = 0; k < nbytes; ++k) sop[flushed + k] = (uint8_t)(v >> (8 * k));
+                        }
+                        base_bits = 0;
+                        flushed = 0;
+                    } else {
+                        if (lane == 0) L.obuf[0] = carry;
+                        wave_lds_sync();
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+                    st = nst;
+                    done = ndone;
                 }
-                // end mark and the last partial word
-                if (lane == 0) {
-                    const uint32_t v = L.obuf[0] | (1u << base_bits);
-                    const uint32_t nbytes = (base_bits + 1 + 7) >> 3;
-                    for (uint32_t k = 0; k < nbytes; ++k) sop[flushed + k] = (uint8_t)(v >> (8 * k));
-                }
-                __syncthreads();
             }
             opos += passBytes;
-            __syncthreads();
+            wave_lds_sync();
             PHASE(5);
         }
     }
