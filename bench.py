@@ -50,6 +50,21 @@ def cpu_baseline(min_seconds=8.0, n_reads=2048):
     }
 
 
+def committed_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest rocprofv3 PMC summary committed under profiles/
+    (tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).
+    bench.py cannot run the profiler on itself; the summary is for the same 8192-read workload."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
+    for path in reversed(files):
+        for r in csv.DictReader(open(path)):
+            if r["kernel"].startswith(kernel):
+                return int(float(r["hbm_MB_per_launch"]) * 1e6), os.path.basename(path)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,11 +179,12 @@ def main():
         svb_bytes = None
         per_sample = {
             # algorithmic bytes per int16 sample handled by ONE launch of that kernel (DESIGN.md "Kernels")
-            "svb_encode": 2.0 + 2.0 * 1.261 / 2.0 * 0 + 1.261,   # read raw, write svb stream
+            "svb_encode": 2.0 + 1.261,                             # read raw, write svb stream
             "svb_decode": 1.261 + 2.0,
             "zstd_encode": 1.261 + 2.0 / ratio,                   # read svb stream, write frame
             "zstd_decode": 2.0 / ratio + 1.261,
         }.get(name, 2.0)
+        traffic, traffic_src = committed_traffic(name + "_kernel")
         avg_ms = tot_ms / max(launches, 1)
         alg_bytes = per_sample * (samples / args.steps)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -204,7 +220,8 @@ def main():
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5),
-                "traffic": None,
+                "traffic": traffic if n == 8192 else None,
+                "traffic_source": traffic_src if n == 8192 else None,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_launch_ms": round(avg_ms, 4),
             },

@@ -431,3 +431,63 @@ def test_zstd_encoder_tables_match_libzstd_construction():
         assert lit[3] == tree, len(data)
         checked += 1
     assert checked >= 8
+
+
+def test_hdf5_filter_32020_calling_convention():
+    """The plugin's H5Z filter function with libhdf5's calling convention (vbz_plugin.cpp:97-229):
+    chunks it writes decode with the oracle's filter, chunks the reference wrote decode with it."""
+    from vbz_compression_amd import _lib
+
+    P = ctypes.CDLL(_lib.PLUGIN_PATH)
+    sz, vp = ctypes.c_size_t, ctypes.c_void_p
+    P.vbz_filter.restype = sz
+    P.vbz_filter.argtypes = [ctypes.c_uint, sz, ctypes.POINTER(ctypes.c_uint), sz, ctypes.POINTER(sz), ctypes.POINTER(vp)]
+    libc = ctypes.CDLL(None)
+    libc.malloc.restype = vp
+    libc.malloc.argtypes = [sz]
+    libc.free.argtypes = [vp]
+
+    def run(fn, flags, cd, data):
+        buf = libc.malloc(max(len(data), 1))
+        ctypes.memmove(buf, data.ctypes.data, len(data))
+        pbuf, size = vp(buf), sz(len(data))
+        cdv = (ctypes.c_uint * len(cd))(*cd)
+        used = fn(flags, len(cd), cdv, len(data), ctypes.byref(size), ctypes.byref(pbuf))
+        out = None
+        if used:
+            out = np.ctypeslib.as_array(ctypes.cast(pbuf, ctypes.POINTER(ctypes.c_uint8)), (used,)).copy()
+        libc.free(pbuf)
+        return used, out
+
+    a = O.synth_signal(5, 4, 123627)
+    raw = np.frombuffer(a.tobytes(), np.uint8)
+    for cd in ([1, 2, 1, 1], [0, 2, 1, 1], [0, 2, 1], [1, 2, 1, 0], [0, 2, 1, 1, 1]):
+        used, chunk = run(P.vbz_filter, 0, cd, raw)
+        assert used > 0 and int(chunk[:4].view("<u4")[0]) == len(raw)
+        u2, back = run(O.lib().vbo_filter, 0x100, cd, chunk)       # the reference's decoder reads it
+        assert u2 == len(raw) and back.tobytes() == raw.tobytes()
+        u3, chunk_ref = run(O.lib().vbo_filter, 0, cd, raw)          # and the plugin reads the reference's chunk
+        u4, back2 = run(P.vbz_filter, 0x100, cd, chunk_ref)
+        assert u4 == len(raw) and back2.tobytes() == raw.tobytes()
+    assert run(P.vbz_filter, 0, [1, 2], raw)[0] == 0                  # cd_nelmts < 3
+    assert run(P.vbz_filter, 0, [1, 2, 1, 1], raw[:-1])[0] == 0        # size not a multiple of integer_size
+    assert run(P.vbz_filter, 0x100, [1, 2, 1, 1], raw[:1000])[0] == 0  # not a vbz chunk
+    # config 3 stand-in: the 10 real reads of the shipped fast5 file through the filter, both directions
+    idx = json.load(open(os.path.join(GOLDEN, "fast5_chunks.json")))
+    blob = np.fromfile(os.path.join(GOLDEN, "fast5_chunks.bin"), np.uint8)
+    total_ref = total_gpu = 0
+    for e in idx:
+        chunk = blob[e["chunk_offset"] : e["chunk_offset"] + e["chunk_size"]]
+        cd = e["filter_v0"][1]
+        u, sig = run(P.vbz_filter, 0x100, cd, chunk)
+        assert u == 2 * e["samples"] and hashlib.sha256(sig.tobytes()).hexdigest() == e["raw_sha256"]
+        u, mine = run(P.vbz_filter, 0, cd[:4], sig)
+        u2, back = run(O.lib().vbo_filter, 0x100, cd[:4], mine)
+        assert back.tobytes() == sig.tobytes()
+        # per-chunk svb payload byte-identical to the reference's (recovered by un-zstd-ing both)
+        svb_mine = O.zstd_decompress(mine[4:], int(O.zstd_content_size(mine[4:])))
+        svb_ref = O.zstd_decompress(chunk[4:], int(O.zstd_content_size(chunk[4:])))
+        assert svb_mine.tobytes() == svb_ref.tobytes()
+        total_ref += len(chunk)
+        total_gpu += len(mine)
+    assert abs(total_gpu / total_ref - 1.0) < 0.03, (total_gpu, total_ref)

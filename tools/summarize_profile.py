@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/, scratch) into the small files kept under profiles/.
+
+  python tools/summarize_profile.py <round tag> <kernel_stats.csv> [<fetch_counter_collection.csv> <write_counter_collection.csv>]
+
+Writes profiles/<tag>_kernel_stats.csv (the rocprofv3 --kernel-trace --stats summary, library kernels
+first) and profiles/<tag>_hbm_traffic.csv (per-kernel average FETCH_SIZE / WRITE_SIZE from separate --pmc
+passes, with the gfx950 correction of MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced
+read, so read bytes = 2 x FETCH_SIZE x 1024; WRITE_SIZE x 1024 is taken as is)."""
+import collections
+import csv
+import os
+import sys
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    n = n.split("(")[0].replace("vbzhip::", "")
+    return n[:90]
+
+
+def main():
+    tag, stats = sys.argv[1], sys.argv[2]
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    os.makedirs(out, exist_ok=True)
+    rows = list(csv.DictReader(open(stats)))
+    rows.sort(key=lambda r: (0 if "vbzhip" in r["Name"] else 1, -float(r["TotalDurationNs"])))
+    with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
+        for r in rows[:16]:
+            w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.4f" % (float(r["AverageNs"]) / 1e6),
+                        r["Percentage"], "%.4f" % (float(r["MinNs"]) / 1e6), "%.4f" % (float(r["MaxNs"]) / 1e6)])
+    if len(sys.argv) >= 5:
+        agg = collections.defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
+        for path in sys.argv[3:5]:
+            for r in csv.DictReader(open(path)):
+                a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+        with open(os.path.join(out, tag + "_hbm_traffic.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "read_MB_corrected(2x)", "write_MB", "hbm_MB_per_launch"])
+            for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"][1] + kv[1]["WRITE_SIZE"][1])):
+                if "svb_" not in k and "zstd_" not in k and "elementwise" not in k:
+                    continue
+                fn, fs = v["FETCH_SIZE"]
+                wn, ws = v["WRITE_SIZE"]
+                fa = fs / max(fn, 1)
+                wa = ws / max(wn, 1)
+                w.writerow([k, max(fn, wn), "%.1f" % fa, "%.1f" % wa, "%.1f" % (2 * fa * 1024 / 1e6), "%.1f" % (wa * 1024 / 1e6),
+                            "%.1f" % ((2 * fa + wa) * 1024 / 1e6)])
+
+
+if __name__ == "__main__":
+    main()
