@@ -15,6 +15,7 @@ SOURCES = ["svb_kernels.hip", "zstd_encode.hip", "zstd_decode.hip", "helpers.hip
 HEADERS = ["vbz_kernels.h", "zstd_entropy.h", "../../include/vbz.h", "../../include/vbz_gpu.h", "../../include/vbz_hdf_plugin.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+FLAGS += os.environ.get("VBZ_HIPCC_EXTRA", "").split()
 
 
 def _stale(target, deps):

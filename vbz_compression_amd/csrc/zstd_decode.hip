@@ -24,17 +24,30 @@ constexpr int WAVE = 64;
 constexpr uint32_t BLOCK_MAX = 128u << 10;
 constexpr int HBUF = 768;
 
+#ifndef VBZ_DEC_RING
+#define VBZ_DEC_RING 32
+#endif
+#define VBZ_DEC_RING_DECL VBZ_DEC_RING
 struct DecLds
 {
     uint16_t huf[2][2048];   // two Huffman decoding tables: symbol | nbBits << 8 (a 12-bit table spans both)
-    uint32_t fse[3][512];    // LL, OF, ML decoding tables: symbol | nbBits << 8 | base << 16
+    // The input rings of the stream decoders share their LDS with everything that is only needed while
+    // headers are parsed or sequences are executed.  Frames that carry sequences (fse tables must survive
+    // from block to block) decode their literal streams with the ring-less path instead.
+    union
+    {
+        uint32_t inbuf[VBZ_DEC_RING_DECL][WAVE];  // per-lane rings of compressed input ([dword][lane])
+        struct
+        {
+            uint32_t fse[3][512];  // LL, OF, ML decoding tables: symbol | nbBits << 8 | base << 16
+            uint8_t hbuf[HBUF];    // staged header bytes of the current block section
+            int16_t norm[256];
+            uint16_t symnext[256];
+        } p;
+    } u;
     uint32_t wfse[64];       // FSE table of the Huffman weights (accuracy log <= 6)
-    uint8_t hbuf[HBUF];      // staged header bytes of the current block section
     uint8_t weights[256];
-    int16_t norm[256];
-    uint16_t symnext[256];
     uint32_t t_src[WAVE], t_size[WAVE], t_out[WAVE], t_cnt[WAVE], t_tab[WAVE];  // pending stream tasks
-    uint32_t inbuf[32][WAVE]; // per-lane rings of compressed input for the stream decoders
     uint32_t ctl[24];
 };
 
@@ -110,7 +123,7 @@ struct BitReader  // backward bit stream (RFC 8878 4.1): bits are consumed from 
 __device__ __forceinline__ int hbit(uint32_t v) { return 31 - __clz((int)v); }
 
 // FSE table description (RFC 8878 4.1.1) read from LDS bytes; lane 0 only.
-// returns bytes consumed or -1; fills L.norm[0..nsym)
+// returns bytes consumed or -1; fills L.u.p.norm[0..nsym)
 __device__ int read_ncount(DecLds& L, const uint8_t* p, int n, int max_symbol, int max_log, int* out_log, int* out_nsym)
 {
     if (n < 1) return -1;
@@ -136,7 +149,7 @@ __device__ int read_ncount(DecLds& L, const uint8_t* p, int n, int max_symbol, i
                 bitpos += 2;
                 for (uint32_t k = 0; k < rr; ++k) {
                     if (sym > max_symbol) return -1;
-                    L.norm[sym++] = 0;
+                    L.u.p.norm[sym++] = 0;
                 }
                 if (rr != 3) break;
             }
@@ -157,7 +170,7 @@ __device__ int read_ncount(DecLds& L, const uint8_t* p, int n, int max_symbol, i
         }
         count--;
         remaining -= count < 0 ? -count : count;
-        L.norm[sym++] = (int16_t)count;
+        L.u.p.norm[sym++] = (int16_t)count;
         prev0 = (count == 0);
         while (remaining < threshold) {
             nbits--;
@@ -173,23 +186,23 @@ __device__ int read_ncount(DecLds& L, const uint8_t* p, int n, int max_symbol, i
     return used;
 }
 
-// FSE decoding table from L.norm (lane 0 only): RFC 8878 4.1.1
+// FSE decoding table from L.u.p.norm (lane 0 only): RFC 8878 4.1.1
 __device__ int fse_build(DecLds& L, uint32_t* tab, int nsym, int log)
 {
     const int size = 1 << log;
     int high = size - 1;
     for (int s = 0; s < nsym; ++s) {
-        if (L.norm[s] == -1) {
+        if (L.u.p.norm[s] == -1) {
             tab[high--] = (uint32_t)s;
-            L.symnext[s] = 1;
+            L.u.p.symnext[s] = 1;
         } else {
-            L.symnext[s] = (uint16_t)L.norm[s];
+            L.u.p.symnext[s] = (uint16_t)L.u.p.norm[s];
         }
     }
     const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     int pos = 0;
     for (int s = 0; s < nsym; ++s) {
-        for (int i = 0; i < L.norm[s]; ++i) {
+        for (int i = 0; i < L.u.p.norm[s]; ++i) {
             tab[pos] = (uint32_t)s;
             do {
                 pos = (pos + step) & mask;
@@ -199,7 +212,7 @@ __device__ int fse_build(DecLds& L, uint32_t* tab, int nsym, int log)
     if (pos != 0) return -1;
     for (int u = 0; u < size; ++u) {
         const uint32_t s = tab[u] & 0xFF;
-        const uint32_t ns = L.symnext[s]++;
+        const uint32_t ns = L.u.p.symnext[s]++;
         const int nb = log - hbit(ns);
         tab[u] = s | ((uint32_t)nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFFu) << 16);
     }
@@ -227,7 +240,7 @@ __device__ int seq_table(DecLds& L, uint32_t* tab, int* log_io, bool* have, int 
                          const int16_t* def, int def_n, int def_log, int max_sym, int max_log)
 {
     if (mode == 0) {
-        for (int i = 0; i < def_n; ++i) L.norm[i] = def[i];
+        for (int i = 0; i < def_n; ++i) L.u.p.norm[i] = def[i];
         if (fse_build(L, tab, def_n, def_log) != 0) return -1;
         *log_io = def_log;
         *have = true;
@@ -394,31 +407,39 @@ __device__ void huf_fill_table(DecLds& L, uint16_t* T, uint32_t nw, uint32_t tlo
 // requested a period ago and requests the next one.  A period consumes at most 11 dwords (32 symbols x
 // 11 bits), so a ring that holds more than 16 dwords can always skip a top-up: no lane ever runs dry,
 // and all ring traffic happens at wave-uniform points (no divergent refill code).
-constexpr int RING = 32;
-constexpr int BATCH = 16;
-constexpr int PERIOD = 32;
+typedef __attribute__((address_space(1))) const uint8_t gcu8;  // global memory, not flat
+typedef __attribute__((address_space(1))) uint8_t gu8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef VBZ_DEC_RING
+#define VBZ_DEC_RING 32
+#endif
+constexpr int RING = VBZ_DEC_RING;      // dwords per lane in the LDS ring (32 or 16)
+constexpr int BATCH = RING / 2;         // dwords fetched per top-up
+constexpr int PERIOD = RING;            // symbols between two top-up points (a period eats <= 11*PERIOD/32 dwords)
 
 // next BATCH dwords below `nextbyte`, in consumption order (w[0] holds the highest bytes)
-__device__ __forceinline__ void fetch_batch(const uint8_t* p, uint32_t& nextbyte, uint32_t (&w)[BATCH])
+__device__ __forceinline__ void fetch_batch(gcu8* p, uint32_t& nextbyte, uint32_t (&w)[BATCH])
 {
-    if (nextbyte >= 64) {
-        const uint8_t* q = p + nextbyte - 64;
-        uint4 a, b, c, d;
-        __builtin_memcpy(&a, q, 16);
-        __builtin_memcpy(&b, q + 16, 16);
-        __builtin_memcpy(&c, q + 32, 16);
-        __builtin_memcpy(&d, q + 48, 16);
-        w[0] = d.w; w[1] = d.z; w[2] = d.y; w[3] = d.x;
-        w[4] = c.w; w[5] = c.z; w[6] = c.y; w[7] = c.x;
-        w[8] = b.w; w[9] = b.z; w[10] = b.y; w[11] = b.x;
-        w[12] = a.w; w[13] = a.z; w[14] = a.y; w[15] = a.x;
-        nextbyte -= 64;
+    typedef __attribute__((address_space(1), aligned(1))) const u32x4 gq4;
+    if (nextbyte >= 4 * BATCH) {
+        gcu8* q = p + nextbyte - 4 * BATCH;
+#pragma unroll
+        for (int v = 0; v < BATCH / 4; ++v) {
+            const u32x4 x = *(gq4*)(q + 16 * (BATCH / 4 - 1 - v));
+            w[4 * v + 0] = x.w;
+            w[4 * v + 1] = x.z;
+            w[4 * v + 2] = x.y;
+            w[4 * v + 3] = x.x;
+        }
+        nextbyte -= 4 * BATCH;
     } else {
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) {
             uint32_t v = 0;
             if (nextbyte >= 4) {
-                __builtin_memcpy(&v, p + nextbyte - 4, 4);
+                typedef __attribute__((address_space(1), aligned(1))) const uint32_t gq1;
+                v = *(gq1*)(p + nextbyte - 4);
                 nextbyte -= 4;
             } else if (nextbyte > 0) {
                 for (uint32_t j = 0; j < nextbyte; ++j) v |= (uint32_t)p[j] << (8 * (j + 4 - nextbyte));
@@ -429,30 +450,74 @@ __device__ __forceinline__ void fetch_batch(const uint8_t* p, uint32_t& nextbyte
     }
 }
 
+// ring-less variant: every lane reads its stream straight from memory, 4 bytes at a time.  Used while
+// FSE tables are live in the LDS the rings would need (frames with sequences, i.e. libzstd's frames).
+__device__ bool flush_tasks_direct(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
+{
+    bool bad = false;
+    if ((uint32_t)lane < ntask) {
+        const uint8_t* p = src + L.t_src[lane];
+        const uint32_t n = L.t_size[lane];
+        uint8_t* o = dst + L.t_out[lane];
+        uint32_t cnt = L.t_cnt[lane];
+        const uint32_t tab = L.t_tab[lane];
+        const int log = (int)(tab >> 16);
+        const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
+        BitReader br;
+        if (!br.init(p, n)) {
+            bad = true;
+        } else {
+            while (cnt >= 4) {
+                uint32_t e0, e1, e2, e3;
+                br.refill();
+                e0 = T[br.peek(log)]; br.skip((int)(e0 >> 8));
+                e1 = T[br.peek(log)]; br.skip((int)(e1 >> 8));
+                br.refill();
+                e2 = T[br.peek(log)]; br.skip((int)(e2 >> 8));
+                e3 = T[br.peek(log)]; br.skip((int)(e3 >> 8));
+                const uint32_t w = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
+                __builtin_memcpy(o, &w, 4);
+                o += 4;
+                cnt -= 4;
+            }
+            while (cnt > 0) {
+                br.refill();
+                const uint32_t e = T[br.peek(log)];
+                br.skip((int)(e >> 8));
+                *o++ = (uint8_t)e;
+                --cnt;
+            }
+            if (!br.finished()) bad = true;
+        }
+    }
+    ntask = 0;
+    __syncthreads();  // makes the decoded bytes visible to the whole wave (vmcnt drain)
+    return __any(bad);
+}
+
 // all lanes: decode the queued Huffman streams, one per lane.  Returns true if any stream is corrupt.
-__device__ bool flush_tasks(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
+__device__ bool flush_tasks_ring(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
 {
     bool bad = false;
     const bool mine = (uint32_t)lane < ntask;
-    const uint8_t* p = src;
+    gcu8* p = (gcu8*)src;
     uint32_t n = 0, cnt = 0, tab = 0;
-    uint8_t* o = dst;
+    gu8* o = (gu8*)dst;
     if (mine) {
-        p = src + L.t_src[lane];
+        p = (gcu8*)src + L.t_src[lane];
         n = L.t_size[lane];
-        o = dst + L.t_out[lane];
+        o = (gu8*)dst + L.t_out[lane];
         cnt = L.t_cnt[lane];
         tab = L.t_tab[lane];
     }
     const int log = (int)(tab >> 16);
     const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
-    uint32_t* ring = &L.inbuf[0][0] + lane;  // ring[k * WAVE]
+    uint32_t* ring = &L.u.inbuf[0][0] + lane;  // ring[k * WAVE]
 
     uint64_t buf = 0;
     int32_t avail = 0, bits_left = 0;
     uint32_t nextbyte = 0, ridx = 0, widx = 0, occ = 0;
     uint32_t pend[BATCH];
-    bool have_pend = false;
     if (mine) {
         const uint32_t last = n ? p[n - 1] : 0;
         if (last == 0) {
@@ -466,37 +531,27 @@ __device__ bool flush_tasks(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_
             nextbyte = n - 1;
         }
     }
-#pragma unroll
-    for (int k = 0; k < BATCH; ++k) pend[k] = 0;
-    // initial fill: two batches into the ring, a third one in flight
+    // initial fill: two batches into the ring, a third one in flight.  Past the start of the stream
+    // fetch_batch yields zeros, so the ring never runs dry (bits_left tells real bits from padding).
     for (int f = 0; f < 2; ++f) {
-        if (nextbyte > 0) fetch_batch(p, nextbyte, pend);
-        else {
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) pend[k] = 0;
-        }
+        fetch_batch(p, nextbyte, pend);
 #pragma unroll
         for (int k = 0; k < BATCH; ++k) ring[((widx + k) & (RING - 1)) * WAVE] = pend[k];
         widx += BATCH;
         occ += BATCH;
     }
-    if (nextbyte > 0) {
-        fetch_batch(p, nextbyte, pend);
-        have_pend = true;
-    }
+    fetch_batch(p, nextbyte, pend);
 
+    // branch-free refill: the ring read is always issued, its result used only if the buffer is low
 #define HUF_REFILL()                                                   \
     do {                                                               \
-        if (avail <= 32) {                                             \
-            uint32_t w__ = 0;                                          \
-            if (occ) {                                                 \
-                w__ = ring[(ridx & (RING - 1)) * WAVE];                \
-                ++ridx;                                                \
-                --occ;                                                 \
-            }                                                          \
-            buf |= (uint64_t)w__ << (32 - avail);                      \
-            avail += 32;                                               \
-        }                                                              \
+        const uint32_t w__ = ring[(ridx & (RING - 1)) * WAVE];         \
+        const bool need__ = avail <= 32;                               \
+        const uint64_t add__ = (uint64_t)w__ << ((32 - avail) & 63);   \
+        buf |= need__ ? add__ : 0ull;                                  \
+        avail += need__ ? 32 : 0;                                      \
+        ridx += need__ ? 1u : 0u;                                      \
+        occ -= need__ ? 1u : 0u;                                       \
     } while (0)
 #define HUF_SYM(dstvar)                                                \
     do {                                                               \
@@ -504,28 +559,25 @@ __device__ bool flush_tasks(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_
         const int nb__ = (int)(e__ >> 8);                              \
         buf <<= nb__;                                                  \
         avail -= nb__;                                                 \
-        bits_left -= nb__;                                             \
         dstvar = e__ & 0xFFu;                                          \
     } while (0)
 
     while (__any(cnt > 0)) {
         // ---- uniform top-up point
-        if (have_pend && occ <= (uint32_t)(RING - BATCH)) {
+        if (occ <= (uint32_t)(RING - BATCH)) {
 #pragma unroll
             for (int k = 0; k < BATCH; ++k) ring[((widx + k) & (RING - 1)) * WAVE] = pend[k];
             widx += BATCH;
             occ += BATCH;
-            have_pend = false;
-        }
-        if (!have_pend && nextbyte > 0) {
             fetch_batch(p, nextbyte, pend);
-            have_pend = true;
         }
         // ---- one period: two groups of 16 symbols, each stored with one 16-byte write
 #pragma unroll
         for (int g = 0; g < PERIOD / 16; ++g) {
             if (cnt >= 16) {
                 uint32_t ow[4];
+                const int32_t before = avail;
+                uint32_t refills = ridx;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     uint32_t s0, s1, s2, s3;
@@ -537,15 +589,21 @@ __device__ bool flush_tasks(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_
                     HUF_SYM(s3);
                     ow[q] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
                 }
-                const uint4 v = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-                __builtin_memcpy(o, &v, 16);
+                refills = ridx - refills;
+                bits_left -= before + 32 * (int32_t)refills - avail;  // bits consumed by the 16 symbols
+                typedef __attribute__((address_space(1), aligned(1))) u32x4 gs4;
+                const u32x4 ov = { ow[0], ow[1], ow[2], ow[3] };
+                *(gs4*)o = ov;
                 o += 16;
                 cnt -= 16;
             } else if (cnt > 0) {
                 while (cnt > 0) {
                     uint32_t s0;
+                    const int32_t before = avail;
+                    const uint32_t r0 = ridx;
                     HUF_REFILL();
                     HUF_SYM(s0);
+                    bits_left -= before + 32 * (int32_t)(ridx - r0) - avail;
                     *o++ = (uint8_t)s0;
                     --cnt;
                 }
@@ -566,7 +624,10 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
     __syncthreads();
 }
 
-__global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg)
+#ifndef VBZ_DEC_WAVES
+#define VBZ_DEC_WAVES 1
+#endif
+__global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg)
 {
     __shared__ DecLds L;
     unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
@@ -593,11 +654,11 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
     } while (0)
 
     // ---- frame header (RFC 8878 3.1.1.1)
-    stage_bytes(L.hbuf, src, n < 32 ? n : 32, lane);
+    stage_bytes(L.u.p.hbuf, src, n < 32 ? n : 32, lane);
     if (lane == 0) {
         uint32_t err = 0, pos = 0;
         uint64_t fcs = 0, window = 0;
-        const uint8_t* h = L.hbuf;
+        const uint8_t* h = L.u.p.hbuf;
         if (n < 6) err = 1;
         if (!err) {
             const uint32_t magic = h[0] | (h[1] << 8) | (h[2] << 16) | ((uint32_t)h[3] << 24);
@@ -641,6 +702,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
 
     uint32_t opos = 0, ntask = 0;
     bool huf_valid = false;
+    bool fse_live = false;  // a block with sequences has been seen: the FSE tables own the shared LDS
     int cur_slot = 0, cur_log = 0;      // current Huffman table: slot and table log
     bool have_ll = false, have_of = false, have_ml = false;
     int log_ll = 0, log_of = 0, log_ml = 0;
@@ -649,8 +711,8 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
     for (;;) {
         if (pos + 3 > n) FAIL();
         // one staged read covers the block header, the literals header and (treeless blocks) the jump table
-        stage_bytes(L.hbuf, src + pos, (n - pos) < 24 ? (n - pos) : 24, lane);
-        const uint32_t bh = L.hbuf[0] | ((uint32_t)L.hbuf[1] << 8) | ((uint32_t)L.hbuf[2] << 16);
+        stage_bytes(L.u.p.hbuf, src + pos, (n - pos) < 24 ? (n - pos) : 24, lane);
+        const uint32_t bh = L.u.p.hbuf[0] | ((uint32_t)L.u.p.hbuf[1] << 8) | ((uint32_t)L.u.p.hbuf[2] << 16);
         pos += 3;
         const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
         if (btype == 3) FAIL();
@@ -672,7 +734,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
             uint32_t ltype, lh = 0, regen = 0, csize = 0, streams = 1, tree_used = 0, nw = 0, tlog = 0;
             uint32_t jt[3] = { 0, 0, 0 };  // jump table when it sits right behind the header (treeless blocks)
             {
-                const uint8_t* h = L.hbuf + 3;
+                const uint8_t* h = L.u.p.hbuf + 3;
                 const uint32_t fmt = (h[0] >> 2) & 3;
                 ltype = h[0] & 3;
                 if (ltype < 2) {
@@ -703,10 +765,10 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
             if (ltype == 2) {
                 // tree description: at most 129 bytes; lane 0 decodes the weights, the wave fills the table
                 const uint32_t tn = csize < 160 ? csize : 160;
-                stage_bytes(L.hbuf, blk + lh, tn, lane);
+                stage_bytes(L.u.p.hbuf, blk + lh, tn, lane);
                 if (lane == 0) {
                     int inw = 0, ilog = 0;
-                    const int used = huf_read_weights(L, L.hbuf, (int)tn, &inw, &ilog);
+                    const int used = huf_read_weights(L, L.u.p.hbuf, (int)tn, &inw, &ilog);
                     L.ctl[C_ERR] = used < 0;
                     L.ctl[C_F] = (uint32_t)used;
                     L.ctl[C_G] = (uint32_t)inw;
@@ -724,7 +786,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                 for (uint32_t t = 0; t < ntask && !clash; ++t)
                     clash = ((L.t_tab[t] & 0xFFFF) == (uint32_t)slot * 2048u);
                 if (clash && ntask) {
-                    if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+                    if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
                 }
                 if (tlog == 12) slot = 0;
                 huf_fill_table(L, &L.huf[0][0] + slot * 2048, nw, tlog, lane);
@@ -741,10 +803,11 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
             if (nseq == 0) {
                 if (sqn != 1) FAIL();
             } else {
-                stage_bytes(L.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
+                fse_live = true;
+                stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
                 if (lane == 0) {
                     uint32_t err = 0, used = 1, ns = nseq;
-                    const uint8_t* h = L.hbuf;
+                    const uint8_t* h = L.u.p.hbuf;
                     const int hn = (int)(sqn < HBUF ? sqn : HBUF);
                     if (ns >= 128) {
                         if (ns == 255) {
@@ -759,15 +822,15 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                         if (modes & 3) err = 1;
                         int u;
                         if (!err) {
-                            u = seq_table(L, L.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
+                            u = seq_table(L, L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err) {
-                            u = seq_table(L, L.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
+                            u = seq_table(L, L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err) {
-                            u = seq_table(L, L.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
+                            u = seq_table(L, L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err && used >= sqn) err = 1;
@@ -792,7 +855,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                 const uint8_t* q = blk + lh + tree_used;
                 uint32_t qn = csize - tree_used;
                 if (ntask + streams > WAVE) {
-                    if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+                    if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
                 }
                 const uint32_t tabref = (uint32_t)cur_slot * 2048u | ((uint32_t)cur_log << 16);
                 if (streams == 1) {
@@ -842,7 +905,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                 opos += regen;
             } else {
                 // everything decoded so far must be in memory before matches can read it
-                if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+                if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
                 const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
                 const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
                 const uint8_t* bs = sq + sq_used;
@@ -866,7 +929,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
                 for (uint32_t i = 0; i < nseq; ++i) {
                     uint32_t llen = 0, mlen = 0, offset = 0;
                     if (lane == 0) {
-                        const uint32_t el = L.fse[0][sl], eo = L.fse[1][so], em = L.fse[2][sm];
+                        const uint32_t el = L.u.p.fse[0][sl], eo = L.u.p.fse[1][so], em = L.u.p.fse[2][sm];
                         const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
                         if (lc > 35 || mc > 52 || oc > 31) err = 1;
                         if (!err) {
@@ -956,7 +1019,7 @@ __global__ __launch_bounds__(WAVE) void zstd_decode_kernel(ReadBatch b, uint32_t
     }
     PHASE(0);
     if (ntask) {
-        if (flush_tasks(L, src, dst, ntask, lane)) FAIL();
+        if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
     }
     PHASE(1);
     if (has_checksum) {

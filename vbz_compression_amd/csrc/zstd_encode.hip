@@ -34,7 +34,11 @@ constexpr uint32_t BLOCK_MAX = 128u << 10;
 constexpr uint32_t MIN_BLOCK = 4096;      // target block size is at least this
 constexpr uint32_t SPLIT_MIN = 2048;      // frames smaller than this are one region
 constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams = 64 lanes)
-constexpr int STEP_LANE = 32;               // symbols packed per lane per step
+#ifndef VBZ_STEP_LANE
+#define VBZ_STEP_LANE 16
+#endif
+constexpr int STEP_LANE = VBZ_STEP_LANE;    // symbols packed per lane per step (16 or 32)
+constexpr int STEP_DW = STEP_LANE / 4;      // dwords per lane chunk
 constexpr int STEP_SYMS = WAVE * STEP_LANE; // symbols packed per wave step
 constexpr int OBUF_WORDS = (STEP_SYMS * 11) / 32 + 8;  // one step packs at most 2048 symbols of 11 bits
 
@@ -333,7 +337,10 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
     wave_lds_sync();
 }
 
-__global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
+#ifndef VBZ_ENC_WAVES
+#define VBZ_ENC_WAVES 4   // measured: 2.2 ms (4 waves/SIMD, 16 symbols/lane) vs 2.85 ms (2 waves, 32 symbols/lane)
+#endif
+__global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg)
 {
     __shared__ EncLds L;
@@ -573,19 +580,22 @@ __global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const ui
                 uint32_t st = 0;
                 while (st < 4 * nb && L.scnt[st] == 0) ++st;
                 uint32_t done = 0;
-                uint32_t cur[8], nxt[8];
-                auto load_chunk = [&](uint32_t sbeg, uint32_t scount, uint32_t dn, uint32_t (&w)[8]) {
+                uint32_t cur[STEP_DW], nxt[STEP_DW];
+                auto load_chunk = [&](uint32_t sbeg, uint32_t scount, uint32_t dn, uint32_t (&w)[STEP_DW]) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) w[k] = 0;
+                    for (int k = 0; k < STEP_DW; ++k) w[k] = 0;
                     const int64_t hi = (int64_t)sbeg + scount - dn - STEP_LANE * (int64_t)lane;
                     const int64_t lo = hi - STEP_LANE;
                     if (hi > (int64_t)sbeg) {
                         if ((int64_t)r0 + lo >= 0) {
-                            uint4 v0, v1;
+                            uint4 v0;
                             __builtin_memcpy(&v0, rin + lo, 16);       // may start before the stream:
-                            __builtin_memcpy(&v1, rin + lo + 16, 16);  // those bytes are masked when used
                             w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
-                            w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+                            if (STEP_DW == 8) {                        // those bytes are masked when used
+                                uint4 v1;
+                                __builtin_memcpy(&v1, rin + lo + 16, 16);
+                                w[4 % STEP_DW] = v1.x; w[5 % STEP_DW] = v1.y; w[6 % STEP_DW] = v1.z; w[7 % STEP_DW] = v1.w;
+                            }
                         } else {  // never read in front of the input buffer
 #pragma unroll
                             for (int k = 0; k < STEP_LANE; ++k) {
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(WAVE) void zstd_encode_kernel(ReadBatch b, const ui
                         wave_lds_sync();
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+                    for (int k = 0; k < STEP_DW; ++k) cur[k] = nxt[k];
                     st = nst;
                     done = ndone;
                 }
