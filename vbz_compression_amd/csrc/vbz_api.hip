@@ -52,6 +52,8 @@ struct vbz_gpu_ctx
     // single-buffer API staging
     DevBuf one_in, one_out, one_meta;
     DevBuf dbg;       // per-read phase timers (VBZ_HIP_PHASE_TIMING=1)
+    DevBuf seqtab;    // encoding tables of the predefined sequence distributions
+    bool zero_run_sequences = true;
     bool phase_timing = false;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -245,7 +247,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
@@ -280,7 +282,9 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     unsigned long long* dbg = dbg_begin(c, n);
     {
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, c->zero_run_sequences ? svb_cap : nullptr,
+                                     c->zero_run_sequences ? c->seqtab.p : nullptr, s),
+               "zstd_encode launch");
     }
     dbg_end(c, n, "zstd_encode: setup hist plan size hdr encode", dbg);
     return 0;
@@ -411,6 +415,17 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     vbz_gpu_ctx* c = new vbz_gpu_ctx();
     c->device = device;
     if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
+    {
+        std::vector<uint8_t> host(seq_tables_bytes());
+        seq_tables_build(host.data());
+        if (!ensure(c, c->seqtab, host.size()) ||
+            hipMemcpy(c->seqtab.p, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error(nullptr, "could not upload the sequence tables");
+            vbz_gpu_destroy(c);
+            return nullptr;
+        }
+    }
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {
@@ -434,7 +449,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab })
         if (b->p) hipFree(b->p);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -513,7 +528,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
     if (!c || !bt) return -1;
     (void)hipSetDevice(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->stream), "zstd_encode launch");
     return 0;
 }
 

@@ -47,8 +47,13 @@ hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, 
 // hdr: 0 or 4 (sized header carrying orig_size[i] in front of the frame).
 // key_bytes (nullable) gives the key-section length per read directly and overrides key_elem.
 // dbg (nullable): 8 x u64 per read, shader-clock cycles spent per phase (debug aid, VBZ_HIP_PHASE_TIMING=1)
+// src_cap + seq_tables (both nullable): the source streams live in library-owned scratch slots of that
+// capacity, which lets the encoder rewrite the control-byte region as literals + zero-run sequences.
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                              uint32_t hdr, unsigned long long* dbg, hipStream_t s);
+                              uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables,
+                              hipStream_t s);
+size_t seq_tables_bytes();
+void seq_tables_build(void* host_buffer);
 // decode: result[i] = frame content size, E_ZSTD for a malformed frame, or `toosmall_code` when the
 // frame's content size exceeds dst_cap[i].
 hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, hipStream_t s);

@@ -120,6 +120,95 @@ struct BitReader  // backward bit stream (RFC 8878 4.1): bits are consumed from 
     __device__ __forceinline__ bool finished() const { return !over && avail == 0 && nextbyte == 0; }
 };
 
+// Same stream, but the bytes arrive in 16-byte chunks requested one chunk ahead, so a serial consumer
+// (lane 0 walking the FSE states of a sequences section) never waits for memory.
+struct BitReaderPF
+{
+    const uint8_t* p;
+    uint32_t nextbyte;
+    uint64_t buf;
+    int32_t avail;
+    bool over;
+    uint32_t c0, c1, c2, c3;  // current chunk, c3 = highest addresses = consumed first
+    int cw;                   // dwords left in the current chunk
+    uint32_t n0, n1, n2, n3;  // the chunk below it, already requested
+    bool nvalid;
+
+    __device__ __forceinline__ void request()
+    {
+        nvalid = nextbyte >= 16;
+        if (nvalid) {
+            uint4 v;
+            __builtin_memcpy(&v, p + nextbyte - 16, 16);
+            n0 = v.x; n1 = v.y; n2 = v.z; n3 = v.w;
+            nextbyte -= 16;
+        }
+    }
+    __device__ __forceinline__ bool init(const uint8_t* ptr, uint32_t n)
+    {
+        over = false;
+        p = ptr;
+        buf = 0;
+        avail = 0;
+        nextbyte = 0;
+        cw = 0;
+        nvalid = false;
+        c0 = c1 = c2 = c3 = n0 = n1 = n2 = n3 = 0;
+        if (n == 0) return false;
+        const uint32_t last = ptr[n - 1];
+        if (last == 0) return false;
+        const int hb = 31 - __clz((int)last);
+        nextbyte = n - 1;
+        buf = hb ? ((uint64_t)(last & ((1u << hb) - 1u)) << (64 - hb)) : 0ull;
+        avail = hb;
+        request();
+        refill();
+        return true;
+    }
+    __device__ __forceinline__ void refill()
+    {
+        if (avail > 32) return;
+        uint32_t w = 0;
+        int got = 32;
+        if (cw == 0 && nvalid) {
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            cw = 4;
+            request();
+        }
+        if (cw > 0) {
+            w = c3;
+            c3 = c2; c2 = c1; c1 = c0;
+            --cw;
+        } else if (nextbyte >= 4) {
+            __builtin_memcpy(&w, p + nextbyte - 4, 4);
+            nextbyte -= 4;
+        } else if (nextbyte > 0) {
+            for (uint32_t k = 0; k < nextbyte; ++k) w |= (uint32_t)p[k] << (8 * (k + 4 - nextbyte));
+            got = 8 * (int)nextbyte;
+            nextbyte = 0;
+        } else {
+            return;
+        }
+        buf |= (uint64_t)w << (32 - avail);
+        avail += got;
+    }
+    __device__ __forceinline__ uint32_t read(int nb)  // nb <= 32
+    {
+        refill();
+        const uint32_t v = nb ? (uint32_t)(buf >> (64 - nb)) : 0u;
+        if (nb > avail) {
+            over = true;
+            buf = 0;
+            avail = 0;
+        } else {
+            buf <<= nb;
+            avail -= nb;
+        }
+        return v;
+    }
+    __device__ __forceinline__ bool finished() const { return !over && avail == 0 && nextbyte == 0 && cw == 0 && !nvalid; }
+};
+
 __device__ __forceinline__ int hbit(uint32_t v) { return 31 - __clz((int)v); }
 
 // FSE table description (RFC 8878 4.1.1) read from LDS bytes; lane 0 only.
@@ -700,9 +789,18 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const uint32_t block_max = L.ctl[C_C];
     const uint32_t has_checksum = L.ctl[C_D];
 
+    const uint32_t first_block = pos;
     uint32_t opos = 0, ntask = 0;
+    for (int attempt = 0;; ++attempt) {
+    // attempt 0 lets the stream decoders' rings reuse the LDS of FSE tables that are (normally) dead; if a later
+    // block turns out to repeat such a table, the frame is decoded again with the tables kept (attempt 1)
+    bool restart = false;
+    pos = first_block;
+    opos = 0;
+    ntask = 0;
     bool huf_valid = false;
-    bool fse_live = false;  // a block with sequences has been seen: the FSE tables own the shared LDS
+    bool fse_live = attempt != 0;  // FSE tables must survive: literal streams use the ring-less path
+    bool tables_built = false, tables_lost = false;
     int cur_slot = 0, cur_log = 0;      // current Huffman table: slot and table log
     bool have_ll = false, have_of = false, have_ml = false;
     int log_ll = 0, log_of = 0, log_ml = 0;
@@ -800,56 +898,14 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             const uint8_t* sq = blk + lit_end;
             const uint32_t sqn = bsize - lit_end;
             uint32_t nseq = sq[0], sq_used = 1;
-            if (nseq == 0) {
-                if (sqn != 1) FAIL();
-            } else {
-                fse_live = true;
-                stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
-                if (lane == 0) {
-                    uint32_t err = 0, used = 1, ns = nseq;
-                    const uint8_t* h = L.u.p.hbuf;
-                    const int hn = (int)(sqn < HBUF ? sqn : HBUF);
-                    if (ns >= 128) {
-                        if (ns == 255) {
-                            if (hn < 3) err = 1; else { ns = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
-                        } else {
-                            if (hn < 2) err = 1; else { ns = ((ns - 128) << 8) + h[1]; used = 2; }
-                        }
-                    }
-                    if (!err && (int)used >= hn) err = 1;
-                    if (!err) {
-                        const uint32_t modes = h[used++];
-                        if (modes & 3) err = 1;
-                        int u;
-                        if (!err) {
-                            u = seq_table(L, L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
-                            if (u < 0) err = 1; else used += (uint32_t)u;
-                        }
-                        if (!err) {
-                            u = seq_table(L, L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
-                            if (u < 0) err = 1; else used += (uint32_t)u;
-                        }
-                        if (!err) {
-                            u = seq_table(L, L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
-                            if (u < 0) err = 1; else used += (uint32_t)u;
-                        }
-                        if (!err && used >= sqn) err = 1;
-                    }
-                    L.ctl[C_ERR] = err;
-                    L.ctl[C_I] = ns;
-                    L.ctl[C_J] = used;
-                }
-                __syncthreads();
-                if (L.ctl[C_ERR]) FAIL();
-                nseq = L.ctl[C_I];
-                sq_used = L.ctl[C_J];
-            }
+            const bool has_seq = nseq != 0;
+            if (!has_seq && sqn != 1) FAIL();
             if ((uint64_t)opos + regen > fcs) FAIL();
             // ---- literals: where do they go?
             //   no sequences : straight to the output (Huffman streams become pending tasks)
             //   sequences    : Huffman literals are staged right-aligned at the end of the frame's
             //                  output, where the growing output can never overtake the unread part
-            const uint32_t lit_dst = nseq == 0 ? opos : fcs - regen;
+            const uint32_t lit_dst = !has_seq ? opos : fcs - regen;
             const uint8_t* lit_src = blk + lh;  // raw literals are read in place
             if (ltype >= 2) {
                 const uint8_t* q = blk + lh + tree_used;
@@ -894,7 +950,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 }
                 __syncthreads();
             }
-            if (nseq == 0) {
+            if (!has_seq) {
                 if (ltype == 0) {
                     for (uint32_t i = lane; i < regen; i += WAVE) dst[opos + i] = lit_src[i];
                 } else if (ltype == 1) {
@@ -906,10 +962,186 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             } else {
                 // everything decoded so far must be in memory before matches can read it
                 if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
+                // (this block's own Huffman literals were queued above, so they were decoded with the ring too)
+                if (!fse_live && tables_built) tables_lost = true;  // the ring shares its LDS with the FSE tables
+                stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
+                if (lane == 0) {
+                    uint32_t err = 0, used = 1, ns = nseq;
+                    const bool lost = tables_lost;
+                    const uint8_t* h = L.u.p.hbuf;
+                    const int hn = (int)(sqn < HBUF ? sqn : HBUF);
+                    if (ns >= 128) {
+                        if (ns == 255) {
+                            if (hn < 3) err = 1; else { ns = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
+                        } else {
+                            if (hn < 2) err = 1; else { ns = ((ns - 128) << 8) + h[1]; used = 2; }
+                        }
+                    }
+                    if (!err && (int)used >= hn) err = 1;
+                    if (!err) {
+                        const uint32_t modes = h[used++];
+                        if (modes & 3) err = 1;
+                        // a repeated table that a ring flush has overwritten: decode the frame again, carefully
+                        if (!err && lost && (((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3)) err = 3;
+                        int u;
+                        if (!err) {
+                            u = seq_table(L, L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err) {
+                            u = seq_table(L, L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err) {
+                            u = seq_table(L, L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err && used >= sqn) err = 1;
+                    }
+                    L.ctl[C_ERR] = err;
+                    L.ctl[C_I] = ns;
+                    L.ctl[C_J] = used;
+                }
+                __syncthreads();
+                if (L.ctl[C_ERR] == 3) {
+                    restart = true;
+                    break;
+                }
+                if (L.ctl[C_ERR]) FAIL();
+                nseq = L.ctl[C_I];
+                sq_used = L.ctl[C_J];
+                tables_built = true;
                 const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
                 const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
                 const uint8_t* bs = sq + sq_used;
                 const uint32_t bsn = sqn - sq_used;
+                // ---- fast path: every match is "offset 1" (OF table = RLE of code 0 while repeat offset 1 is
+                // 1, every literal length > 0): the frames of zstd_encode.hip code zero runs this way.  Lane 0
+                // only walks the FSE states and leaves (literal length, match length) pairs in the unused tail
+                // of the destination slot; the wave then places all literals and run fills in parallel.
+                bool did_fast = false;
+                {
+                    const uint32_t ws_off = (fcs + 7u) & ~7u;
+                    uint32_t go = 0;
+                    if (lane == 0)
+                        go = (log_of == 0 && (L.u.p.fse[1][0] & 0xFF) == 0 && rep0 == 1 &&
+                              (uint64_t)ws_off + 8ull * nseq + 8 <= cap) ? 1u : 0u;
+                    go = (uint32_t)__shfl((int)go, 0, 64);
+                    if (go) {
+                        uint2* ws = reinterpret_cast<uint2*>(dst + ws_off);
+                        // length tables next to the FSE tables: base | extra bits << 24
+                        uint32_t* lt = reinterpret_cast<uint32_t*>(L.u.p.norm);
+                        if (lane < 36) lt[lane] = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
+                        if (lane < 53) lt[36 + lane] = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
+                        __syncthreads();
+                        uint32_t ok = 1;
+                        if (lane == 0) {
+                            BitReaderPF pr;
+                            if (!pr.init(bs, bsn)) ok = 0;
+                            uint32_t sl = 0, sm = 0;
+                            uint64_t sum_ll = 0, sum_all = 0;
+                            if (ok) {
+                                sl = pr.read(log_ll);
+                                sm = pr.read(log_ml);  // the offset state has no bits
+                                if (pr.over) ok = 0;
+                            }
+                            for (uint32_t i = 0; ok && i < nseq; ++i) {
+                                const uint32_t el = L.u.p.fse[0][sl], em = L.u.p.fse[2][sm];
+                                const uint32_t lc = el & 0xFF, mc = em & 0xFF;
+                                if (lc > 35 || mc > 52) { ok = 0; break; }
+                                const uint32_t mt = lt[36 + mc], ltv = lt[lc];
+                                const uint32_t mlen = (mt & 0xFFFFFF) + pr.read((int)(mt >> 24));
+                                const uint32_t llen = (ltv & 0xFFFFFF) + pr.read((int)(ltv >> 24));
+                                if (llen == 0) { ok = 2; break; }  // repeat-offset semantics change: general path
+                                ws[i] = make_uint2(llen, mlen);
+                                sum_ll += llen;
+                                sum_all += (uint64_t)llen + mlen;
+                                if (i + 1 < nseq) {
+                                    sl = (el >> 16) + pr.read((int)((el >> 8) & 0xFF));
+                                    sm = (em >> 16) + pr.read((int)((em >> 8) & 0xFF));
+                                }
+                                if (pr.over) ok = 0;
+                            }
+                            if (ok == 1 && !pr.finished()) ok = 0;
+                            // the parallel placement must not write where staged Huffman literals still wait
+                            if (ok == 1 && sum_ll > regen) ok = 0;
+                            if (ok == 1 && ltype >= 2 && (uint64_t)opos + sum_all + (regen - sum_ll) > lit_dst) ok = 2;
+                        }
+                        ok = (uint32_t)__shfl((int)ok, 0, 64);
+                        if (ok == 0) FAIL();
+                        if (ok == 1) {
+                            __syncthreads();  // the pairs were written by lane 0 (vmcnt drain)
+                            const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
+                            const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
+                            uint32_t lposw = 0, oposw = opos;
+                            for (uint32_t base = 0; base < nseq; base += WAVE) {
+                                const uint32_t i = base + (uint32_t)lane;
+                                uint32_t ll = 0, ml = 0;
+                                if (i < nseq) {
+                                    const uint2 v = ws[i];
+                                    ll = v.x;
+                                    ml = v.y;
+                                }
+                                const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(ll + ml);
+                                const uint32_t tl = (uint32_t)__shfl((int)il, 63, 64), tt = (uint32_t)__shfl((int)it, 63, 64);
+                                if ((uint64_t)lposw + tl > regen || (uint64_t)oposw + tt > fcs) FAIL();
+                                const uint32_t my_lit = lposw + il - ll;
+                                uint32_t my_out = oposw + it - (ll + ml);
+                                uint8_t lastb = rle_byte;
+                                for (uint32_t k = 0; k < ll; ++k) {
+                                    if (ltype != 1) lastb = litp[my_lit + k];
+                                    dst[my_out + k] = lastb;
+                                }
+                                my_out += ll;
+                                // short fills by the owning lane, long ones by the whole wave
+                                if (ml < 64)
+                                    for (uint32_t k = 0; k < ml; ++k) dst[my_out + k] = lastb;
+                                uint64_t big = __ballot(ml >= 64);
+                                while (big) {
+                                    const int sl_ = __ffsll((long long)big) - 1;
+                                    big &= big - 1;
+                                    const uint32_t bo = (uint32_t)__shfl((int)my_out, sl_, 64);
+                                    const uint32_t bl = (uint32_t)__shfl((int)ml, sl_, 64);
+                                    const uint32_t bv = (uint32_t)__shfl((int)lastb, sl_, 64);
+                                    for (uint32_t k = lane; k < bl; k += WAVE) dst[bo + k] = (uint8_t)bv;
+                                }
+                                lposw += tl;
+                                oposw += tt;
+                            }
+                            if (oposw - opos > BLOCK_MAX) FAIL();
+                            // remaining literals
+                            const uint32_t rest = regen - lposw;
+                            if ((uint64_t)oposw + rest > fcs) FAIL();
+                            __syncthreads();
+                            if (ltype == 1) {
+                                for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
+                            } else {
+                                const uint8_t* from = litp + lposw;
+                                uint8_t* to = dst + oposw;
+                                if (from != to) {
+                                    for (uint32_t k0 = 0; k0 < rest; k0 += WAVE) {
+                                        const uint32_t k = k0 + lane;
+                                        uint8_t v = 0;
+                                        if (k < rest) v = from[k];
+                                        __syncthreads();
+                                        if (k < rest) to[k] = v;
+                                    }
+                                }
+                            }
+                            oposw += rest;
+                            if (oposw - opos > BLOCK_MAX || oposw - opos > block_max) FAIL();
+                            opos = oposw;
+                            __syncthreads();
+                            did_fast = true;
+                        }
+                    }
+                }
+                if (did_fast) {
+                    pos += bsize;
+                    if (last) break;
+                    continue;
+                }
+                fse_live = true;  // libzstd-style frame: keep the FSE tables, later literal streams use the direct path
                 BitReader br;
                 uint32_t sl = 0, so = 0, sm = 0;
                 uint32_t err = 0;
@@ -1017,11 +1249,14 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         }
         if (last) break;
     }
+    if (restart) continue;
     PHASE(0);
     if (ntask) {
         if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
     }
     PHASE(1);
+    break;
+    }
     if (has_checksum) {
         if (pos + 4 > n) FAIL();
         pos += 4;  // xxh64 of the content: not verified

@@ -64,6 +64,8 @@ struct EncLds
     uint32_t obuf[OBUF_WORDS]; // bit buffer of the stream being packed
     uint32_t bopos[MAXBLK]; // output offset of each block of the current pass
     uint32_t passBytes;
+    uint32_t seqOff, seqBytes;  // zero-run sequences block: where its sequences section starts / its size
+    SeqCTables seq;             // encoding tables of the predefined LL / ML distributions
 };
 
 __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
@@ -337,11 +339,227 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
     wave_lds_sync();
 }
 
+// ---- zero-run sequences for the control-byte region -------------------------------------------------------
+// Control bytes are mostly 0x00; a Huffman code cannot spend less than one bit on each of them, libzstd's
+// LZ stage does.  The device equivalent keeps everything data-parallel: every run of >= RMIN zero bytes
+// becomes one zstd sequence "copy run-1 bytes from offset 1" (offset 1 = repeat offset 1 of a fresh frame,
+// so the offset costs no bits: OF table in RLE mode, code 0), its first zero stays a literal, and the
+// literals (everything outside the run tails) are Huffman coded as before.  Which bytes are run tails is a
+// morphological open of the zero mask, computed with shifts on a 64-bit window per lane; positions come from
+// wave prefix sums.  Only the FSE state chain of the sequences is serial (lane 0, ~RMIN+ bytes per step).
+constexpr uint32_t RMIN = 8;        // shortest zero run that becomes a match (break-even is ~13 bits); >= 8, <= 24
+static_assert(RMIN >= 8 && RMIN <= 24, "the tokeniser handles at most two run ends per 16 positions and a 64-bit window");
+constexpr uint32_t TOK_PAYLOAD = 60 * 16;
+
+__device__ __forceinline__ uint64_t erode_right(uint64_t w, uint32_t r)  // bit j = AND of bits j .. j+r-1
+{
+    uint32_t span = 1;
+    while (span * 2 <= r) { w &= w >> span; span *= 2; }
+    if (span < r) w &= w >> (r - span);
+    return w;
+}
+
+__device__ __forceinline__ uint64_t dilate_left(uint64_t w, uint32_t r)  // bit j = OR of bits j-r+1 .. j
+{
+    uint32_t span = 1;
+    while (span * 2 <= r) { w |= w << span; span *= 2; }
+    if (span < r) w |= w << (r - span);
+    return w;
+}
+
+// all lanes.  Compacts the literals of k[0..K) in place (k[0..Lit)) and writes one record per qualifying
+// run, in order: rec[j] = (end position of the run, literals before that position).
+__device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit, uint32_t& nrec, int lane)
+{
+    uint32_t lit_total = 0, rec_total = 0;
+    uint32_t carry60 = 0, carry61 = 0;  // zero masks of the 32 positions in front of the payload
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint32_t pb = 0; pb < K; pb += TOK_PAYLOAD) {
+        const int64_t lo = (int64_t)pb + 16 * ((int64_t)lane - 2);
+        uint32_t w[4] = { 0, 0, 0, 0 };
+        uint32_t zm = 0, valid = 0;
+        if (lane >= 2 && lo < (int64_t)K) {
+            uint4 v;
+            __builtin_memcpy(&v, k + lo, 16);  // the slot has 16+ bytes of slack behind the stream
+            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            const uint32_t nvalid = (K - (uint32_t)lo) >= 16 ? 16u : (K - (uint32_t)lo);
+            valid = nvalid >= 16 ? 0xFFFFu : ((1u << nvalid) - 1u);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) zm |= (((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == 0 ? 1u : 0u) << i;
+            zm &= valid;
+        }
+        if (lane == 0) zm = carry60;
+        if (lane == 1) zm = carry61;
+        uint32_t m1 = (uint32_t)__shfl_up((int)zm, 1, 64), m2 = (uint32_t)__shfl_up((int)zm, 2, 64);
+        uint32_t p1 = (uint32_t)__shfl_down((int)zm, 1, 64), p2 = (uint32_t)__shfl_down((int)zm, 2, 64);
+        if (lane < 1) m1 = 0;
+        if (lane < 2) m2 = 0;
+        if (lane > 62) p1 = 0;
+        if (lane > 61) p2 = 0;
+        // window bit j <-> position lo - 24 + j
+        const uint64_t W = (uint64_t)((m2 >> 8) & 0xFF) | ((uint64_t)m1 << 8) | ((uint64_t)zm << 24) | ((uint64_t)p1 << 40) |
+                           ((uint64_t)(p2 & 0xFF) << 56);
+        const uint64_t Q = dilate_left(erode_right(W, RMIN), RMIN);  // positions inside runs of >= RMIN zeros
+        const uint64_t RM = Q & (W << 1);                            // ... except the first one of each run
+        const uint64_t END = RM & ~(W >> 1);                         // last position of such a run
+        const bool payload = lane >= 2 && lane < 62;
+        const uint32_t r16 = payload ? (uint32_t)(RM >> 24) & 0xFFFFu : 0u;
+        const uint32_t end16 = payload ? (uint32_t)(END >> 24) & 0xFFFFu & valid : 0u;
+        const uint32_t kept16 = payload ? (~r16 & valid) : 0u;
+        const uint32_t c = (uint32_t)__popc(kept16);
+        const uint32_t incl = wave_incl_scan_u32(c);
+        const uint32_t excl = incl - c;
+        const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+        // with RMIN <= 8 two qualifying runs can end inside one lane's 16 positions (never three)
+        const uint32_t second = end16 & (end16 - 1);
+        const uint64_t endmask1 = __ballot(end16 != 0), endmask2 = __ballot(second != 0);
+        if (end16) {
+            const uint32_t idx = rec_total + (uint32_t)__popcll(endmask1 & below) + (uint32_t)__popcll(endmask2 & below);
+            const uint32_t i = (uint32_t)__ffs((int)end16) - 1u;
+            rec[idx] = make_uint2((uint32_t)lo + i + 1u, lit_total + excl + (uint32_t)__popc(kept16 & ((2u << i) - 1u)));
+            if (second) {
+                const uint32_t i2 = (uint32_t)__ffs((int)second) - 1u;
+                rec[idx + 1] = make_uint2((uint32_t)lo + i2 + 1u, lit_total + excl + (uint32_t)__popc(kept16 & ((2u << i2) - 1u)));
+            }
+        }
+        uint32_t off = lit_total + excl;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((kept16 >> i) & 1u) k[off++] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        rec_total += (uint32_t)__popcll(endmask1) + (uint32_t)__popcll(endmask2);
+        lit_total += tot;
+        carry60 = (uint32_t)__shfl((int)zm, 60, 64);
+        carry61 = (uint32_t)__shfl((int)zm, 61, 64);
+    }
+    Lit = lit_total;
+    nrec = rec_total;
+}
+
+// all lanes.  Sequences section (RFC 8878 3.1.1.3.2) for the records of tokenise_zero_runs: LL and ML with the
+// predefined distributions, OF in RLE mode with code 0 (repeat offset 1); same bit order as libzstd's
+// ZSTD_encodeSequences (last sequence first).  Per chunk of 64 sequences: every lane turns one record into
+// codes and extra bits; lanes 0 and 1 walk the two independent FSE state chains (match length / literal
+// length) and leave each step's output bits in LDS; every lane then assembles the <= 44 bits of its sequence,
+// a wave prefix sum places them, and the chunk is written out as dwords.  Returns the bytes written.
+__device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uint2* rec, uint32_t nseq, int lane)
+{
+    uint32_t hdr = 0;
+    if (lane == 0) {
+        uint8_t* op = dst;
+        if (nseq < 128) { *op++ = (uint8_t)nseq; }
+        else if (nseq < 0x7F00) { *op++ = (uint8_t)((nseq >> 8) + 128); *op++ = (uint8_t)nseq; }
+        else { *op++ = 255; *op++ = (uint8_t)(nseq - 0x7F00); *op++ = (uint8_t)((nseq - 0x7F00) >> 8); }
+        *op++ = 0x10;  // LL predefined | OF RLE | ML predefined
+        *op++ = 0;     // OF code 0
+        hdr = (uint32_t)(op - dst);
+    }
+    hdr = (uint32_t)__shfl((int)hdr, 0, 64);
+    uint8_t* out = dst + hdr;
+    // LDS scratch inside the (idle) bit buffer of the stream packer: [0..127] bit words, then codes / pieces
+    uint32_t* bits = L.obuf;                 // 128 words: 64 sequences x 44 bits + carry
+    uint32_t* codes = L.obuf + 128;          // [64] : ml code | ll code << 8
+    uint32_t* pieces = L.obuf + 192;         // [2][64] : value | nbits << 16 of the ML / LL state step
+    for (int i = lane; i < 128; i += WAVE) bits[i] = 0;
+    uint32_t st = 0;                         // lane 0: match-length state, lane 1: literal-length state
+    const uint16_t* stab = lane == 0 ? L.seq.ml_state : L.seq.ll_state;
+    const uint32_t* dnb = lane == 0 ? L.seq.ml_dnb : L.seq.ll_dnb;
+    const int32_t* dfs = lane == 0 ? L.seq.ml_dfs : L.seq.ll_dfs;
+    uint32_t base_bits = 0, flushed = 0;
+    for (uint32_t t0 = 0; t0 < nseq; t0 += WAVE) {
+        const uint32_t cnt = (nseq - t0) < (uint32_t)WAVE ? (nseq - t0) : (uint32_t)WAVE;
+        const uint32_t t = t0 + (uint32_t)lane;
+        uint32_t lex = 0, lnb = 0, mex = 0, mnb = 0;
+        if (t < nseq) {
+            const uint32_t n = nseq - 1 - t;
+            const uint2 cur = rec[n];
+            const uint2 prev = n ? rec[n - 1] : make_uint2(0u, 0u);
+            const uint32_t ll = cur.y - prev.y;
+            const uint32_t ml = (cur.x - prev.x) - ll;
+            uint32_t lc, mc;
+            seq_ll_code(ll, &lc, &lex, &lnb);
+            seq_ml_code(ml, &mc, &mex, &mnb);
+            codes[lane] = mc | (lc << 8);
+        }
+        wave_lds_sync();
+        if (lane < 2) {
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint32_t c = (codes[j] >> (8 * lane)) & 0xFF;
+                uint32_t piece = 0;
+                if (t0 + j == 0) {  // FSE_initCState2: the first symbol only selects the state
+                    const uint32_t nbo = (dnb[c] + (1u << 15)) >> 16;
+                    st = stab[(int32_t)(((nbo << 16) - dnb[c]) >> nbo) + dfs[c]];
+                } else {            // FSE_encodeSymbol
+                    const uint32_t nbo = (st + dnb[c]) >> 16;
+                    piece = (st & ((1u << nbo) - 1u)) | (nbo << 16);
+                    st = stab[(int32_t)(st >> nbo) + dfs[c]];
+                }
+                pieces[lane * WAVE + j] = piece;
+            }
+        }
+        wave_lds_sync();
+        uint64_t v = 0;
+        uint32_t len = 0;
+        if (t < nseq) {
+            const uint32_t pm = pieces[lane], pl = pieces[WAVE + lane];
+            v = (uint64_t)(pm & 0xFFFF);
+            len = pm >> 16;
+            v |= (uint64_t)(pl & 0xFFFF) << len;
+            len += pl >> 16;
+            v |= (uint64_t)lex << len;
+            len += lnb;
+            v |= (uint64_t)mex << len;
+            len += mnb;
+        }
+        const uint32_t incl = wave_incl_scan_u32(len);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint32_t pos = base_bits + incl - len;
+        if (len) {
+            const uint32_t w = pos >> 5, sh = pos & 31;
+            const uint64_t lo = v << sh;                 // len <= 44, sh <= 31: may spill into a third word
+            atomicOr(&bits[w], (uint32_t)lo);
+            if (sh + len > 32) atomicOr(&bits[w + 1], (uint32_t)(lo >> 32));
+            if (sh + len > 64) atomicOr(&bits[w + 2], (uint32_t)(v >> (64 - sh)));
+        }
+        wave_lds_sync();
+        const uint32_t allbits = base_bits + total;
+        const uint32_t full = allbits >> 5;
+        for (uint32_t i = lane; i < full; i += WAVE) {
+            const uint32_t wv = bits[i];
+            __builtin_memcpy(out + flushed + 4 * i, &wv, 4);
+        }
+        const uint32_t carry = bits[full];
+        wave_lds_sync();
+        for (uint32_t i = lane; i <= full; i += WAVE) bits[i] = 0;
+        wave_lds_sync();
+        if (lane == 0) bits[0] = carry;
+        flushed += 4 * full;
+        base_bits = allbits & 31;
+        wave_lds_sync();
+    }
+    // final states (match length, then literal length) and the end mark
+    const uint32_t stLL = (uint32_t)__shfl((int)st, 1, 64);
+    uint32_t nbytes = 0;
+    if (lane == 0) {
+        uint64_t acc = bits[0];
+        uint32_t nbit = base_bits;
+        acc |= (uint64_t)(st & 63u) << nbit; nbit += SEQ_DEF_LOG;
+        acc |= (uint64_t)(stLL & 63u) << nbit; nbit += SEQ_DEF_LOG;
+        acc |= 1ull << nbit; nbit += 1;
+        nbytes = (nbit + 7) >> 3;
+        for (uint32_t i = 0; i < nbytes; ++i) out[flushed + i] = (uint8_t)(acc >> (8 * i));
+        bits[0] = 0;
+    }
+    nbytes = (uint32_t)__shfl((int)nbytes, 0, 64);
+    wave_lds_sync();
+    return hdr + flushed + nbytes;
+}
+
 #ifndef VBZ_ENC_WAVES
 #define VBZ_ENC_WAVES 4   // measured: 2.2 ms (4 waves/SIMD, 16 symbols/lane) vs 2.85 ms (2 waves, 32 symbols/lane)
 #endif
 __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
-                                                           const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg)
+                                                           const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
+                                                           const uint32_t* src_cap, const SeqCTables* seqtab)
 {
     __shared__ EncLds L;
     unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
@@ -374,6 +592,11 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             return;                                              \
         }                                                        \
     } while (0)
+    if (seqtab) {  // 968 bytes of encoding tables, copied once per frame
+        const uint32_t* g = reinterpret_cast<const uint32_t*>(seqtab);
+        uint32_t* l = reinterpret_cast<uint32_t*>(&L.seq);
+        for (uint32_t i = lane; i < sizeof(SeqCTables) / 4; i += WAVE) l[i] = g[i];
+    }
     uint32_t opos = 0;
     NEED(hdr + 9 + (N == 0 ? 3 : 0));
     if (lane == 0) {
@@ -396,10 +619,31 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         const uint32_t r0 = region == 0 ? 0 : K;
         const uint32_t r1 = region == 0 ? (K ? K : N) : N;
         if (region == 1 && K == 0) break;
-        const uint32_t S = r1 - r0;
+        uint32_t S = r1 - r0;
         const bool lastRegion = (r1 == N);
         const uint8_t* rin = in + r0;
         uint32_t nblk = (S + T - 1) / T;
+        // control-byte region of a library-owned svb stream: turn long zero runs into sequences.  The
+        // literals are compacted in place, the run records go to the unused tail of the scratch slot.
+        bool seqmode = false;
+        uint32_t nrec = 0;
+        const uint2* rec = nullptr;
+        if (region == 0 && K != 0 && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
+            const uint32_t slot = src_cap[r];
+            const uint64_t need = (uint64_t)N + 16 + 8ull * (S / RMIN + 2);
+            if (need <= slot) {
+                uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * (S / RMIN + 2)) & ~7u);
+                uint32_t Lit = 0;
+                tokenise_zero_runs(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, lane);
+                __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
+                if (nrec) {
+                    seqmode = true;
+                    rec = reinterpret_cast<const uint2*>(ws);
+                    S = Lit;      // from here on the region is its literal stream: one block
+                    nblk = 1;
+                }
+            }
+        }
         PHASE(0);
         region_histogram(L, rin, S, lane);
         PHASE(1);
@@ -407,6 +651,22 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         wave_lds_sync();
         PHASE(2);
         const uint32_t mode = L.mode;
+        if (seqmode && mode != 2) {
+            // literals do not pay for a Huffman table: Raw_Literals_Block + sequences in one compressed block
+            const uint32_t lh = S < 32 ? 1u : (S < 4096 ? 2u : 3u);
+            NEED(3ull + lh + S + 8 + 8ull * nrec);
+            uint8_t* bp = out + opos;
+            if (lane == 0) {
+                if (lh == 1) bp[3] = (uint8_t)(S << 3);
+                else if (lh == 2) put_le(bp + 3, (S << 4) | 4u, 2);
+                else put_le(bp + 3, (S << 4) | 12u, 3);
+            }
+            for (uint32_t i = lane; i < S; i += WAVE) bp[3 + lh + i] = rin[i];
+            const uint32_t sb = encode_zero_run_sequences(L, bp + 3 + lh + S, rec, nrec, lane);
+            if (lane == 0) put_le(bp, ((lh + S + sb) << 3) | (2u << 1) | (lastRegion ? 1u : 0u), 3);
+            opos += 3 + lh + S + sb;
+            continue;
+        }
         if (mode == 1) {
             // RLE blocks (Block_Type 1): Block_Size = run length, one byte of content
             const uint32_t nb = (S + BLOCK_MAX - 1) / BLOCK_MAX;
@@ -520,6 +780,18 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             const uint32_t sbytes = (active && cnt) ? (L.sbits[lane] >> 3) + 1 : 0;
             L.ssize[lane] = sbytes;
             wave_lds_sync();
+            // --- the zero-run block carries a sequences section behind its literals: encode it first
+            uint32_t seqBytes = 1;  // a plain block ends with Number_of_Sequences = 0
+            if (seqmode) {
+                if (lane == 0) {
+                    const uint32_t lit = treeSize + (S < 256 ? 0 : 6) + L.ssize[0] + L.ssize[1] + L.ssize[2] + L.ssize[3];
+                    const uint32_t big = S > lit ? S : lit;
+                    L.seqOff = opos + 3 + (3 + (big >= 1024) + (big >= 16384)) + lit;
+                }
+                wave_lds_sync();
+                NEED((uint64_t)(L.seqOff - opos) + 8 + 8ull * nrec);
+                seqBytes = encode_zero_run_sequences(L, out + L.seqOff, rec, nrec, lane);
+            }
             // --- block layout (lane 0), then headers (first lane of each block)
             if (lane == 0) {
                 uint32_t o = opos;
@@ -531,7 +803,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                                          L.ssize[4 * j + 2] + L.ssize[4 * j + 3];
                     const uint32_t big = jbs > lit ? jbs : lit;
                     const uint32_t lh = 3 + (big >= 1024) + (big >= 16384);
-                    o += 3 + lh + lit + 1;
+                    o += 3 + lh + lit + seqBytes;
                 }
                 L.passBytes = o - opos;
             }
@@ -548,7 +820,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 uint8_t* bp = out + L.bopos[j];
                 if (q == 0) {
                     const uint32_t last = (lastRegion && bj + 1 == nblk) ? 1u : 0u;
-                    put_le(bp, ((lh + lit + 1) << 3) | (2u << 1) | last, 3);
+                    put_le(bp, ((lh + lit + seqBytes) << 3) | (2u << 1) | last, 3);
                     const uint64_t type = bj == 0 ? 2 : 3;  // Compressed_Literals_Block / Treeless
                     if (lh == 3) put_le(bp + 3, type | ((single ? 0ull : 1ull) << 2) | ((uint64_t)bs << 4) | ((uint64_t)lit << 14), 3);
                     else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)bs << 4) | ((uint64_t)lit << 18), 4);
@@ -560,7 +832,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         put_le(tp + tsz + 2, s1, 2);
                         put_le(tp + tsz + 4, s2, 2);
                     }
-                    bp[3 + lh + lit] = 0;  // Number_of_Sequences = 0
+                    if (!seqmode) bp[3 + lh + lit] = 0;  // Number_of_Sequences = 0
                 }
                 // where this lane's stream starts in the output (offset from `out`)
                 L.sout[lane] = L.bopos[j] + 3 + lh + tsz + (single ? 0 : 6) + (q > 0 ? s0 : 0) + (q > 1 ? s1 : 0) + (q > 2 ? s2 : 0);
@@ -702,11 +974,17 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 }  // namespace
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                              uint32_t hdr, unsigned long long* dbg, hipStream_t s)
+                              uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables,
+                              hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(zstd_encode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg);
+    hipLaunchKernelGGL(zstd_encode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg, src_cap,
+                       reinterpret_cast<const SeqCTables*>(seq_tables));
     return hipGetLastError();
 }
+
+// host: the encoding tables of the predefined sequence distributions (uploaded once per context)
+size_t seq_tables_bytes() { return sizeof(SeqCTables); }
+void seq_tables_build(void* host_buffer) { seq_build_default_ctables(reinterpret_cast<SeqCTables*>(host_buffer)); }
 
 }  // namespace vbzhip

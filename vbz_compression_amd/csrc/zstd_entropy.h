@@ -412,6 +412,124 @@ VBZ_HDN int fse_write_ncount(uint8_t* out, int cap, const int16_t* norm, uint32_
     return (int)(out - ostart);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Generic FSE encoding table (zstd FSE_buildCTable_wksp) for a normalized distribution.
+//   stateTable[1 << tableLog], deltaNbBits/deltaFindState[maxSymbolValue + 1]
+//   scratch: tableSymbol[1 << tableLog], cumul[maxSymbolValue + 2]
+// ------------------------------------------------------------------------------------------------
+VBZ_HDN void fse_build_ctable(const int16_t* norm, uint32_t maxSymbolValue, uint32_t tableLog, uint16_t* stateTable,
+                              uint32_t* deltaNbBits, int32_t* deltaFindState, uint8_t* tableSymbol, uint32_t* cumul)
+{
+    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1;
+    const uint32_t step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    uint32_t highThreshold = tableSize - 1;
+    cumul[0] = 0;
+    for (uint32_t u = 1; u <= maxSymbolValue + 1; u++) {
+        if (norm[u - 1] == -1) {
+            cumul[u] = cumul[u - 1] + 1;
+            tableSymbol[highThreshold--] = (uint8_t)(u - 1);
+        } else {
+            cumul[u] = cumul[u - 1] + (uint32_t)norm[u - 1];
+        }
+    }
+    cumul[maxSymbolValue + 1] = tableSize + 1;
+    {
+        uint32_t position = 0;
+        for (uint32_t symbol = 0; symbol <= maxSymbolValue; symbol++) {
+            const int freq = norm[symbol];
+            for (int occ = 0; occ < freq; occ++) {
+                tableSymbol[position] = (uint8_t)symbol;
+                position = (position + step) & tableMask;
+                while (position > highThreshold) position = (position + step) & tableMask;
+            }
+        }
+    }
+    for (uint32_t u = 0; u < tableSize; u++) {
+        const uint8_t s = tableSymbol[u];
+        stateTable[cumul[s]++] = (uint16_t)(tableSize + u);
+    }
+    uint32_t total = 0;
+    for (uint32_t s = 0; s <= maxSymbolValue; s++) {
+        const int nc = norm[s];
+        if (nc == 0) {
+            deltaNbBits[s] = ((tableLog + 1) << 16) - (1u << tableLog);
+            deltaFindState[s] = 0;
+        } else if (nc == -1 || nc == 1) {
+            deltaNbBits[s] = (tableLog << 16) - (1u << tableLog);
+            deltaFindState[s] = (int32_t)total - 1;
+            total++;
+        } else {
+            const uint32_t maxBitsOut = tableLog - (uint32_t)hb32((uint32_t)nc - 1);
+            const uint32_t minStatePlus = (uint32_t)nc << maxBitsOut;
+            deltaNbBits[s] = (maxBitsOut << 16) - minStatePlus;
+            deltaFindState[s] = (int32_t)total - nc;
+            total += (uint32_t)nc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sequences (RFC 8878 3.1.1.3.2): predefined distributions and value -> code maps
+// ------------------------------------------------------------------------------------------------
+constexpr int SEQ_LL_SYMS = 36, SEQ_ML_SYMS = 53, SEQ_DEF_LOG = 6;
+
+struct SeqCTables  // encoding tables of the predefined literal-length / match-length distributions
+{
+    uint16_t ll_state[64];
+    uint16_t ml_state[64];
+    uint32_t ll_dnb[SEQ_LL_SYMS];
+    int32_t ll_dfs[SEQ_LL_SYMS];
+    uint32_t ml_dnb[SEQ_ML_SYMS];
+    int32_t ml_dfs[SEQ_ML_SYMS];
+};
+
+VBZ_HDN void seq_default_norms(int16_t* ll, int16_t* ml)
+{
+    const int16_t LLD[36] = { 4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1 };
+    const int16_t MLD[53] = { 1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                              1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1 };
+    for (int i = 0; i < 36; ++i) ll[i] = LLD[i];
+    for (int i = 0; i < 53; ++i) ml[i] = MLD[i];
+}
+
+VBZ_HDN void seq_build_default_ctables(SeqCTables* t)
+{
+    int16_t ll[36], ml[53];
+    uint8_t sym[64];
+    uint32_t cumul[56];
+    seq_default_norms(ll, ml);
+    fse_build_ctable(ll, 35, SEQ_DEF_LOG, t->ll_state, t->ll_dnb, t->ll_dfs, sym, cumul);
+    fse_build_ctable(ml, 52, SEQ_DEF_LOG, t->ml_state, t->ml_dnb, t->ml_dfs, sym, cumul);
+}
+
+// literal length -> (code, extra bits, number of extra bits)
+VBZ_HD void seq_ll_code(uint32_t v, uint32_t* code, uint32_t* extra, uint32_t* nbits)
+{
+    if (v < 16) { *code = v; *extra = 0; *nbits = 0; return; }
+    uint32_t c, base, nb;
+    if (v < 24) { c = 16 + ((v - 16) >> 1); nb = 1; base = 16 + ((v - 16) & ~1u); }
+    else if (v < 32) { c = 20 + ((v - 24) >> 2); nb = 2; base = 24 + ((v - 24) & ~3u); }
+    else if (v < 48) { c = 22 + ((v - 32) >> 3); nb = 3; base = 32 + ((v - 32) & ~7u); }
+    else if (v < 64) { c = 24; nb = 4; base = 48; }
+    else { const uint32_t h = (uint32_t)hb32(v); c = h + 19; nb = h; base = 1u << h; }
+    *code = c; *extra = v - base; *nbits = nb;
+}
+
+// match length (>= 3) -> (code, extra bits, number of extra bits)
+VBZ_HD void seq_ml_code(uint32_t ml, uint32_t* code, uint32_t* extra, uint32_t* nbits)
+{
+    const uint32_t v = ml - 3;
+    if (v < 32) { *code = v; *extra = 0; *nbits = 0; return; }
+    uint32_t c, base, nb;
+    if (v < 40) { c = 32 + ((v - 32) >> 1); nb = 1; base = 32 + ((v - 32) & ~1u); }
+    else if (v < 48) { c = 36 + ((v - 40) >> 2); nb = 2; base = 40 + ((v - 40) & ~3u); }
+    else if (v < 64) { c = 38 + ((v - 48) >> 3); nb = 3; base = 48 + ((v - 48) & ~7u); }
+    else if (v < 96) { c = 40 + ((v - 64) >> 4); nb = 4; base = 64 + ((v - 64) & ~15u); }
+    else if (v < 128) { c = 42; nb = 5; base = 96; }
+    else { const uint32_t h = (uint32_t)hb32(v); c = h + 36; nb = h; base = 1u << h; }
+    *code = c; *extra = v - base; *nbits = nb;
+}
+
 // FSE-compress the weight list (zstd HUF_compressWeights). Returns bytes, 0 = not compressible,
 // 1 = single repeated weight (caller falls back), -1 = error.
 // `counted`: w->count[0..12] already holds the histogram of the weights (the wave fills it in parallel)
@@ -439,55 +557,7 @@ VBZ_HDN int huf_compress_weights(uint8_t* dst, int cap, const uint8_t* weights, 
         if (h < 0) return -1;
         op += h;
     }
-    // FSE_buildCTable
-    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1;
-    const uint32_t step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    uint32_t highThreshold = tableSize - 1;
-    w->cumul[0] = 0;
-    for (uint32_t u = 1; u <= maxSymbolValue + 1; u++) {
-        if (w->norm[u - 1] == -1) {
-            w->cumul[u] = w->cumul[u - 1] + 1;
-            w->tableSymbol[highThreshold--] = (uint8_t)(u - 1);
-        } else {
-            w->cumul[u] = w->cumul[u - 1] + (uint32_t)w->norm[u - 1];
-        }
-    }
-    w->cumul[maxSymbolValue + 1] = tableSize + 1;
-    {
-        uint32_t position = 0;
-        for (uint32_t symbol = 0; symbol <= maxSymbolValue; symbol++) {
-            const int freq = w->norm[symbol];
-            for (int occ = 0; occ < freq; occ++) {
-                w->tableSymbol[position] = (uint8_t)symbol;
-                position = (position + step) & tableMask;
-                while (position > highThreshold) position = (position + step) & tableMask;
-            }
-        }
-    }
-    for (uint32_t u = 0; u < tableSize; u++) {
-        uint8_t s = w->tableSymbol[u];
-        w->stateTable[w->cumul[s]++] = (uint16_t)(tableSize + u);
-    }
-    {
-        uint32_t total = 0;
-        for (uint32_t s = 0; s <= maxSymbolValue; s++) {
-            const int nc = w->norm[s];
-            if (nc == 0) {
-                w->deltaNbBits[s] = ((tableLog + 1) << 16) - (1u << tableLog);
-                w->deltaFindState[s] = 0;
-            } else if (nc == -1 || nc == 1) {
-                w->deltaNbBits[s] = (tableLog << 16) - (1u << tableLog);
-                w->deltaFindState[s] = (int32_t)total - 1;
-                total++;
-            } else {
-                const uint32_t maxBitsOut = tableLog - (uint32_t)hb32((uint32_t)nc - 1);
-                const uint32_t minStatePlus = (uint32_t)nc << maxBitsOut;
-                w->deltaNbBits[s] = (maxBitsOut << 16) - minStatePlus;
-                w->deltaFindState[s] = (int32_t)total - nc;
-                total += (uint32_t)nc;
-            }
-        }
-    }
+    fse_build_ctable(w->norm, maxSymbolValue, tableLog, w->stateTable, w->deltaNbBits, w->deltaFindState, w->tableSymbol, w->cumul);
     // FSE_compress_usingCTable: two interleaved states, symbols consumed from the end
     BitW bw;
     bw.acc = 0;
