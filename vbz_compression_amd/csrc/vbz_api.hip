@@ -361,7 +361,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         // decode it and then fail in the svb stage with a stream error
         HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, s), "zstd_decode launch");
     }
-    dbg_end(c, n, "zstd_decode: parse flush", dbg);
+    dbg_end(c, n, "zstd_decode: parse flush seqtables chain place", dbg);
     ReadBatch d = rb;
     d.src = (const uint8_t*)c->scratch.p;
     d.src_off = svb_off;

@@ -707,6 +707,81 @@ __device__ bool flush_tasks_ring(DecLds& L, const uint8_t* src, uint8_t* dst, ui
     return __any(bad);
 }
 
+// all lanes.  Second half of the zero-run fast path: (literal length, match length) pairs are known, every
+// match copies the byte in front of it.  Positions come from wave prefix sums, so all sequences of a chunk of 64
+// are placed at once: a lane copies its literals and fills its run; runs of 64+ bytes are filled by the wave.
+// Returns the output position behind the block, or 0xFFFFFFFF if the pairs do not fit the block.
+__device__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pairs, uint32_t nseq, const uint8_t* litp, uint32_t ltype,
+                                    uint32_t regen, uint32_t opos, uint32_t fcs, uint32_t block_max, uint8_t* lds_lit,
+                                    uint32_t lds_cap, int lane)
+{
+    const uint8_t rle_byte = ltype == 1 ? litp[0] : 0;
+    uint32_t lposw = 0, oposw = opos;
+    for (uint32_t base = 0; base < nseq; base += WAVE) {
+        const uint32_t i = base + (uint32_t)lane;
+        uint32_t ll = 0, ml = 0;
+        if (i < nseq) {
+            const uint2 v = pairs[i];
+            ll = v.x;
+            ml = v.y;
+        }
+        const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(ll + ml);
+        const uint32_t tl = (uint32_t)__shfl((int)il, 63, 64), tt = (uint32_t)__shfl((int)it, 63, 64);
+        if ((uint64_t)lposw + tl > regen || (uint64_t)oposw + tt > fcs) return 0xFFFFFFFFu;
+        const uint32_t my_lit = lposw + il - ll;
+        uint32_t my_out = oposw + it - (ll + ml);
+        uint8_t lastb = rle_byte;
+        if (ltype != 1 && tl <= lds_cap) {
+            // the chunk's literals are contiguous: one coalesced copy into LDS, then short per-lane loops
+            __syncthreads();
+            for (uint32_t j = lane; 4 * j < tl; j += WAVE) {
+                uint32_t v;
+                __builtin_memcpy(&v, litp + lposw + 4 * j, 4);  // may read 3 bytes past the literals (staging slack)
+                reinterpret_cast<uint32_t*>(lds_lit)[j] = v;
+            }
+            __syncthreads();
+            const uint32_t lo = il - ll;
+            for (uint32_t k = 0; k < ll; ++k) {
+                lastb = lds_lit[lo + k];
+                dst[my_out + k] = lastb;
+            }
+        } else {
+            for (uint32_t k = 0; k < ll; ++k) {
+                if (ltype != 1) lastb = litp[my_lit + k];
+                dst[my_out + k] = lastb;
+            }
+        }
+        my_out += ll;
+        if (ml < 64) {  // unaligned dword stores are fine in global memory
+            const uint32_t v4 = (uint32_t)lastb * 0x01010101u;
+            uint32_t k = 0;
+            for (; k + 4 <= ml; k += 4) __builtin_memcpy(dst + my_out + k, &v4, 4);
+            for (; k < ml; ++k) dst[my_out + k] = lastb;
+        }
+        uint64_t big = __ballot(ml >= 64);
+        while (big) {
+            const int sl_ = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bo = (uint32_t)__shfl((int)my_out, sl_, 64);
+            const uint32_t bl = (uint32_t)__shfl((int)ml, sl_, 64);
+            const uint32_t bv = (uint32_t)__shfl((int)lastb, sl_, 64);
+            for (uint32_t k = lane; k < bl; k += WAVE) dst[bo + k] = (uint8_t)bv;
+        }
+        lposw += tl;
+        oposw += tt;
+    }
+    const uint32_t rest = regen - lposw;
+    if ((uint64_t)oposw + rest > fcs) return 0xFFFFFFFFu;
+    if (ltype == 1) {
+        for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
+    } else {
+        for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = litp[lposw + k];  // literals never alias the output here
+    }
+    oposw += rest;
+    if (oposw - opos > BLOCK_MAX || oposw - opos > block_max) return 0xFFFFFFFFu;
+    return oposw;
+}
+
 __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint32_t n, int lane)
 {
     for (uint32_t i = lane; i < n; i += WAVE) lds[i] = g[i];
@@ -736,6 +811,20 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     }
     uint8_t* dst = b.dst + b.dst_off[r];
     const uint32_t cap = b.dst_cap[r];
+#define FLUSH()                                                                                                       \
+    do {                                                                                                              \
+        if (fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane)) FAIL(); \
+        if (d_active) {                                                                                               \
+            PHASE(1);                                                                                                 \
+            if (place_zero_runs(dst, reinterpret_cast<const uint2*>(dst + d_pairs), d_nseq, d_lit, d_ltype, d_regen,    \
+                                d_opos, fcs, block_max, reinterpret_cast<uint8_t*>(&L.u.inbuf[0][0]),                 \
+                                (uint32_t)sizeof(L.u.inbuf) - 8u, lane) == 0xFFFFFFFFu)                                \
+                FAIL();                                                                                               \
+            d_active = false;                                                                                         \
+            __syncthreads();                                                                                          \
+            PHASE(4);                                                                                                 \
+        }                                                                                                             \
+    } while (0)
 #define FAIL()                                   \
     do {                                         \
         if (lane == 0) b.result[r] = E_ZSTD;     \
@@ -801,6 +890,11 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     bool huf_valid = false;
     bool fse_live = attempt != 0;  // FSE tables must survive: literal streams use the ring-less path
     bool tables_built = false, tables_lost = false;
+    // one block whose zero-run sequences are already decoded into pairs but not yet placed: its literals are
+    // still queued as stream tasks (staged behind the frame), it is finished right after the next flush
+    bool d_active = false;
+    uint32_t d_opos = 0, d_regen = 0, d_nseq = 0, d_ltype = 0, d_pairs = 0;
+    const uint8_t* d_lit = nullptr;
     int cur_slot = 0, cur_log = 0;      // current Huffman table: slot and table log
     bool have_ll = false, have_of = false, have_ml = false;
     int log_ll = 0, log_of = 0, log_ml = 0;
@@ -884,7 +978,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 for (uint32_t t = 0; t < ntask && !clash; ++t)
                     clash = ((L.t_tab[t] & 0xFFFF) == (uint32_t)slot * 2048u);
                 if (clash && ntask) {
-                    if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
+                    FLUSH();
                 }
                 if (tlog == 12) slot = 0;
                 huf_fill_table(L, &L.huf[0][0] + slot * 2048, nw, tlog, lane);
@@ -905,13 +999,39 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             //   no sequences : straight to the output (Huffman streams become pending tasks)
             //   sequences    : Huffman literals are staged right-aligned at the end of the frame's
             //                  output, where the growing output can never overtake the unread part
-            const uint32_t lit_dst = !has_seq ? opos : fcs - regen;
+            // A block whose sequences are all "offset 1" runs (OF table = RLE of code 0 while repeat offset 1 is 1:
+            // how zstd_encode.hip codes zero runs) is not executed in order: lane 0 only walks its FSE states now,
+            // its literal streams join the task queue (staged behind the frame in the slack of the destination
+            // slot), and the runs are placed in parallel after the next flush.
+            bool defer = false;
+            uint32_t ws_lit = 0, ws_pairs = 0;
+            if (has_seq && attempt == 0) {
+                if (d_active) FLUSH();
+                uint32_t go = 0;
+                if (lane == 0 && sqn >= 4) {
+                    const uint32_t used0 = nseq < 128 ? 1u : (nseq < 255 ? 2u : 3u);
+                    const uint32_t ns0 = nseq < 128 ? nseq : (nseq < 255 ? ((nseq - 128) << 8) + sq[1] : sq[1] + ((uint32_t)sq[2] << 8) + 0x7F00);
+                    if (used0 + 2 < sqn) {
+                        const uint32_t modes = sq[used0];
+                        const uint32_t llm = modes >> 6, ofm = (modes >> 4) & 3;
+                        const uint32_t ofsym_at = used0 + 1 + (llm == 1 ? 1u : 0u);
+                        ws_lit = (fcs + 15u) & ~15u;
+                        ws_pairs = ws_lit + (ltype >= 2 ? ((regen + 7u) & ~7u) : 0u);
+                        go = (ofm == 1 && llm != 2 && ofsym_at < sqn && sq[ofsym_at] == 0 && rep0 == 1 &&
+                              (uint64_t)ws_pairs + 8ull * ns0 + 8 <= cap) ? 1u : 0u;
+                    }
+                }
+                defer = __shfl((int)go, 0, 64) != 0;
+                ws_lit = (uint32_t)__shfl((int)ws_lit, 0, 64);
+                ws_pairs = (uint32_t)__shfl((int)ws_pairs, 0, 64);
+            }
+            const uint32_t lit_dst = !has_seq ? opos : (defer ? ws_lit : fcs - regen);
             const uint8_t* lit_src = blk + lh;  // raw literals are read in place
             if (ltype >= 2) {
                 const uint8_t* q = blk + lh + tree_used;
                 uint32_t qn = csize - tree_used;
                 if (ntask + streams > WAVE) {
-                    if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
+                    FLUSH();
                 }
                 const uint32_t tabref = (uint32_t)cur_slot * 2048u | ((uint32_t)cur_log << 16);
                 if (streams == 1) {
@@ -959,9 +1079,207 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 }
                 if (regen > block_max) FAIL();
                 opos += regen;
+            } else if (defer) {
+                PHASE(0);
+                // tables of this block (the union LDS is free: queued tasks are only descriptors)
+                stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
+                if (lane == 0) {
+                    uint32_t err = 0, used = 1, ns = nseq;
+                    const bool lost = tables_lost;
+                    const uint8_t* h = L.u.p.hbuf;
+                    const int hn = (int)(sqn < HBUF ? sqn : HBUF);
+                    if (ns >= 128) {
+                        if (ns == 255) {
+                            if (hn < 3) err = 1; else { ns = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
+                        } else {
+                            if (hn < 2) err = 1; else { ns = ((ns - 128) << 8) + h[1]; used = 2; }
+                        }
+                    }
+                    if (!err && (int)used >= hn) err = 1;
+                    if (!err) {
+                        const uint32_t modes = h[used++];
+                        if (modes & 3) err = 1;
+                        // a repeated table that a ring flush has overwritten: decode the frame again, carefully
+                        if (!err && lost && (((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3)) err = 3;
+                        int u;
+                        if (!err) {
+                            u = seq_table(L, L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err) {
+                            u = seq_table(L, L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err) {
+                            u = seq_table(L, L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
+                            if (u < 0) err = 1; else used += (uint32_t)u;
+                        }
+                        if (!err && used >= sqn) err = 1;
+                    }
+                    L.ctl[C_ERR] = err;
+                    L.ctl[C_I] = ns;
+                    L.ctl[C_J] = used;
+                }
+                __syncthreads();
+                if (L.ctl[C_ERR] == 3) {
+                    restart = true;
+                    break;
+                }
+                if (L.ctl[C_ERR]) FAIL();
+                nseq = L.ctl[C_I];
+                sq_used = L.ctl[C_J];
+                tables_built = true;
+                {
+                    const uint8_t* bs = sq + sq_used;
+                    const uint32_t bsn = sqn - sq_used;
+                    uint2* ws = reinterpret_cast<uint2*>(dst + ws_pairs);
+                    PHASE(2);
+                    // Lane 0 walks the two FSE state machines.  So that it never waits for memory, the wave keeps a
+                    // window of the (backward) bit stream in LDS; lane 0 holds 128 unread bits in registers and tops
+                    // them up 64 at a time from the window (the address of a top-up does not depend on the sequence
+                    // being decoded, so it is off the critical path).  The two tables are re-packed into 8-byte
+                    // entries {base value, next-state base, extra bits, state bits}: one LDS read per state and step.
+                    constexpr uint32_t WIN = 752;                                   // hbuf: 768 bytes
+                    uint32_t* win32 = reinterpret_cast<uint32_t*>(L.u.p.hbuf);
+                    uint2* llt = reinterpret_cast<uint2*>(L.u.p.symnext);           // 64 entries
+                    uint2* mlt = reinterpret_cast<uint2*>(L.u.p.norm);              // 64 entries
+                    uint32_t ok = 1, total = 0, si = 0;
+                    {
+                        // eligibility of the compact tables: accuracy logs <= 6, valid codes
+                        uint32_t bad = 0;
+                        if (lane == 0) bad = (log_ll > 6 || log_ml > 6 || log_of != 0 || (L.u.p.fse[1][0] & 0xFF) != 0) ? 1u : 0u;
+                        bad = (uint32_t)__shfl((int)bad, 0, 64);
+                        const int lgl = __shfl(log_ll, 0, 64), lgm = __shfl(log_ml, 0, 64);
+                        if (!bad) {
+                            uint32_t e1 = 0, e2 = 0;
+                            if (lane < (1 << lgl)) {
+                                const uint32_t e = L.u.p.fse[0][lane], c = e & 0xFF;
+                                if (c > 35) e1 = 1;
+                                else e1 = 0, llt[lane] = make_uint2(LL_BASE[c], (e >> 16) | ((uint32_t)LL_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
+                            }
+                            if (lane < (1 << lgm)) {
+                                const uint32_t e = L.u.p.fse[2][lane], c = e & 0xFF;
+                                if (c > 52) e2 = 1;
+                                else mlt[lane] = make_uint2(ML_BASE[c], (e >> 16) | ((uint32_t)ML_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
+                            }
+                            if (__any(e1 | e2)) FAIL();
+                        } else {
+                            ok = 2;
+                        }
+                    }
+                    int64_t bpos = 0;  // unread bits of the stream, including those held in registers (lane 0)
+                    if (bsn == 0 || bs[bsn - 1] == 0) FAIL();
+                    bpos = (int64_t)(bsn - 1) * 8 + hbit(bs[bsn - 1]);
+                    uint32_t sl = 0, sm = 0;
+                    uint64_t sum_ll = 0, sum_all = 0;
+                    uint64_t xhi = 0, xlo = 0;  // the next `have` unread bits, left aligned in xhi:xlo
+                    uint32_t have = 0;
+                    bool first = true;
+                    while (ok == 1) {
+                        // (re)fill the window so that it ends at the byte holding the lowest bit not yet in registers
+                        const int64_t wtop = bpos - have;
+                        const uint32_t whi = (uint32_t)((wtop + 7) >> 3) < bsn ? (uint32_t)((wtop + 7) >> 3) : bsn;
+                        const uint32_t wlo = whi > WIN ? whi - WIN : 0u;
+                        __syncthreads();
+                        for (uint32_t j = lane; 4 * j < whi - wlo; j += WAVE) {
+                            uint32_t v;
+                            __builtin_memcpy(&v, bs + wlo + 4 * j, 4);  // may read 3 bytes past the section (arena slack)
+                            win32[j] = v;
+                        }
+                        __syncthreads();
+                        if (lane == 0) {
+                            bool starved = false;
+                            auto topup = [&]() {  // append the 64 bits below the register window (have <= 64)
+                                const int64_t top = bpos - have;   // first bit not yet in registers
+                                if (top <= 0) return;
+                                const int64_t lo = top - 64;
+                                const uint32_t lob = lo > 0 ? (uint32_t)lo : 0u;
+                                if ((lob >> 3) < wlo) { starved = true; return; }
+                                const uint32_t rel = (lob >> 3) - wlo;
+                                const uint32_t q = rel >> 2, sh = 8 * (rel & 3) + (lob & 7);
+                                const uint64_t d10 = (uint64_t)win32[q] | ((uint64_t)win32[q + 1] << 32);
+                                const uint64_t d2 = win32[q + 2];
+                                uint64_t nw = sh ? ((d10 >> sh) | (d2 << (64 - sh))) : d10;
+                                uint32_t got = 64;
+                                if (lo < 0) { nw <<= (uint32_t)(-lo); got = (uint32_t)top; }
+                                xhi |= have < 64 ? (nw >> have) : 0ull;
+                                xlo |= have ? (nw << (64 - have)) : 0ull;
+                                if (have == 0) xlo = 0;
+                                have += got;
+                            };
+                            auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 50, nb <= have checked by the caller
+                                const uint32_t v = nb ? (uint32_t)(xhi >> (64 - nb)) : 0u;  // callers take <= 32 bits at once
+                                if (nb) {
+                                    xhi = (xhi << nb) | (xlo >> (64 - nb));
+                                    xlo <<= nb;
+                                }
+                                have -= nb;
+                                bpos -= nb;
+                                return v;
+                            };
+                            if (have <= 64) topup();
+                            if (first && !starved) {
+                                if ((uint32_t)(log_ll + log_ml) > have) ok = 0;
+                                else {
+                                    sl = take((uint32_t)log_ll);
+                                    sm = take((uint32_t)log_ml);  // the offset state has no bits
+                                }
+                            }
+                            while (ok == 1 && si < nseq && !starved) {
+                                if (have <= 64) {
+                                    topup();
+                                    if (starved) break;
+                                }
+                                const uint2 el = llt[sl], em = mlt[sm];
+                                const uint32_t mnb = (em.y >> 16) & 0xFF, lnb = (el.y >> 16) & 0xFF;
+                                const uint32_t snl = si + 1 < nseq ? el.y >> 24 : 0u, snm = si + 1 < nseq ? em.y >> 24 : 0u;
+                                if (mnb + lnb + snl + snm > have) { ok = 0; break; }  // reads past the start of the stream
+                                const uint32_t mlen = em.x + take(mnb);
+                                const uint32_t llen = el.x + take(lnb);
+                                if (llen == 0) { ok = 2; break; }  // repeat-offset semantics change: decode in order
+                                ws[si] = make_uint2(llen, mlen);
+                                sum_ll += llen;
+                                sum_all += (uint64_t)llen + mlen;
+                                sl = (el.y & 0xFFFF) + take(snl);
+                                sm = (em.y & 0xFFFF) + take(snm);
+                                ++si;
+                            }
+                        }
+                        first = false;
+                        ok = (uint32_t)__shfl((int)ok, 0, 64);
+                        si = (uint32_t)__shfl((int)si, 0, 64);
+                        have = (uint32_t)__shfl((int)have, 0, 64);
+                        bpos = ((int64_t)__shfl((int)(bpos >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bpos, 0, 64);
+                        if (si >= nseq) break;
+                    }
+                    PHASE(3);
+                    if (lane == 0) {
+                        if (ok == 1 && bpos != 0) ok = 0;  // every bit must be consumed, none beyond
+                        if (ok == 1 && sum_ll > regen) ok = 0;
+                        if (ok == 1 && sum_all + (regen - sum_ll) > BLOCK_MAX) ok = 0;
+                        total = (uint32_t)(sum_all + (regen - sum_ll));
+                    }
+                    ok = (uint32_t)__shfl((int)ok, 0, 64);
+                    total = (uint32_t)__shfl((int)total, 0, 64);
+                    if (ok == 0) FAIL();
+                    if (ok == 2) {  // not a pure zero-run block after all: decode the frame again, in order
+                        restart = true;
+                        break;
+                    }
+                    if ((uint64_t)opos + total > fcs || total > block_max) FAIL();
+                    d_active = true;
+                    d_opos = opos;
+                    d_regen = regen;
+                    d_nseq = nseq;
+                    d_ltype = ltype;
+                    d_pairs = ws_pairs;
+                    d_lit = ltype >= 2 ? dst + ws_lit : lit_src;
+                    opos += total;
+                    tables_lost = true;  // the next ring flush reuses the LDS of these tables
+                }
             } else {
                 // everything decoded so far must be in memory before matches can read it
-                if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
+                FLUSH();
                 // (this block's own Huffman literals were queued above, so they were decoded with the ring too)
                 if (!fse_live && tables_built) tables_lost = true;  // the ring shares its LDS with the FSE tables
                 stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
@@ -1015,132 +1333,6 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
                 const uint8_t* bs = sq + sq_used;
                 const uint32_t bsn = sqn - sq_used;
-                // ---- fast path: every match is "offset 1" (OF table = RLE of code 0 while repeat offset 1 is
-                // 1, every literal length > 0): the frames of zstd_encode.hip code zero runs this way.  Lane 0
-                // only walks the FSE states and leaves (literal length, match length) pairs in the unused tail
-                // of the destination slot; the wave then places all literals and run fills in parallel.
-                bool did_fast = false;
-                {
-                    const uint32_t ws_off = (fcs + 7u) & ~7u;
-                    uint32_t go = 0;
-                    if (lane == 0)
-                        go = (log_of == 0 && (L.u.p.fse[1][0] & 0xFF) == 0 && rep0 == 1 &&
-                              (uint64_t)ws_off + 8ull * nseq + 8 <= cap) ? 1u : 0u;
-                    go = (uint32_t)__shfl((int)go, 0, 64);
-                    if (go) {
-                        uint2* ws = reinterpret_cast<uint2*>(dst + ws_off);
-                        // length tables next to the FSE tables: base | extra bits << 24
-                        uint32_t* lt = reinterpret_cast<uint32_t*>(L.u.p.norm);
-                        if (lane < 36) lt[lane] = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
-                        if (lane < 53) lt[36 + lane] = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
-                        __syncthreads();
-                        uint32_t ok = 1;
-                        if (lane == 0) {
-                            BitReaderPF pr;
-                            if (!pr.init(bs, bsn)) ok = 0;
-                            uint32_t sl = 0, sm = 0;
-                            uint64_t sum_ll = 0, sum_all = 0;
-                            if (ok) {
-                                sl = pr.read(log_ll);
-                                sm = pr.read(log_ml);  // the offset state has no bits
-                                if (pr.over) ok = 0;
-                            }
-                            for (uint32_t i = 0; ok && i < nseq; ++i) {
-                                const uint32_t el = L.u.p.fse[0][sl], em = L.u.p.fse[2][sm];
-                                const uint32_t lc = el & 0xFF, mc = em & 0xFF;
-                                if (lc > 35 || mc > 52) { ok = 0; break; }
-                                const uint32_t mt = lt[36 + mc], ltv = lt[lc];
-                                const uint32_t mlen = (mt & 0xFFFFFF) + pr.read((int)(mt >> 24));
-                                const uint32_t llen = (ltv & 0xFFFFFF) + pr.read((int)(ltv >> 24));
-                                if (llen == 0) { ok = 2; break; }  // repeat-offset semantics change: general path
-                                ws[i] = make_uint2(llen, mlen);
-                                sum_ll += llen;
-                                sum_all += (uint64_t)llen + mlen;
-                                if (i + 1 < nseq) {
-                                    sl = (el >> 16) + pr.read((int)((el >> 8) & 0xFF));
-                                    sm = (em >> 16) + pr.read((int)((em >> 8) & 0xFF));
-                                }
-                                if (pr.over) ok = 0;
-                            }
-                            if (ok == 1 && !pr.finished()) ok = 0;
-                            // the parallel placement must not write where staged Huffman literals still wait
-                            if (ok == 1 && sum_ll > regen) ok = 0;
-                            if (ok == 1 && ltype >= 2 && (uint64_t)opos + sum_all + (regen - sum_ll) > lit_dst) ok = 2;
-                        }
-                        ok = (uint32_t)__shfl((int)ok, 0, 64);
-                        if (ok == 0) FAIL();
-                        if (ok == 1) {
-                            __syncthreads();  // the pairs were written by lane 0 (vmcnt drain)
-                            const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
-                            const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
-                            uint32_t lposw = 0, oposw = opos;
-                            for (uint32_t base = 0; base < nseq; base += WAVE) {
-                                const uint32_t i = base + (uint32_t)lane;
-                                uint32_t ll = 0, ml = 0;
-                                if (i < nseq) {
-                                    const uint2 v = ws[i];
-                                    ll = v.x;
-                                    ml = v.y;
-                                }
-                                const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(ll + ml);
-                                const uint32_t tl = (uint32_t)__shfl((int)il, 63, 64), tt = (uint32_t)__shfl((int)it, 63, 64);
-                                if ((uint64_t)lposw + tl > regen || (uint64_t)oposw + tt > fcs) FAIL();
-                                const uint32_t my_lit = lposw + il - ll;
-                                uint32_t my_out = oposw + it - (ll + ml);
-                                uint8_t lastb = rle_byte;
-                                for (uint32_t k = 0; k < ll; ++k) {
-                                    if (ltype != 1) lastb = litp[my_lit + k];
-                                    dst[my_out + k] = lastb;
-                                }
-                                my_out += ll;
-                                // short fills by the owning lane, long ones by the whole wave
-                                if (ml < 64)
-                                    for (uint32_t k = 0; k < ml; ++k) dst[my_out + k] = lastb;
-                                uint64_t big = __ballot(ml >= 64);
-                                while (big) {
-                                    const int sl_ = __ffsll((long long)big) - 1;
-                                    big &= big - 1;
-                                    const uint32_t bo = (uint32_t)__shfl((int)my_out, sl_, 64);
-                                    const uint32_t bl = (uint32_t)__shfl((int)ml, sl_, 64);
-                                    const uint32_t bv = (uint32_t)__shfl((int)lastb, sl_, 64);
-                                    for (uint32_t k = lane; k < bl; k += WAVE) dst[bo + k] = (uint8_t)bv;
-                                }
-                                lposw += tl;
-                                oposw += tt;
-                            }
-                            if (oposw - opos > BLOCK_MAX) FAIL();
-                            // remaining literals
-                            const uint32_t rest = regen - lposw;
-                            if ((uint64_t)oposw + rest > fcs) FAIL();
-                            __syncthreads();
-                            if (ltype == 1) {
-                                for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
-                            } else {
-                                const uint8_t* from = litp + lposw;
-                                uint8_t* to = dst + oposw;
-                                if (from != to) {
-                                    for (uint32_t k0 = 0; k0 < rest; k0 += WAVE) {
-                                        const uint32_t k = k0 + lane;
-                                        uint8_t v = 0;
-                                        if (k < rest) v = from[k];
-                                        __syncthreads();
-                                        if (k < rest) to[k] = v;
-                                    }
-                                }
-                            }
-                            oposw += rest;
-                            if (oposw - opos > BLOCK_MAX || oposw - opos > block_max) FAIL();
-                            opos = oposw;
-                            __syncthreads();
-                            did_fast = true;
-                        }
-                    }
-                }
-                if (did_fast) {
-                    pos += bsize;
-                    if (last) break;
-                    continue;
-                }
                 fse_live = true;  // libzstd-style frame: keep the FSE tables, later literal streams use the direct path
                 BitReader br;
                 uint32_t sl = 0, so = 0, sm = 0;
@@ -1251,8 +1443,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     }
     if (restart) continue;
     PHASE(0);
-    if (ntask) {
-        if ((fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane))) FAIL();
+    if (ntask || d_active) {
+        FLUSH();
     }
     PHASE(1);
     break;
@@ -1267,6 +1459,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     if (dbg && lane == 0)
         for (int k = 0; k < 6; ++k) dbg[(size_t)r * 8 + k] = tph[k];
 #undef PHASE
+#undef FLUSH
 #undef FAIL
 }
 

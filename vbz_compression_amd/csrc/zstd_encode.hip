@@ -347,7 +347,10 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
 // literals (everything outside the run tails) are Huffman coded as before.  Which bytes are run tails is a
 // morphological open of the zero mask, computed with shifts on a 64-bit window per lane; positions come from
 // wave prefix sums.  Only the FSE state chain of the sequences is serial (lane 0, ~RMIN+ bytes per step).
-constexpr uint32_t RMIN = 8;        // shortest zero run that becomes a match (break-even is ~13 bits); >= 8, <= 24
+#ifndef VBZ_RMIN
+#define VBZ_RMIN 16
+#endif
+constexpr uint32_t RMIN = VBZ_RMIN;  // shortest zero run that becomes a match (break-even is ~13 bytes); >= 8, <= 24
 static_assert(RMIN >= 8 && RMIN <= 24, "the tokeniser handles at most two run ends per 16 positions and a 64-bit window");
 constexpr uint32_t TOK_PAYLOAD = 60 * 16;
 
