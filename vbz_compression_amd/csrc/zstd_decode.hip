@@ -50,6 +50,9 @@ struct DecLds
     uint32_t t_src[WAVE], t_size[WAVE], t_out[WAVE], t_cnt[WAVE], t_tab[WAVE];  // pending stream tasks
     uint32_t ctl[24];
 };
+// one wave per workgroup: the frame's LDS state.  At namespace scope so that functions that are real calls
+// (not inlined, to keep the kernel's register footprint down) still address it as LDS.
+__shared__ DecLds L;
 
 // ctl slots
 enum { C_ERR = 0, C_A, C_B, C_C, C_D, C_E, C_F, C_G, C_H, C_I, C_J, C_K };
@@ -213,7 +216,7 @@ __device__ __forceinline__ int hbit(uint32_t v) { return 31 - __clz((int)v); }
 
 // FSE table description (RFC 8878 4.1.1) read from LDS bytes; lane 0 only.
 // returns bytes consumed or -1; fills L.u.p.norm[0..nsym)
-__device__ int read_ncount(DecLds& L, const uint8_t* p, int n, int max_symbol, int max_log, int* out_log, int* out_nsym)
+__device__ int read_ncount(const uint8_t* p, int n, int max_symbol, int max_log, int* out_log, int* out_nsym)
 {
     if (n < 1) return -1;
     auto bits = [&](uint32_t bitpos, int k) -> uint32_t {
@@ -276,7 +279,7 @@ __device__ int read_ncount(DecLds& L, const uint8_t* p, int n, int max_symbol, i
 }
 
 // FSE decoding table from L.u.p.norm (lane 0 only): RFC 8878 4.1.1
-__device__ int fse_build(DecLds& L, uint32_t* tab, int nsym, int log)
+__device__ int fse_build(uint32_t* tab, int nsym, int log)
 {
     const int size = 1 << log;
     int high = size - 1;
@@ -325,12 +328,12 @@ __device__ const uint8_t ML_BITS[53] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 
 
 // one sequence-table definition (lane 0): mode 0 predefined, 1 RLE, 2 FSE, 3 repeat.
 // returns bytes consumed from p, or -1
-__device__ int seq_table(DecLds& L, uint32_t* tab, int* log_io, bool* have, int mode, const uint8_t* p, int n,
+__device__ __noinline__ int seq_table(uint32_t* tab, int* log_io, bool* have, int mode, const uint8_t* p, int n,
                          const int16_t* def, int def_n, int def_log, int max_sym, int max_log)
 {
     if (mode == 0) {
         for (int i = 0; i < def_n; ++i) L.u.p.norm[i] = def[i];
-        if (fse_build(L, tab, def_n, def_log) != 0) return -1;
+        if (fse_build(tab, def_n, def_log) != 0) return -1;
         *log_io = def_log;
         *have = true;
         return 0;
@@ -344,9 +347,9 @@ __device__ int seq_table(DecLds& L, uint32_t* tab, int* log_io, bool* have, int 
     }
     if (mode == 2) {
         int log, nsym;
-        const int used = read_ncount(L, p, n, max_sym, max_log, &log, &nsym);
+        const int used = read_ncount(p, n, max_sym, max_log, &log, &nsym);
         if (used < 0) return -1;
-        if (fse_build(L, tab, nsym, log) != 0) return -1;
+        if (fse_build(tab, nsym, log) != 0) return -1;
         *log_io = log;
         *have = true;
         return used;
@@ -355,7 +358,7 @@ __device__ int seq_table(DecLds& L, uint32_t* tab, int* log_io, bool* have, int 
 }
 
 // Huffman tree description -> weights in L.weights (lane 0). returns bytes consumed or -1; sets nw/log
-__device__ int huf_read_weights(DecLds& L, const uint8_t* p, int n, int* out_nw, int* out_log)
+__device__ __noinline__ int huf_read_weights(const uint8_t* p, int n, int* out_nw, int* out_log)
 {
     if (n < 1) return -1;
     int nw = 0, used;
@@ -369,10 +372,10 @@ __device__ int huf_read_weights(DecLds& L, const uint8_t* p, int n, int* out_nw,
         used = 1 + hb;
         if (hb == 0 || used > n) return -1;
         int log, nsym;
-        const int hdr = read_ncount(L, p + 1, hb, 255, 6, &log, &nsym);
+        const int hdr = read_ncount(p + 1, hb, 255, 6, &log, &nsym);
         if (hdr < 0) return -1;
         uint32_t* tab = L.wfse;
-        if (fse_build(L, tab, nsym, log) != 0) return -1;
+        if (fse_build(tab, nsym, log) != 0) return -1;
         // two interleaved FSE states over an LDS-resident backward bit stream (at most 127 bytes)
         const uint8_t* q = p + 1 + hdr;
         const int qn = hb - hdr;
@@ -434,7 +437,7 @@ __device__ int huf_read_weights(DecLds& L, const uint8_t* p, int n, int* out_nw,
 // increasing symbol value).  Table start of a symbol = cells of all lighter symbols + cells of the equally
 // heavy symbols before it, found with ballots in symbol order; short runs are written by the owning lane,
 // long ones by the whole wave.
-__device__ void huf_fill_table(DecLds& L, uint16_t* T, uint32_t nw, uint32_t tlog, int lane)
+__device__ __noinline__ void huf_fill_table(uint16_t* T, uint32_t nw, uint32_t tlog, int lane)
 {
     if (lane < 16) L.ctl[8 + lane] = 0;  // cells per weight live in ctl[8..23]
     __syncthreads();
@@ -541,7 +544,7 @@ __device__ __forceinline__ void fetch_batch(gcu8* p, uint32_t& nextbyte, uint32_
 
 // ring-less variant: every lane reads its stream straight from memory, 4 bytes at a time.  Used while
 // FSE tables are live in the LDS the rings would need (frames with sequences, i.e. libzstd's frames).
-__device__ bool flush_tasks_direct(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
+__device__ __noinline__ bool flush_tasks_direct(const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
 {
     bool bad = false;
     if ((uint32_t)lane < ntask) {
@@ -585,7 +588,7 @@ __device__ bool flush_tasks_direct(DecLds& L, const uint8_t* src, uint8_t* dst, 
 }
 
 // all lanes: decode the queued Huffman streams, one per lane.  Returns true if any stream is corrupt.
-__device__ bool flush_tasks_ring(DecLds& L, const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
+__device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
 {
     bool bad = false;
     const bool mine = (uint32_t)lane < ntask;
@@ -711,7 +714,7 @@ __device__ bool flush_tasks_ring(DecLds& L, const uint8_t* src, uint8_t* dst, ui
 // match copies the byte in front of it.  Positions come from wave prefix sums, so all sequences of a chunk of 64
 // are placed at once: a lane copies its literals and fills its run; runs of 64+ bytes are filled by the wave.
 // Returns the output position behind the block, or 0xFFFFFFFF if the pairs do not fit the block.
-__device__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pairs, uint32_t nseq, const uint8_t* litp, uint32_t ltype,
+__device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pairs, uint32_t nseq, const uint8_t* litp, uint32_t ltype,
                                     uint32_t regen, uint32_t opos, uint32_t fcs, uint32_t block_max, uint8_t* lds_lit,
                                     uint32_t lds_cap, int lane)
 {
@@ -782,6 +785,145 @@ __device__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pairs, uint32_t n
     return oposw;
 }
 
+// all lanes.  First half of the zero-run fast path: lane 0 walks the LL and ML state machines of a block whose
+// offsets are all "repeat offset 1" and writes (literal length, match length) pairs to `ws`.
+// Returns 0 = corrupt, 1 = pairs written (*total_out = bytes the block regenerates), 2 = not such a block after
+// all (the caller decodes the frame again, in order).
+__device__ __noinline__ uint32_t zero_run_chain(const uint8_t* bs, uint32_t bsn, uint2* ws, uint32_t nseq, int log_ll, int log_of,
+                                                int log_ml, uint32_t regen, int lane, uint32_t* total_out)
+{
+#define FAIL() return 0u
+    // Lane 0 walks the two FSE state machines.  So that it never waits for memory, the wave keeps a
+    // window of the (backward) bit stream in LDS; lane 0 holds 128 unread bits in registers and tops
+    // them up 64 at a time from the window (the address of a top-up does not depend on the sequence
+    // being decoded, so it is off the critical path).  The two tables are re-packed into 8-byte
+    // entries {base value, next-state base, extra bits, state bits}: one LDS read per state and step.
+    constexpr uint32_t WIN = 752;                                   // hbuf: 768 bytes
+    uint32_t* win32 = reinterpret_cast<uint32_t*>(L.u.p.hbuf);
+    uint2* llt = reinterpret_cast<uint2*>(L.u.p.symnext);           // 64 entries
+    uint2* mlt = reinterpret_cast<uint2*>(L.u.p.norm);              // 64 entries
+    uint32_t ok = 1, total = 0, si = 0;
+    {
+        // eligibility of the compact tables: accuracy logs <= 6, valid codes
+        uint32_t bad = 0;
+        if (lane == 0) bad = (log_ll > 6 || log_ml > 6 || log_of != 0 || (L.u.p.fse[1][0] & 0xFF) != 0) ? 1u : 0u;
+        bad = (uint32_t)__shfl((int)bad, 0, 64);
+        const int lgl = __shfl(log_ll, 0, 64), lgm = __shfl(log_ml, 0, 64);
+        if (!bad) {
+            uint32_t e1 = 0, e2 = 0;
+            if (lane < (1 << lgl)) {
+                const uint32_t e = L.u.p.fse[0][lane], c = e & 0xFF;
+                if (c > 35) e1 = 1;
+                else e1 = 0, llt[lane] = make_uint2(LL_BASE[c], (e >> 16) | ((uint32_t)LL_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
+            }
+            if (lane < (1 << lgm)) {
+                const uint32_t e = L.u.p.fse[2][lane], c = e & 0xFF;
+                if (c > 52) e2 = 1;
+                else mlt[lane] = make_uint2(ML_BASE[c], (e >> 16) | ((uint32_t)ML_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
+            }
+            if (__any(e1 | e2)) FAIL();
+        } else {
+            ok = 2;
+        }
+    }
+    int64_t bpos = 0;  // unread bits of the stream, including those held in registers (lane 0)
+    if (bsn == 0 || bs[bsn - 1] == 0) FAIL();
+    bpos = (int64_t)(bsn - 1) * 8 + hbit(bs[bsn - 1]);
+    uint32_t sl = 0, sm = 0;
+    uint64_t sum_ll = 0, sum_all = 0;
+    uint64_t xhi = 0, xlo = 0;  // the next `have` unread bits, left aligned in xhi:xlo
+    uint32_t have = 0;
+    bool first = true;
+    while (ok == 1) {
+        // (re)fill the window so that it ends at the byte holding the lowest bit not yet in registers
+        const int64_t wtop = bpos - have;
+        const uint32_t whi = (uint32_t)((wtop + 7) >> 3) < bsn ? (uint32_t)((wtop + 7) >> 3) : bsn;
+        const uint32_t wlo = whi > WIN ? whi - WIN : 0u;
+        __syncthreads();
+        for (uint32_t j = lane; 4 * j < whi - wlo; j += WAVE) {
+            uint32_t v;
+            __builtin_memcpy(&v, bs + wlo + 4 * j, 4);  // may read 3 bytes past the section (arena slack)
+            win32[j] = v;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            bool starved = false;
+            auto topup = [&]() {  // append the 64 bits below the register window (have <= 64)
+                const int64_t top = bpos - have;   // first bit not yet in registers
+                if (top <= 0) return;
+                const int64_t lo = top - 64;
+                const uint32_t lob = lo > 0 ? (uint32_t)lo : 0u;
+                if ((lob >> 3) < wlo) { starved = true; return; }
+                const uint32_t rel = (lob >> 3) - wlo;
+                const uint32_t q = rel >> 2, sh = 8 * (rel & 3) + (lob & 7);
+                const uint64_t d10 = (uint64_t)win32[q] | ((uint64_t)win32[q + 1] << 32);
+                const uint64_t d2 = win32[q + 2];
+                uint64_t nw = sh ? ((d10 >> sh) | (d2 << (64 - sh))) : d10;
+                uint32_t got = 64;
+                if (lo < 0) { nw <<= (uint32_t)(-lo); got = (uint32_t)top; }
+                xhi |= have < 64 ? (nw >> have) : 0ull;
+                xlo |= have ? (nw << (64 - have)) : 0ull;
+                if (have == 0) xlo = 0;
+                have += got;
+            };
+            auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 50, nb <= have checked by the caller
+                const uint32_t v = nb ? (uint32_t)(xhi >> (64 - nb)) : 0u;  // callers take <= 32 bits at once
+                if (nb) {
+                    xhi = (xhi << nb) | (xlo >> (64 - nb));
+                    xlo <<= nb;
+                }
+                have -= nb;
+                bpos -= nb;
+                return v;
+            };
+            if (have <= 64) topup();
+            if (first && !starved) {
+                if ((uint32_t)(log_ll + log_ml) > have) ok = 0;
+                else {
+                    sl = take((uint32_t)log_ll);
+                    sm = take((uint32_t)log_ml);  // the offset state has no bits
+                }
+            }
+            while (ok == 1 && si < nseq && !starved) {
+                if (have <= 64) {
+                    topup();
+                    if (starved) break;
+                }
+                const uint2 el = llt[sl], em = mlt[sm];
+                const uint32_t mnb = (em.y >> 16) & 0xFF, lnb = (el.y >> 16) & 0xFF;
+                const uint32_t snl = si + 1 < nseq ? el.y >> 24 : 0u, snm = si + 1 < nseq ? em.y >> 24 : 0u;
+                if (mnb + lnb + snl + snm > have) { ok = 0; break; }  // reads past the start of the stream
+                const uint32_t mlen = em.x + take(mnb);
+                const uint32_t llen = el.x + take(lnb);
+                if (llen == 0) { ok = 2; break; }  // repeat-offset semantics change: decode in order
+                ws[si] = make_uint2(llen, mlen);
+                sum_ll += llen;
+                sum_all += (uint64_t)llen + mlen;
+                sl = (el.y & 0xFFFF) + take(snl);
+                sm = (em.y & 0xFFFF) + take(snm);
+                ++si;
+            }
+        }
+        first = false;
+        ok = (uint32_t)__shfl((int)ok, 0, 64);
+        si = (uint32_t)__shfl((int)si, 0, 64);
+        have = (uint32_t)__shfl((int)have, 0, 64);
+        bpos = ((int64_t)__shfl((int)(bpos >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bpos, 0, 64);
+        if (si >= nseq) break;
+    }
+    if (lane == 0) {
+        if (ok == 1 && bpos != 0) ok = 0;  // every bit must be consumed, none beyond
+        if (ok == 1 && sum_ll > regen) ok = 0;
+        if (ok == 1 && sum_all + (regen - sum_ll) > BLOCK_MAX) ok = 0;
+        total = (uint32_t)(sum_all + (regen - sum_ll));
+    }
+    ok = (uint32_t)__shfl((int)ok, 0, 64);
+    total = (uint32_t)__shfl((int)total, 0, 64);
+    *total_out = total;
+    return ok;
+#undef FAIL
+}
+
 __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint32_t n, int lane)
 {
     for (uint32_t i = lane; i < n; i += WAVE) lds[i] = g[i];
@@ -791,12 +933,14 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
 #ifndef VBZ_DEC_WAVES
 #define VBZ_DEC_WAVES 1
 #endif
+// TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
+// dozens of registers in the production kernel otherwise
+template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg)
 {
-    __shared__ DecLds L;
     unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
-    unsigned long long tlast = dbg ? __builtin_readcyclecounter() : 0;
-#define PHASE(k) do { if (dbg) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
+    unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
+#define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
     const int lane = threadIdx.x;
     if (b.gate && b.gate[r] >= E_FIRST) {
@@ -813,7 +957,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const uint32_t cap = b.dst_cap[r];
 #define FLUSH()                                                                                                       \
     do {                                                                                                              \
-        if (fse_live ? flush_tasks_direct(L, src, dst, ntask, lane) : flush_tasks_ring(L, src, dst, ntask, lane)) FAIL(); \
+        if (fse_live ? flush_tasks_direct(src, dst, ntask, lane) : flush_tasks_ring(src, dst, ntask, lane)) FAIL(); \
         if (d_active) {                                                                                               \
             PHASE(1);                                                                                                 \
             if (place_zero_runs(dst, reinterpret_cast<const uint2*>(dst + d_pairs), d_nseq, d_lit, d_ltype, d_regen,    \
@@ -960,7 +1104,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 stage_bytes(L.u.p.hbuf, blk + lh, tn, lane);
                 if (lane == 0) {
                     int inw = 0, ilog = 0;
-                    const int used = huf_read_weights(L, L.u.p.hbuf, (int)tn, &inw, &ilog);
+                    const int used = huf_read_weights(L.u.p.hbuf, (int)tn, &inw, &ilog);
                     L.ctl[C_ERR] = used < 0;
                     L.ctl[C_F] = (uint32_t)used;
                     L.ctl[C_G] = (uint32_t)inw;
@@ -981,7 +1125,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     FLUSH();
                 }
                 if (tlog == 12) slot = 0;
-                huf_fill_table(L, &L.huf[0][0] + slot * 2048, nw, tlog, lane);
+                huf_fill_table(&L.huf[0][0] + slot * 2048, nw, tlog, lane);
                 huf_valid = true;
                 cur_slot = slot;
                 cur_log = (int)tlog;
@@ -1103,15 +1247,15 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if (!err && lost && (((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3)) err = 3;
                         int u;
                         if (!err) {
-                            u = seq_table(L, L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
+                            u = seq_table(L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err) {
-                            u = seq_table(L, L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
+                            u = seq_table(L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err) {
-                            u = seq_table(L, L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
+                            u = seq_table(L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err && used >= sqn) err = 1;
@@ -1130,137 +1274,11 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 sq_used = L.ctl[C_J];
                 tables_built = true;
                 {
-                    const uint8_t* bs = sq + sq_used;
-                    const uint32_t bsn = sqn - sq_used;
-                    uint2* ws = reinterpret_cast<uint2*>(dst + ws_pairs);
                     PHASE(2);
-                    // Lane 0 walks the two FSE state machines.  So that it never waits for memory, the wave keeps a
-                    // window of the (backward) bit stream in LDS; lane 0 holds 128 unread bits in registers and tops
-                    // them up 64 at a time from the window (the address of a top-up does not depend on the sequence
-                    // being decoded, so it is off the critical path).  The two tables are re-packed into 8-byte
-                    // entries {base value, next-state base, extra bits, state bits}: one LDS read per state and step.
-                    constexpr uint32_t WIN = 752;                                   // hbuf: 768 bytes
-                    uint32_t* win32 = reinterpret_cast<uint32_t*>(L.u.p.hbuf);
-                    uint2* llt = reinterpret_cast<uint2*>(L.u.p.symnext);           // 64 entries
-                    uint2* mlt = reinterpret_cast<uint2*>(L.u.p.norm);              // 64 entries
-                    uint32_t ok = 1, total = 0, si = 0;
-                    {
-                        // eligibility of the compact tables: accuracy logs <= 6, valid codes
-                        uint32_t bad = 0;
-                        if (lane == 0) bad = (log_ll > 6 || log_ml > 6 || log_of != 0 || (L.u.p.fse[1][0] & 0xFF) != 0) ? 1u : 0u;
-                        bad = (uint32_t)__shfl((int)bad, 0, 64);
-                        const int lgl = __shfl(log_ll, 0, 64), lgm = __shfl(log_ml, 0, 64);
-                        if (!bad) {
-                            uint32_t e1 = 0, e2 = 0;
-                            if (lane < (1 << lgl)) {
-                                const uint32_t e = L.u.p.fse[0][lane], c = e & 0xFF;
-                                if (c > 35) e1 = 1;
-                                else e1 = 0, llt[lane] = make_uint2(LL_BASE[c], (e >> 16) | ((uint32_t)LL_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
-                            }
-                            if (lane < (1 << lgm)) {
-                                const uint32_t e = L.u.p.fse[2][lane], c = e & 0xFF;
-                                if (c > 52) e2 = 1;
-                                else mlt[lane] = make_uint2(ML_BASE[c], (e >> 16) | ((uint32_t)ML_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
-                            }
-                            if (__any(e1 | e2)) FAIL();
-                        } else {
-                            ok = 2;
-                        }
-                    }
-                    int64_t bpos = 0;  // unread bits of the stream, including those held in registers (lane 0)
-                    if (bsn == 0 || bs[bsn - 1] == 0) FAIL();
-                    bpos = (int64_t)(bsn - 1) * 8 + hbit(bs[bsn - 1]);
-                    uint32_t sl = 0, sm = 0;
-                    uint64_t sum_ll = 0, sum_all = 0;
-                    uint64_t xhi = 0, xlo = 0;  // the next `have` unread bits, left aligned in xhi:xlo
-                    uint32_t have = 0;
-                    bool first = true;
-                    while (ok == 1) {
-                        // (re)fill the window so that it ends at the byte holding the lowest bit not yet in registers
-                        const int64_t wtop = bpos - have;
-                        const uint32_t whi = (uint32_t)((wtop + 7) >> 3) < bsn ? (uint32_t)((wtop + 7) >> 3) : bsn;
-                        const uint32_t wlo = whi > WIN ? whi - WIN : 0u;
-                        __syncthreads();
-                        for (uint32_t j = lane; 4 * j < whi - wlo; j += WAVE) {
-                            uint32_t v;
-                            __builtin_memcpy(&v, bs + wlo + 4 * j, 4);  // may read 3 bytes past the section (arena slack)
-                            win32[j] = v;
-                        }
-                        __syncthreads();
-                        if (lane == 0) {
-                            bool starved = false;
-                            auto topup = [&]() {  // append the 64 bits below the register window (have <= 64)
-                                const int64_t top = bpos - have;   // first bit not yet in registers
-                                if (top <= 0) return;
-                                const int64_t lo = top - 64;
-                                const uint32_t lob = lo > 0 ? (uint32_t)lo : 0u;
-                                if ((lob >> 3) < wlo) { starved = true; return; }
-                                const uint32_t rel = (lob >> 3) - wlo;
-                                const uint32_t q = rel >> 2, sh = 8 * (rel & 3) + (lob & 7);
-                                const uint64_t d10 = (uint64_t)win32[q] | ((uint64_t)win32[q + 1] << 32);
-                                const uint64_t d2 = win32[q + 2];
-                                uint64_t nw = sh ? ((d10 >> sh) | (d2 << (64 - sh))) : d10;
-                                uint32_t got = 64;
-                                if (lo < 0) { nw <<= (uint32_t)(-lo); got = (uint32_t)top; }
-                                xhi |= have < 64 ? (nw >> have) : 0ull;
-                                xlo |= have ? (nw << (64 - have)) : 0ull;
-                                if (have == 0) xlo = 0;
-                                have += got;
-                            };
-                            auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 50, nb <= have checked by the caller
-                                const uint32_t v = nb ? (uint32_t)(xhi >> (64 - nb)) : 0u;  // callers take <= 32 bits at once
-                                if (nb) {
-                                    xhi = (xhi << nb) | (xlo >> (64 - nb));
-                                    xlo <<= nb;
-                                }
-                                have -= nb;
-                                bpos -= nb;
-                                return v;
-                            };
-                            if (have <= 64) topup();
-                            if (first && !starved) {
-                                if ((uint32_t)(log_ll + log_ml) > have) ok = 0;
-                                else {
-                                    sl = take((uint32_t)log_ll);
-                                    sm = take((uint32_t)log_ml);  // the offset state has no bits
-                                }
-                            }
-                            while (ok == 1 && si < nseq && !starved) {
-                                if (have <= 64) {
-                                    topup();
-                                    if (starved) break;
-                                }
-                                const uint2 el = llt[sl], em = mlt[sm];
-                                const uint32_t mnb = (em.y >> 16) & 0xFF, lnb = (el.y >> 16) & 0xFF;
-                                const uint32_t snl = si + 1 < nseq ? el.y >> 24 : 0u, snm = si + 1 < nseq ? em.y >> 24 : 0u;
-                                if (mnb + lnb + snl + snm > have) { ok = 0; break; }  // reads past the start of the stream
-                                const uint32_t mlen = em.x + take(mnb);
-                                const uint32_t llen = el.x + take(lnb);
-                                if (llen == 0) { ok = 2; break; }  // repeat-offset semantics change: decode in order
-                                ws[si] = make_uint2(llen, mlen);
-                                sum_ll += llen;
-                                sum_all += (uint64_t)llen + mlen;
-                                sl = (el.y & 0xFFFF) + take(snl);
-                                sm = (em.y & 0xFFFF) + take(snm);
-                                ++si;
-                            }
-                        }
-                        first = false;
-                        ok = (uint32_t)__shfl((int)ok, 0, 64);
-                        si = (uint32_t)__shfl((int)si, 0, 64);
-                        have = (uint32_t)__shfl((int)have, 0, 64);
-                        bpos = ((int64_t)__shfl((int)(bpos >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bpos, 0, 64);
-                        if (si >= nseq) break;
-                    }
+                    uint32_t total = 0;
+                    const uint32_t ok = zero_run_chain(sq + sq_used, sqn - sq_used, reinterpret_cast<uint2*>(dst + ws_pairs), nseq,
+                                                       log_ll, log_of, log_ml, regen, lane, &total);
                     PHASE(3);
-                    if (lane == 0) {
-                        if (ok == 1 && bpos != 0) ok = 0;  // every bit must be consumed, none beyond
-                        if (ok == 1 && sum_ll > regen) ok = 0;
-                        if (ok == 1 && sum_all + (regen - sum_ll) > BLOCK_MAX) ok = 0;
-                        total = (uint32_t)(sum_all + (regen - sum_ll));
-                    }
-                    ok = (uint32_t)__shfl((int)ok, 0, 64);
-                    total = (uint32_t)__shfl((int)total, 0, 64);
                     if (ok == 0) FAIL();
                     if (ok == 2) {  // not a pure zero-run block after all: decode the frame again, in order
                         restart = true;
@@ -1303,15 +1321,15 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if (!err && lost && (((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3)) err = 3;
                         int u;
                         if (!err) {
-                            u = seq_table(L, L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
+                            u = seq_table(L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err) {
-                            u = seq_table(L, L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
+                            u = seq_table(L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err) {
-                            u = seq_table(L, L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
+                            u = seq_table(L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
                             if (u < 0) err = 1; else used += (uint32_t)u;
                         }
                         if (!err && used >= sqn) err = 1;
@@ -1456,7 +1474,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     if (pos != n) FAIL();   // one frame per buffer (what vbz writes)
     if (opos != fcs) FAIL();
     if (lane == 0) b.result[r] = fcs;
-    if (dbg && lane == 0)
+    if (TIMED && lane == 0)
         for (int k = 0; k < 6; ++k) dbg[(size_t)r * 8 + k] = tph[k];
 #undef PHASE
 #undef FLUSH
@@ -1468,7 +1486,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
 hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(zstd_decode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg);
+    if (dbg)
+        hipLaunchKernelGGL(zstd_decode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg);
+    else
+        hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg);
     return hipGetLastError();
 }
 

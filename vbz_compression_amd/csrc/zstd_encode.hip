@@ -560,14 +560,17 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
 #ifndef VBZ_ENC_WAVES
 #define VBZ_ENC_WAVES 4   // measured: 2.2 ms (4 waves/SIMD, 16 symbols/lane) vs 2.85 ms (2 waves, 32 symbols/lane)
 #endif
+// TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
+// dozens of registers in the production kernel otherwise
+template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab)
 {
     __shared__ EncLds L;
     unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
-    unsigned long long tlast = dbg ? __builtin_readcyclecounter() : 0;
-#define PHASE(k) do { if (dbg) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
+    unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
+#define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
     const int lane = threadIdx.x;
     if (b.gate && b.gate[r] >= E_FIRST) {
@@ -968,7 +971,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         }
     }
     if (lane == 0) b.result[r] = opos;
-    if (dbg && lane == 0)
+    if (TIMED && lane == 0)
         for (int k = 0; k < 6; ++k) dbg[(size_t)r * 8 + k] = tph[k];
 #undef PHASE
 #undef NEED
@@ -981,8 +984,12 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
                               hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
-    hipLaunchKernelGGL(zstd_encode_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg, src_cap,
-                       reinterpret_cast<const SeqCTables*>(seq_tables));
+    if (dbg)
+        hipLaunchKernelGGL(zstd_encode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables));
+    else
+        hipLaunchKernelGGL(zstd_encode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables));
     return hipGetLastError();
 }
 
