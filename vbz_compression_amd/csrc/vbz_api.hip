@@ -53,6 +53,7 @@ struct vbz_gpu_ctx
     DevBuf one_in, one_out, one_meta;
     DevBuf dbg;       // per-read phase timers (VBZ_HIP_PHASE_TIMING=1)
     DevBuf seqtab;    // encoding tables of the predefined sequence distributions
+    DevBuf seqdtab;   // decoding tables of the same distributions
     bool zero_run_sequences = true;
     bool phase_timing = false;
     void* pinned = nullptr;
@@ -335,7 +336,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     }
     if (o->integer_size == 0) {  // vbz.cpp:259-262: content larger than the destination -> DESTINATION_SIZE
         Timed t(c, "zstd_decode");
-        HIPCHK(c, launch_zstd_decode(rb, E_DESTINATION_SIZE, nullptr, s), "zstd_decode launch");
+        HIPCHK(c, launch_zstd_decode(rb, E_DESTINATION_SIZE, nullptr, c->seqdtab.p, s), "zstd_decode launch");
         return 0;
     }
     // entropy stage into scratch (sized for the largest svb stream the expected output can have),
@@ -359,9 +360,9 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         Timed t(c, "zstd_decode");
         // a frame whose content cannot be a valid svb stream of the expected size: the reference would
         // decode it and then fail in the svb stage with a stream error
-        HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, s), "zstd_decode launch");
+        HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, c->seqdtab.p, s), "zstd_decode launch");
     }
-    dbg_end(c, n, "zstd_decode: parse flush seqtables chain place", dbg);
+    dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable", dbg);
     ReadBatch d = rb;
     d.src = (const uint8_t*)c->scratch.p;
     d.src_off = svb_off;
@@ -425,6 +426,14 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
             vbz_gpu_destroy(c);
             return nullptr;
         }
+        std::vector<uint8_t> hostd(seq_dtables_bytes());
+        seq_dtables_build(hostd.data());
+        if (!ensure(c, c->seqdtab, hostd.size()) ||
+            hipMemcpy(c->seqdtab.p, hostd.data(), hostd.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error(nullptr, "could not upload the sequence decoding tables");
+            vbz_gpu_destroy(c);
+            return nullptr;
+        }
     }
     if (stream) {
         c->stream = (hipStream_t)stream;
@@ -449,7 +458,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab })
         if (b->p) hipFree(b->p);
     if (c->pinned) hipHostFree(c->pinned);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -537,7 +546,7 @@ int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
     if (!c || !bt) return -1;
     (void)hipSetDevice(c->device);
     Timed t(c, "zstd_decode");
-    HIPCHK(c, launch_zstd_decode(to_rb(bt), E_ZSTD, nullptr, c->stream), "zstd_decode launch");
+    HIPCHK(c, launch_zstd_decode(to_rb(bt), E_ZSTD, nullptr, c->seqdtab.p, c->stream), "zstd_decode launch");
     return 0;
 }
 

@@ -56,7 +56,11 @@ size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);
 // decode: result[i] = frame content size, E_ZSTD for a malformed frame, or `toosmall_code` when the
 // frame's content size exceeds dst_cap[i].
-hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, hipStream_t s);
+// seq_dtables (device, from seq_dtables_build): decoding tables of the predefined LL / ML distributions.
+hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, const void* seq_dtables,
+                              hipStream_t s);
+size_t seq_dtables_bytes();
+void seq_dtables_build(void* host_buffer);
 
 // ---- helpers (helpers.hip) ---------------------------------------------------------------------
 // scratch slots for the intermediate svb streams: slot(i) = align16(ceil(raw_size[i]*num/den)+8)+48,

@@ -28,18 +28,26 @@ constexpr int HBUF = 768;
 #define VBZ_DEC_RING 32
 #endif
 #define VBZ_DEC_RING_DECL VBZ_DEC_RING
+// experiment knobs (defaults are the full decoder): entries per Huffman table slot, entries per FSE table
+#ifndef VBZ_DEC_HUF_SLOT
+#define VBZ_DEC_HUF_SLOT 2048
+#endif
+#ifndef VBZ_DEC_FSE_SLOT
+#define VBZ_DEC_FSE_SLOT 512
+#endif
+constexpr int HUF_SLOT = VBZ_DEC_HUF_SLOT, FSE_SLOT = VBZ_DEC_FSE_SLOT;
 struct DecLds
 {
-    uint16_t huf[2][2048];   // two Huffman decoding tables: symbol | nbBits << 8 (a 12-bit table spans both)
+    uint16_t huf[2][HUF_SLOT];   // two Huffman decoding tables: symbol | nbBits << 8 (a 12-bit table spans both)
     // The input rings of the stream decoders share their LDS with everything that is only needed while
     // headers are parsed or sequences are executed.  Frames that carry sequences (fse tables must survive
     // from block to block) decode their literal streams with the ring-less path instead.
     union
     {
-        uint32_t inbuf[VBZ_DEC_RING_DECL][WAVE];  // per-lane rings of compressed input ([dword][lane])
+        uint32_t inbuf[VBZ_DEC_RING_DECL + 1][WAVE];  // per-lane rings of compressed input ([slot][lane]), slot 0 mirrors the last
         struct
         {
-            uint32_t fse[3][512];  // LL, OF, ML decoding tables: symbol | nbBits << 8 | base << 16
+            uint32_t fse[3][FSE_SLOT];  // LL, OF, ML decoding tables: symbol | nbBits << 8 | base << 16
             uint8_t hbuf[HBUF];    // staged header bytes of the current block section
             int16_t norm[256];
             uint16_t symnext[256];
@@ -213,6 +221,10 @@ struct BitReaderPF
 };
 
 __device__ __forceinline__ int hbit(uint32_t v) { return 31 - __clz((int)v); }
+// wave-uniform helpers: values the compiler keeps in scalar registers, and reads of one lane of a vector register
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+__device__ __forceinline__ uint32_t lane_put(uint32_t reg, uint32_t l, uint32_t v, int lane) { return (uint32_t)lane == l ? v : reg; }
 
 // FSE table description (RFC 8878 4.1.1) read from LDS bytes; lane 0 only.
 // returns bytes consumed or -1; fills L.u.p.norm[0..nsym)
@@ -433,6 +445,187 @@ __device__ __noinline__ int huf_read_weights(const uint8_t* p, int n, int* out_n
     return used;
 }
 
+// all lanes.  Huffman tree description at g[0..n) -> weights in L.weights, like huf_read_weights, but written as
+// wave-uniform code: the description (at most 129 bytes) sits across the lanes of one register (lane j = bytes
+// 4j..4j+3), so do the probabilities and the FSE table of the weights (at most 64 cells), and the two interleaved
+// state machines run on the scalar unit.  Returns bytes consumed, -1 for a corrupt description, -2 when the
+// description is legal but does not fit this layout (the caller falls back to huf_read_weights).
+__device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lane, uint32_t* out_nw, uint32_t* out_log)
+{
+    const uint32_t n = uni(n_);
+    if (n < 1) return -1;
+    uint32_t d = 0;
+    if (4u * (uint32_t)lane < n) __builtin_memcpy(&d, g + 4 * lane, 4);  // up to 3 bytes past n: inside the block / arena slack
+    const uint32_t hb = lane_get(d, 0) & 0xFF;
+    uint32_t nw = 0, used;
+    if (hb >= 128) {  // direct representation: 4 bits per weight
+        nw = hb - 127;
+        used = 1 + (nw + 1) / 2;
+        if (used > n) return -1;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t i = (uint32_t)lane + 64u * j, b = 1 + i / 2;
+            const uint32_t dw = (uint32_t)__shfl((int)d, (int)(b >> 2), 64);
+            const uint32_t by = (dw >> (8 * (b & 3))) & 0xFF;
+            if (i < nw) L.weights[i] = (uint8_t)((i & 1) ? (by & 0xF) : (by >> 4));
+        }
+    } else {
+        used = 1 + hb;
+        if (hb == 0 || used > n) return -1;
+        {  // bytes behind the description read as zero
+            const uint32_t lo = 4u * (uint32_t)lane;
+            if (lo >= used) d = 0;
+            else if (lo + 4 > used) d &= (1u << (8 * (used - lo))) - 1u;
+        }
+        auto bits = [&](uint32_t bitpos, uint32_t k) -> uint32_t {  // k <= 16 bits at absolute bit position bitpos
+            const uint32_t idx = bitpos >> 5;
+            const uint64_t v = (uint64_t)lane_get(d, idx & 63) | ((uint64_t)lane_get(d, (idx + 1) & 63) << 32);
+            return (uint32_t)(v >> (bitpos & 31)) & ((1u << k) - 1u);
+        };
+        // ---- probabilities (RFC 8878 4.1.1), forward bit stream from byte 1; lane s of `nrm` = count of symbol s
+        const uint32_t log = (bits(8, 4)) + 5;
+        if (log > 6) return -1;
+        uint32_t bitpos = 12, nrm = 0, sym = 0;
+        int remaining = (1 << log) + 1, threshold = 1 << log, nbits = (int)log + 1;
+        bool prev0 = false;
+        while (remaining > 1 && sym <= 255) {
+            if (prev0) {
+                for (;;) {
+                    const uint32_t rr = bits(bitpos, 2);
+                    bitpos += 2;
+                    sym += rr;  // zero counts: nrm is already 0 there
+                    if (rr != 3) break;
+                }
+                prev0 = false;
+                if (sym > 255) break;
+                continue;
+            }
+            const int max = (2 * threshold - 1) - remaining;
+            const uint32_t v = bits(bitpos, (uint32_t)nbits);
+            int count;
+            if ((int)(v & (uint32_t)(threshold - 1)) < max) {
+                count = (int)(v & (uint32_t)(threshold - 1));
+                bitpos += (uint32_t)(nbits - 1);
+            } else {
+                count = (int)(v & (uint32_t)(2 * threshold - 1));
+                if (count >= threshold) count -= max;
+                bitpos += (uint32_t)nbits;
+            }
+            count--;
+            remaining -= count < 0 ? -count : count;
+            if (sym >= 64) return -2;  // more symbols than lanes: legal, but not what a weight table looks like
+            nrm = lane_put(nrm, sym, (uint32_t)count, lane);
+            ++sym;
+            prev0 = (count == 0);
+            while (remaining < threshold) {
+                nbits--;
+                threshold >>= 1;
+            }
+        }
+        if (remaining != 1) return -1;
+        if (sym > 256) return -1;
+        if (sym > 64) return -2;
+        const uint32_t nsym = sym;
+        const uint32_t hdr = (bitpos - 8 + 7) >> 3;  // bytes of the table description
+        if (hdr > hb) return -1;
+        // ---- FSE decoding table (4.1.1): lane u of `tab` = cell u (symbol | nbBits << 8 | base << 16)
+        const uint32_t size = 1u << log, mask = size - 1;
+        uint32_t tab = 0, snext = 0, high = size - 1;
+        for (uint32_t s2 = 0; s2 < nsym; ++s2) {
+            const int c = (int)lane_get(nrm, s2);
+            if (c == -1) {
+                tab = lane_put(tab, high, s2, lane);
+                --high;
+                snext = lane_put(snext, s2, 1u, lane);
+            } else {
+                snext = lane_put(snext, s2, (uint32_t)c, lane);
+            }
+        }
+        {
+            const uint32_t step = (size >> 1) + (size >> 3) + 3;
+            uint32_t pos = 0;
+            for (uint32_t s2 = 0; s2 < nsym; ++s2) {
+                const int c = (int)lane_get(nrm, s2);
+                for (int i = 0; i < c; ++i) {
+                    tab = lane_put(tab, pos, s2, lane);
+                    do {
+                        pos = (pos + step) & mask;
+                    } while (pos > high);
+                }
+            }
+            if (pos != 0) return -1;
+        }
+        for (uint32_t u = 0; u < size; ++u) {
+            const uint32_t s2 = lane_get(tab, u) & 0xFF;
+            const uint32_t ns = lane_get(snext, s2);
+            snext = lane_put(snext, s2, ns + 1, lane);
+            const uint32_t nb = log - (uint32_t)hbit(ns);
+            tab = lane_put(tab, u, s2 | (nb << 8) | ((((ns << nb) - size) & 0xFFFFu) << 16), lane);
+        }
+        // ---- the weights: two interleaved states over the backward bit stream in bytes [1 + hdr, 1 + hb)
+        const uint32_t lowbit = 8 * (1 + hdr);
+        const uint32_t lastbyte = bits(8 * hb, 8);
+        if (hdr >= hb || lastbyte == 0) return -1;
+        uint32_t P = 8 * hb + (uint32_t)hbit(lastbyte);  // unread bits are [lowbit, P)
+        bool over = false;
+        auto rd = [&](uint32_t nb) -> uint32_t {  // nb <= 6; past the start: zero fill, over = true
+            const uint32_t have = P - lowbit;
+            uint32_t v;
+            if (nb <= have) {
+                P -= nb;
+                v = nb ? bits(P, nb) : 0u;
+            } else {
+                v = (have ? bits(lowbit, have) : 0u) << (nb - have);
+                P = lowbit;
+                over = true;
+            }
+            return v;
+        };
+        uint32_t s1 = rd(log), s2 = rd(log);
+        if (over) return -1;
+        for (;;) {
+            if (nw > 253) return -1;
+            uint32_t e = lane_get(tab, s1);
+            L.weights[nw++] = (uint8_t)e;
+            s1 = (e >> 16) + rd((e >> 8) & 0xFF);
+            if (over) { L.weights[nw++] = (uint8_t)lane_get(tab, s2); break; }
+            if (nw > 253) return -1;
+            e = lane_get(tab, s2);
+            L.weights[nw++] = (uint8_t)e;
+            s2 = (e >> 16) + rd((e >> 8) & 0xFF);
+            if (over) { L.weights[nw++] = (uint8_t)lane_get(tab, s1); break; }
+        }
+    }
+    __syncthreads();
+    // ---- the implied last weight and the sanity rules of libzstd's HUF_readStats, four weights per lane
+    uint32_t part = 0, ones = 0, badw = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t i = (uint32_t)lane + 64u * j;
+        const uint32_t wt = i < nw ? L.weights[i] : 0u;
+        badw |= wt >= 12 ? 1u : 0u;
+        part += (wt && wt < 12) ? (1u << (wt - 1)) : 0u;
+        ones += wt == 1 ? 1u : 0u;
+    }
+    if (__any(badw)) return -1;
+    const uint32_t total = (uint32_t)__shfl((int)wave_incl_scan_u32(part), 63, 64);
+    uint32_t r1 = (uint32_t)__shfl((int)wave_incl_scan_u32(ones), 63, 64);
+    if (total == 0) return -1;
+    const uint32_t tlog = (uint32_t)hbit(total) + 1;
+    if (tlog > 12) return -1;
+    const uint32_t rest = (1u << tlog) - total;
+    if (rest & (rest - 1)) return -1;
+    const uint32_t lastw = (uint32_t)hbit(rest) + 1;
+    if (lane == 0) L.weights[nw] = (uint8_t)lastw;
+    ++nw;
+    r1 += lastw == 1 ? 1u : 0u;
+    if (r1 < 2 || (r1 & 1)) return -1;
+    *out_nw = nw;
+    *out_log = tlog;
+    __syncthreads();
+    return (int)used;
+}
+
 // all lanes: fill a Huffman decoding table from L.weights[0..nw) (RFC 8878 4.2.1: increasing weight, then
 // increasing symbol value).  Table start of a symbol = cells of all lighter symbols + cells of the equally
 // heavy symbols before it, found with ballots in symbol order; short runs are written by the owning lane,
@@ -588,101 +781,91 @@ __device__ __noinline__ bool flush_tasks_direct(const uint8_t* src, uint8_t* dst
 }
 
 // all lanes: decode the queued Huffman streams, one per lane.  Returns true if any stream is corrupt.
+//
+// A lane's compressed bytes arrive through its LDS ring ([slot][lane], filled 64 bytes at a time one period
+// ahead, at wave-uniform points).  The decoder keeps no bit buffer: with c = bits consumed so far (c >= 1, the end
+// mark), the next 32 unread bits are {D[k], D[k+1]} << ((c-1) % 32 + 1) >> 32 with k = (c-1) / 32.  Holding
+// n = -c makes that one v_alignbit_b32(D[k], D[k+1], n), and storing the ring upside down (dword k in slot
+// RING - k % RING, slot 0 mirroring slot RING) makes the pair one ds_read2st64_b32 at slot (n >> 5) % RING.
+// 32 fresh bits are good for two symbols (codes are at most 11 bits), so a pair of symbols costs one ring read,
+// two table reads and about a dozen ALU operations, with no conditional refill.
 __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
 {
     bool bad = false;
     const bool mine = (uint32_t)lane < ntask;
     gcu8* p = (gcu8*)src;
-    uint32_t n = 0, cnt = 0, tab = 0;
+    uint32_t nbytes = 0, cnt = 0, tab = 0;
     gu8* o = (gu8*)dst;
     if (mine) {
         p = (gcu8*)src + L.t_src[lane];
-        n = L.t_size[lane];
+        nbytes = L.t_size[lane];
         o = (gu8*)dst + L.t_out[lane];
         cnt = L.t_cnt[lane];
         tab = L.t_tab[lane];
     }
-    const int log = (int)(tab >> 16);
+    const uint32_t sL = 32u - (tab >> 16);  // a table index is the top `log` bits of the fresh word
     const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
-    uint32_t* ring = &L.u.inbuf[0][0] + lane;  // ring[k * WAVE]
+    uint32_t* ring = &L.u.inbuf[0][0] + lane;  // slot s of this lane: ring[s * WAVE]
 
-    uint64_t buf = 0;
-    int32_t avail = 0, bits_left = 0;
-    uint32_t nextbyte = 0, ridx = 0, widx = 0, occ = 0;
+    int32_t n = -1;  // minus the number of bits consumed
+    uint32_t nextbyte = 0, widx = 0;
     uint32_t pend[BATCH];
     if (mine) {
-        const uint32_t last = n ? p[n - 1] : 0;
+        const uint32_t last = nbytes ? p[nbytes - 1] : 0;
         if (last == 0) {
             bad = true;
             cnt = 0;
         } else {
-            const int hb = 31 - __clz((int)last);
-            buf = hb ? ((uint64_t)(last & ((1u << hb) - 1u)) << (64 - hb)) : 0ull;
-            avail = hb;
-            bits_left = (int32_t)((n - 1) * 8u) + hb;
-            nextbyte = n - 1;
+            n = -(int32_t)(8 - (31 - __clz((int)last)));  // padding and end mark
+            nextbyte = nbytes;
         }
     }
-    // initial fill: two batches into the ring, a third one in flight.  Past the start of the stream
-    // fetch_batch yields zeros, so the ring never runs dry (bits_left tells real bits from padding).
+    // initial fill: the whole ring, a further batch in flight.  Past the start of the stream fetch_batch
+    // yields zeros, so the ring never runs dry (the final value of n tells real bits from padding).
+#define RING_PUT()                                                              \
+    do {                                                                        \
+        const uint32_t wb__ = (uint32_t)RING - (widx & (uint32_t)(RING - 1));   \
+        _Pragma("unroll") for (int k = 0; k < BATCH; ++k) ring[(wb__ - (uint32_t)k) * WAVE] = pend[k]; \
+        if (wb__ == (uint32_t)RING) ring[0] = pend[0];                          \
+        widx += BATCH;                                                          \
+    } while (0)
     for (int f = 0; f < 2; ++f) {
         fetch_batch(p, nextbyte, pend);
-#pragma unroll
-        for (int k = 0; k < BATCH; ++k) ring[((widx + k) & (RING - 1)) * WAVE] = pend[k];
-        widx += BATCH;
-        occ += BATCH;
+        RING_PUT();
     }
     fetch_batch(p, nextbyte, pend);
 
-    // branch-free refill: the ring read is always issued, its result used only if the buffer is low
-#define HUF_REFILL()                                                   \
-    do {                                                               \
-        const uint32_t w__ = ring[(ridx & (RING - 1)) * WAVE];         \
-        const bool need__ = avail <= 32;                               \
-        const uint64_t add__ = (uint64_t)w__ << ((32 - avail) & 63);   \
-        buf |= need__ ? add__ : 0ull;                                  \
-        avail += need__ ? 32 : 0;                                      \
-        ridx += need__ ? 1u : 0u;                                      \
-        occ -= need__ ? 1u : 0u;                                       \
-    } while (0)
-#define HUF_SYM(dstvar)                                                \
-    do {                                                               \
-        const uint32_t e__ = T[(uint32_t)(buf >> (64 - log))];         \
-        const int nb__ = (int)(e__ >> 8);                              \
-        buf <<= nb__;                                                  \
-        avail -= nb__;                                                 \
-        dstvar = e__ & 0xFFu;                                          \
+    // two symbols from 32 fresh bits
+#define HUF_PAIR(e1, e2)                                                               \
+    do {                                                                               \
+        const uint32_t slot__ = ((uint32_t)n >> 5) & (uint32_t)(RING - 1);             \
+        const uint32_t d1__ = ring[slot__ * WAVE], d0__ = ring[(slot__ + 1) * WAVE];   \
+        uint32_t x__ = __builtin_amdgcn_alignbit(d0__, d1__, (uint32_t)n);             \
+        e1 = T[x__ >> sL];                                                             \
+        x__ <<= (e1 >> 8);                                                             \
+        e2 = T[x__ >> sL];                                                             \
     } while (0)
 
     while (__any(cnt > 0)) {
-        // ---- uniform top-up point
-        if (occ <= (uint32_t)(RING - BATCH)) {
-#pragma unroll
-            for (int k = 0; k < BATCH; ++k) ring[((widx + k) & (RING - 1)) * WAVE] = pend[k];
-            widx += BATCH;
-            occ += BATCH;
+        // ---- top-up point (at least BATCH dwords are still unread in the ring afterwards)
+        if (widx - (((uint32_t)~n) >> 5) <= (uint32_t)(RING - BATCH)) {
+            RING_PUT();
             fetch_batch(p, nextbyte, pend);
         }
-        // ---- one period: two groups of 16 symbols, each stored with one 16-byte write
+        // ---- one period: groups of 16 symbols, each stored with one 16-byte write
 #pragma unroll
         for (int g = 0; g < PERIOD / 16; ++g) {
             if (cnt >= 16) {
                 uint32_t ow[4];
-                const int32_t before = avail;
-                uint32_t refills = ridx;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    uint32_t s0, s1, s2, s3;
-                    HUF_REFILL();
-                    HUF_SYM(s0);
-                    HUF_SYM(s1);
-                    HUF_REFILL();
-                    HUF_SYM(s2);
-                    HUF_SYM(s3);
-                    ow[q] = s0 | (s1 << 8) | (s2 << 16) | (s3 << 24);
+                    uint32_t e1, e2, e3, e4;
+                    HUF_PAIR(e1, e2);
+                    n -= (int32_t)((e1 >> 8) + (e2 >> 8));
+                    HUF_PAIR(e3, e4);
+                    n -= (int32_t)((e3 >> 8) + (e4 >> 8));
+                    ow[q] = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((e3 & 0xFFu) << 16) | (e4 << 24);
                 }
-                refills = ridx - refills;
-                bits_left -= before + 32 * (int32_t)refills - avail;  // bits consumed by the 16 symbols
                 typedef __attribute__((address_space(1), aligned(1))) u32x4 gs4;
                 const u32x4 ov = { ow[0], ow[1], ow[2], ow[3] };
                 *(gs4*)o = ov;
@@ -690,21 +873,18 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
                 cnt -= 16;
             } else if (cnt > 0) {
                 while (cnt > 0) {
-                    uint32_t s0;
-                    const int32_t before = avail;
-                    const uint32_t r0 = ridx;
-                    HUF_REFILL();
-                    HUF_SYM(s0);
-                    bits_left -= before + 32 * (int32_t)(ridx - r0) - avail;
-                    *o++ = (uint8_t)s0;
+                    uint32_t e1, e2;
+                    HUF_PAIR(e1, e2);
+                    n -= (int32_t)(e1 >> 8);
+                    *o++ = (uint8_t)e1;
                     --cnt;
                 }
             }
         }
     }
-#undef HUF_REFILL
-#undef HUF_SYM
-    if (mine && bits_left != 0) bad = true;  // every bit of the stream must be consumed, none beyond
+#undef HUF_PAIR
+#undef RING_PUT
+    if (mine && !bad && n != -(int32_t)(8u * nbytes)) bad = true;  // every bit of the stream must be consumed, none beyond
     ntask = 0;
     __syncthreads();  // also makes the decoded bytes visible to the whole wave (vmcnt drain)
     return __any(bad);
@@ -785,143 +965,101 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
     return oposw;
 }
 
-// all lanes.  First half of the zero-run fast path: lane 0 walks the LL and ML state machines of a block whose
-// offsets are all "repeat offset 1" and writes (literal length, match length) pairs to `ws`.
+// Decoding tables of the predefined LL / ML distributions in the compact form the zero-run chain uses:
+// entry = { base value, next-state base | extra bits << 16 | state bits << 24 }, one entry per lane.
+struct SeqDTables
+{
+    uint2 ll[64], ml[64];
+};
+
+
+// all lanes.  First half of the zero-run fast path: walk the LL and ML state machines of a block whose offsets are
+// all "repeat offset 1" and write (literal length, match length) pairs to `ws`.
+// The walk is one dependent chain, so it is written as wave-uniform code that the compiler keeps on the scalar
+// unit, with everything it looks up held across the lanes of vector registers: lane j of llt / mlt is table entry
+// j (accuracy logs <= 6), lane j of `win` is the j-th dword of the current 256-byte window of the (backward) bit
+// stream, lane (i & 63) of pl / pm collects pair i until 64 of them leave with one store.  No LDS, no memory
+// latency on the chain except one window load per 2048 bits.
 // Returns 0 = corrupt, 1 = pairs written (*total_out = bytes the block regenerates), 2 = not such a block after
 // all (the caller decodes the frame again, in order).
-__device__ __noinline__ uint32_t zero_run_chain(const uint8_t* bs, uint32_t bsn, uint2* ws, uint32_t nseq, int log_ll, int log_of,
-                                                int log_ml, uint32_t regen, int lane, uint32_t* total_out)
+__device__ __noinline__ uint32_t zero_run_chain(const uint8_t* bs_, uint32_t bsn_, uint2* ws, uint32_t nseq_, uint2 llt, uint2 mlt,
+                                                uint32_t log_ll_, uint32_t log_ml_, uint32_t regen_, int lane, uint32_t* total_out)
 {
-#define FAIL() return 0u
-    // Lane 0 walks the two FSE state machines.  So that it never waits for memory, the wave keeps a
-    // window of the (backward) bit stream in LDS; lane 0 holds 128 unread bits in registers and tops
-    // them up 64 at a time from the window (the address of a top-up does not depend on the sequence
-    // being decoded, so it is off the critical path).  The two tables are re-packed into 8-byte
-    // entries {base value, next-state base, extra bits, state bits}: one LDS read per state and step.
-    constexpr uint32_t WIN = 752;                                   // hbuf: 768 bytes
-    uint32_t* win32 = reinterpret_cast<uint32_t*>(L.u.p.hbuf);
-    uint2* llt = reinterpret_cast<uint2*>(L.u.p.symnext);           // 64 entries
-    uint2* mlt = reinterpret_cast<uint2*>(L.u.p.norm);              // 64 entries
-    uint32_t ok = 1, total = 0, si = 0;
-    {
-        // eligibility of the compact tables: accuracy logs <= 6, valid codes
-        uint32_t bad = 0;
-        if (lane == 0) bad = (log_ll > 6 || log_ml > 6 || log_of != 0 || (L.u.p.fse[1][0] & 0xFF) != 0) ? 1u : 0u;
-        bad = (uint32_t)__shfl((int)bad, 0, 64);
-        const int lgl = __shfl(log_ll, 0, 64), lgm = __shfl(log_ml, 0, 64);
-        if (!bad) {
-            uint32_t e1 = 0, e2 = 0;
-            if (lane < (1 << lgl)) {
-                const uint32_t e = L.u.p.fse[0][lane], c = e & 0xFF;
-                if (c > 35) e1 = 1;
-                else e1 = 0, llt[lane] = make_uint2(LL_BASE[c], (e >> 16) | ((uint32_t)LL_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
-            }
-            if (lane < (1 << lgm)) {
-                const uint32_t e = L.u.p.fse[2][lane], c = e & 0xFF;
-                if (c > 52) e2 = 1;
-                else mlt[lane] = make_uint2(ML_BASE[c], (e >> 16) | ((uint32_t)ML_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
-            }
-            if (__any(e1 | e2)) FAIL();
-        } else {
-            ok = 2;
+    const uint32_t bsn = uni(bsn_), nseq = uni(nseq_), log_ll = uni(log_ll_), log_ml = uni(log_ml_), regen = uni(regen_);
+    const uint8_t* bs = reinterpret_cast<const uint8_t*>(((uint64_t)uni((uint32_t)((uint64_t)bs_ >> 32)) << 32) |
+                                                         uni((uint32_t)(uint64_t)bs_));
+    if (bsn == 0) return 0u;
+    uint32_t k0 = 0;  // the window holds dwords k0 .. k0+63, counted from the end of the stream
+    auto load_window = [&]() -> uint32_t {
+        const int64_t off = (int64_t)bsn - 4 * (int64_t)(k0 + (uint32_t)lane + 1);
+        uint32_t v = 0;
+        if (off >= 0) {
+            __builtin_memcpy(&v, bs + off, 4);
+        } else if (off > -4) {  // the first bytes of the stream: fewer than four are left
+            for (int k = 0; k < 4 + (int)off; ++k) v |= (uint32_t)bs[k] << (8 * (k - (int)off));
         }
-    }
-    int64_t bpos = 0;  // unread bits of the stream, including those held in registers (lane 0)
-    if (bsn == 0 || bs[bsn - 1] == 0) FAIL();
-    bpos = (int64_t)(bsn - 1) * 8 + hbit(bs[bsn - 1]);
-    uint32_t sl = 0, sm = 0;
+        return v;  // zeros before the start of the stream (bits_left tells real bits from padding)
+    };
+    uint32_t win = load_window();
+    const uint32_t top = lane_get(win, 0) >> 24;  // the last byte carries the end mark
+    if (top == 0) return 0u;
+    const uint32_t hb = (uint32_t)hbit(top);
+    int64_t bits_left = (int64_t)(bsn - 1) * 8 + hb;
+    uint64_t buf = 0;      // unread bits, left aligned
+    uint32_t have = 0, q = 0;
+    auto refill = [&]() {  // afterwards have > 32
+        if (have <= 32) {
+            if (q - k0 == 64) {
+                k0 += 64;
+                win = load_window();
+            }
+            const uint32_t d = lane_get(win, q - k0);
+            ++q;
+            buf |= (uint64_t)d << (32 - have);
+            have += 32;
+        }
+    };
+    auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 32 <= have
+        const uint32_t v = (uint32_t)((buf >> 1) >> (63 - nb));
+        buf <<= nb;
+        have -= nb;
+        bits_left -= nb;
+        return v;
+    };
+    refill();
+    buf <<= 8 - hb;  // padding and end mark
+    have -= 8 - hb;
+    refill();
+    uint32_t sl = take(log_ll);
+    uint32_t sm = take(log_ml);  // the offset state has no bits (RLE table)
     uint64_t sum_ll = 0, sum_all = 0;
-    uint64_t xhi = 0, xlo = 0;  // the next `have` unread bits, left aligned in xhi:xlo
-    uint32_t have = 0;
-    bool first = true;
-    while (ok == 1) {
-        // (re)fill the window so that it ends at the byte holding the lowest bit not yet in registers
-        const int64_t wtop = bpos - have;
-        const uint32_t whi = (uint32_t)((wtop + 7) >> 3) < bsn ? (uint32_t)((wtop + 7) >> 3) : bsn;
-        const uint32_t wlo = whi > WIN ? whi - WIN : 0u;
-        __syncthreads();
-        for (uint32_t j = lane; 4 * j < whi - wlo; j += WAVE) {
-            uint32_t v;
-            __builtin_memcpy(&v, bs + wlo + 4 * j, 4);  // may read 3 bytes past the section (arena slack)
-            win32[j] = v;
+    uint32_t pl = 0, pm = 0;
+    for (uint32_t si = 0; si < nseq; ++si) {
+        const uint32_t elx = lane_get(llt.x, sl), ely = lane_get(llt.y, sl);
+        const uint32_t emx = lane_get(mlt.x, sm), emy = lane_get(mlt.y, sm);
+        refill();
+        const uint32_t mlen = emx + take((emy >> 16) & 0xFF);
+        refill();
+        const uint32_t llen = elx + take((ely >> 16) & 0xFF);
+        if (llen == 0) return 2u;  // repeat-offset semantics change: decode in order
+        const bool mine = (uint32_t)lane == (si & 63);
+        pl = mine ? llen : pl;
+        pm = mine ? mlen : pm;
+        sum_ll += llen;
+        sum_all += (uint64_t)llen + mlen;
+        if (si + 1 < nseq) {
+            refill();
+            sl = (ely & 0xFFFF) + take(ely >> 24);
+            sm = (emy & 0xFFFF) + take(emy >> 24);
         }
-        __syncthreads();
-        if (lane == 0) {
-            bool starved = false;
-            auto topup = [&]() {  // append the 64 bits below the register window (have <= 64)
-                const int64_t top = bpos - have;   // first bit not yet in registers
-                if (top <= 0) return;
-                const int64_t lo = top - 64;
-                const uint32_t lob = lo > 0 ? (uint32_t)lo : 0u;
-                if ((lob >> 3) < wlo) { starved = true; return; }
-                const uint32_t rel = (lob >> 3) - wlo;
-                const uint32_t q = rel >> 2, sh = 8 * (rel & 3) + (lob & 7);
-                const uint64_t d10 = (uint64_t)win32[q] | ((uint64_t)win32[q + 1] << 32);
-                const uint64_t d2 = win32[q + 2];
-                uint64_t nw = sh ? ((d10 >> sh) | (d2 << (64 - sh))) : d10;
-                uint32_t got = 64;
-                if (lo < 0) { nw <<= (uint32_t)(-lo); got = (uint32_t)top; }
-                xhi |= have < 64 ? (nw >> have) : 0ull;
-                xlo |= have ? (nw << (64 - have)) : 0ull;
-                if (have == 0) xlo = 0;
-                have += got;
-            };
-            auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 50, nb <= have checked by the caller
-                const uint32_t v = nb ? (uint32_t)(xhi >> (64 - nb)) : 0u;  // callers take <= 32 bits at once
-                if (nb) {
-                    xhi = (xhi << nb) | (xlo >> (64 - nb));
-                    xlo <<= nb;
-                }
-                have -= nb;
-                bpos -= nb;
-                return v;
-            };
-            if (have <= 64) topup();
-            if (first && !starved) {
-                if ((uint32_t)(log_ll + log_ml) > have) ok = 0;
-                else {
-                    sl = take((uint32_t)log_ll);
-                    sm = take((uint32_t)log_ml);  // the offset state has no bits
-                }
-            }
-            while (ok == 1 && si < nseq && !starved) {
-                if (have <= 64) {
-                    topup();
-                    if (starved) break;
-                }
-                const uint2 el = llt[sl], em = mlt[sm];
-                const uint32_t mnb = (em.y >> 16) & 0xFF, lnb = (el.y >> 16) & 0xFF;
-                const uint32_t snl = si + 1 < nseq ? el.y >> 24 : 0u, snm = si + 1 < nseq ? em.y >> 24 : 0u;
-                if (mnb + lnb + snl + snm > have) { ok = 0; break; }  // reads past the start of the stream
-                const uint32_t mlen = em.x + take(mnb);
-                const uint32_t llen = el.x + take(lnb);
-                if (llen == 0) { ok = 2; break; }  // repeat-offset semantics change: decode in order
-                ws[si] = make_uint2(llen, mlen);
-                sum_ll += llen;
-                sum_all += (uint64_t)llen + mlen;
-                sl = (el.y & 0xFFFF) + take(snl);
-                sm = (em.y & 0xFFFF) + take(snm);
-                ++si;
-            }
-        }
-        first = false;
-        ok = (uint32_t)__shfl((int)ok, 0, 64);
-        si = (uint32_t)__shfl((int)si, 0, 64);
-        have = (uint32_t)__shfl((int)have, 0, 64);
-        bpos = ((int64_t)__shfl((int)(bpos >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)bpos, 0, 64);
-        if (si >= nseq) break;
+        if ((si & 63) == 63) ws[(si & ~63u) + (uint32_t)lane] = make_uint2(pl, pm);
     }
-    if (lane == 0) {
-        if (ok == 1 && bpos != 0) ok = 0;  // every bit must be consumed, none beyond
-        if (ok == 1 && sum_ll > regen) ok = 0;
-        if (ok == 1 && sum_all + (regen - sum_ll) > BLOCK_MAX) ok = 0;
-        total = (uint32_t)(sum_all + (regen - sum_ll));
-    }
-    ok = (uint32_t)__shfl((int)ok, 0, 64);
-    total = (uint32_t)__shfl((int)total, 0, 64);
-    *total_out = total;
-    return ok;
-#undef FAIL
+    if ((uint32_t)lane < (nseq & 63)) ws[(nseq & ~63u) + (uint32_t)lane] = make_uint2(pl, pm);
+    if (bits_left != 0) return 0u;  // every bit must be consumed, none beyond
+    if (sum_ll > regen) return 0u;
+    if (sum_all + (regen - sum_ll) > BLOCK_MAX) return 0u;
+    *total_out = (uint32_t)(sum_all + (regen - sum_ll));
+    return 1u;
 }
 
 __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint32_t n, int lane)
@@ -936,7 +1074,7 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
 template <bool TIMED>
-__global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg)
+__global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs)
 {
     unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
@@ -1099,36 +1237,41 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             }
             __syncthreads();
             if (ltype == 2) {
-                // tree description: at most 129 bytes; lane 0 decodes the weights, the wave fills the table
+                PHASE(0);
+                // tree description: at most 129 bytes; the weights are decoded by wave-uniform code, the wave fills the table
                 const uint32_t tn = csize < 160 ? csize : 160;
-                stage_bytes(L.u.p.hbuf, blk + lh, tn, lane);
-                if (lane == 0) {
-                    int inw = 0, ilog = 0;
-                    const int used = huf_read_weights(L.u.p.hbuf, (int)tn, &inw, &ilog);
-                    L.ctl[C_ERR] = used < 0;
-                    L.ctl[C_F] = (uint32_t)used;
-                    L.ctl[C_G] = (uint32_t)inw;
-                    L.ctl[C_H] = (uint32_t)ilog;
+                int used_tree = huf_read_tree(blk + lh, tn, lane, &nw, &tlog);
+                if (used_tree == -2) {  // unusual description: the byte-serial reader
+                    stage_bytes(L.u.p.hbuf, blk + lh, tn, lane);
+                    if (lane == 0) {
+                        int inw = 0, ilog = 0;
+                        const int used = huf_read_weights(L.u.p.hbuf, (int)tn, &inw, &ilog);
+                        L.ctl[C_F] = (uint32_t)used;
+                        L.ctl[C_G] = (uint32_t)inw;
+                        L.ctl[C_H] = (uint32_t)ilog;
+                    }
+                    __syncthreads();
+                    used_tree = (int)L.ctl[C_F];
+                    nw = L.ctl[C_G];
+                    tlog = L.ctl[C_H];
                 }
-                __syncthreads();
-                if (L.ctl[C_ERR]) FAIL();
-                tree_used = L.ctl[C_F];
-                nw = L.ctl[C_G];
-                tlog = L.ctl[C_H];
+                if (used_tree < 0) FAIL();
+                tree_used = (uint32_t)used_tree;
                 // new Huffman table: pick the slot not used by the current table; pending tasks that
                 // still reference the slot we are about to overwrite must run first
                 int slot = huf_valid ? 1 - cur_slot : 0;
                 bool clash = (tlog == 12) || (huf_valid && cur_log == 12);
                 for (uint32_t t = 0; t < ntask && !clash; ++t)
-                    clash = ((L.t_tab[t] & 0xFFFF) == (uint32_t)slot * 2048u);
+                    clash = ((L.t_tab[t] & 0xFFFF) == (uint32_t)slot * (uint32_t)HUF_SLOT);
                 if (clash && ntask) {
                     FLUSH();
                 }
                 if (tlog == 12) slot = 0;
-                huf_fill_table(&L.huf[0][0] + slot * 2048, nw, tlog, lane);
+                huf_fill_table(&L.huf[0][0] + slot * HUF_SLOT, nw, tlog, lane);
                 huf_valid = true;
                 cur_slot = slot;
                 cur_log = (int)tlog;
+                PHASE(5);
             }
             // ---- sequences section header (3.1.1.3.2.1)
             const uint32_t lit_end = lh + csize;  // offset of the sequences section in the block
@@ -1147,8 +1290,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             // how zstd_encode.hip codes zero runs) is not executed in order: lane 0 only walks its FSE states now,
             // its literal streams join the task queue (staged behind the frame in the slack of the destination
             // slot), and the runs are placed in parallel after the next flush.
-            bool defer = false;
-            uint32_t ws_lit = 0, ws_pairs = 0;
+            bool defer = false, fast_tabs = false;
+            uint32_t ws_lit = 0, ws_pairs = 0, ns_fast = 0, used_fast = 0;
             if (has_seq && attempt == 0) {
                 if (d_active) FLUSH();
                 uint32_t go = 0;
@@ -1163,9 +1306,15 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         ws_pairs = ws_lit + (ltype >= 2 ? ((regen + 7u) & ~7u) : 0u);
                         go = (ofm == 1 && llm != 2 && ofsym_at < sqn && sq[ofsym_at] == 0 && rep0 == 1 &&
                               (uint64_t)ws_pairs + 8ull * ns0 + 8 <= cap) ? 1u : 0u;
+                        // predefined LL and ML tables (what zstd_encode.hip writes): nothing to build
+                        if (go && modes == 0x10u && dtabs != nullptr) go = 2u | (used0 << 2) | (ns0 << 4);
                     }
                 }
-                defer = __shfl((int)go, 0, 64) != 0;
+                go = (uint32_t)__shfl((int)go, 0, 64);
+                defer = go != 0;
+                fast_tabs = (go & 2u) != 0;
+                ns_fast = go >> 4;
+                used_fast = (go >> 2) & 3u;
                 ws_lit = (uint32_t)__shfl((int)ws_lit, 0, 64);
                 ws_pairs = (uint32_t)__shfl((int)ws_pairs, 0, 64);
             }
@@ -1177,7 +1326,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 if (ntask + streams > WAVE) {
                     FLUSH();
                 }
-                const uint32_t tabref = (uint32_t)cur_slot * 2048u | ((uint32_t)cur_log << 16);
+                const uint32_t tabref = (uint32_t)cur_slot * (uint32_t)HUF_SLOT | ((uint32_t)cur_log << 16);
                 if (streams == 1) {
                     if (lane == 0) {
                         L.t_src[ntask] = (uint32_t)(q - src);
@@ -1225,59 +1374,91 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 opos += regen;
             } else if (defer) {
                 PHASE(0);
-                // tables of this block (the union LDS is free: queued tasks are only descriptors)
-                stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
-                if (lane == 0) {
-                    uint32_t err = 0, used = 1, ns = nseq;
-                    const bool lost = tables_lost;
-                    const uint8_t* h = L.u.p.hbuf;
-                    const int hn = (int)(sqn < HBUF ? sqn : HBUF);
-                    if (ns >= 128) {
-                        if (ns == 255) {
-                            if (hn < 3) err = 1; else { ns = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
-                        } else {
-                            if (hn < 2) err = 1; else { ns = ((ns - 128) << 8) + h[1]; used = 2; }
+                uint2 llt = make_uint2(0, 0), mlt = make_uint2(0, 0);
+                uint32_t lgl = 6, lgm = 6;
+                if (fast_tabs) {
+                    nseq = ns_fast;
+                    sq_used = used_fast + 2u;  // count, modes byte, RLE symbol of the OF table
+                    if (sq_used >= sqn) FAIL();
+                    llt = dtabs->ll[lane];
+                    mlt = dtabs->ml[lane];
+                    tables_lost = true;  // nothing was built in LDS: a later Repeat_Mode block restarts the frame
+                } else {
+                    // tables of this block (the union LDS is free: queued tasks are only descriptors)
+                    stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
+                    if (lane == 0) {
+                        uint32_t err = 0, used = 1, ns = nseq;
+                        const bool lost = tables_lost;
+                        const uint8_t* h = L.u.p.hbuf;
+                        const int hn = (int)(sqn < HBUF ? sqn : HBUF);
+                        if (ns >= 128) {
+                            if (ns == 255) {
+                                if (hn < 3) err = 1; else { ns = h[1] + ((uint32_t)h[2] << 8) + 0x7F00; used = 3; }
+                            } else {
+                                if (hn < 2) err = 1; else { ns = ((ns - 128) << 8) + h[1]; used = 2; }
+                            }
                         }
+                        if (!err && (int)used >= hn) err = 1;
+                        if (!err) {
+                            const uint32_t modes = h[used++];
+                            if (modes & 3) err = 1;
+                            // a repeated table that a ring flush has overwritten: decode the frame again, carefully
+                            if (!err && lost && (((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3)) err = 3;
+                            int u;
+                            if (!err) {
+                                u = seq_table(L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
+                                if (u < 0) err = 1; else used += (uint32_t)u;
+                            }
+                            if (!err) {
+                                u = seq_table(L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
+                                if (u < 0) err = 1; else used += (uint32_t)u;
+                            }
+                            if (!err) {
+                                u = seq_table(L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
+                                if (u < 0) err = 1; else used += (uint32_t)u;
+                            }
+                            if (!err && used >= sqn) err = 1;
+                        }
+                        L.ctl[C_ERR] = err;
+                        L.ctl[C_I] = ns;
+                        L.ctl[C_J] = used;
                     }
-                    if (!err && (int)used >= hn) err = 1;
-                    if (!err) {
-                        const uint32_t modes = h[used++];
-                        if (modes & 3) err = 1;
-                        // a repeated table that a ring flush has overwritten: decode the frame again, carefully
-                        if (!err && lost && (((modes >> 6) & 3) == 3 || ((modes >> 4) & 3) == 3 || ((modes >> 2) & 3) == 3)) err = 3;
-                        int u;
-                        if (!err) {
-                            u = seq_table(L.u.p.fse[0], &log_ll, &have_ll, (modes >> 6) & 3, h + used, hn - (int)used, LL_DEFAULT, 36, 6, 35, 9);
-                            if (u < 0) err = 1; else used += (uint32_t)u;
-                        }
-                        if (!err) {
-                            u = seq_table(L.u.p.fse[1], &log_of, &have_of, (modes >> 4) & 3, h + used, hn - (int)used, OF_DEFAULT, 29, 5, 31, 8);
-                            if (u < 0) err = 1; else used += (uint32_t)u;
-                        }
-                        if (!err) {
-                            u = seq_table(L.u.p.fse[2], &log_ml, &have_ml, (modes >> 2) & 3, h + used, hn - (int)used, ML_DEFAULT, 53, 6, 52, 9);
-                            if (u < 0) err = 1; else used += (uint32_t)u;
-                        }
-                        if (!err && used >= sqn) err = 1;
+                    __syncthreads();
+                    if (L.ctl[C_ERR] == 3) {
+                        restart = true;
+                        break;
                     }
-                    L.ctl[C_ERR] = err;
-                    L.ctl[C_I] = ns;
-                    L.ctl[C_J] = used;
+                    if (L.ctl[C_ERR]) FAIL();
+                    nseq = L.ctl[C_I];
+                    sq_used = L.ctl[C_J];
+                    tables_built = true;
+                    // compact per-lane tables; eligibility: accuracy logs <= 6, OF = RLE of code 0, valid codes
+                    uint32_t bad = 0;
+                    if (lane == 0) bad = (log_ll > 6 || log_ml > 6 || log_of != 0 || (L.u.p.fse[1][0] & 0xFF) != 0) ? 1u : 0u;
+                    if (__shfl((int)bad, 0, 64)) {
+                        restart = true;
+                        break;
+                    }
+                    lgl = (uint32_t)__shfl(log_ll, 0, 64);
+                    lgm = (uint32_t)__shfl(log_ml, 0, 64);
+                    uint32_t e1 = 0, e2 = 0;
+                    if (lane < (1 << lgl)) {
+                        const uint32_t e = L.u.p.fse[0][lane], c = e & 0xFF;
+                        if (c > 35) e1 = 1;
+                        else llt = make_uint2(LL_BASE[c], (e >> 16) | ((uint32_t)LL_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
+                    }
+                    if (lane < (1 << lgm)) {
+                        const uint32_t e = L.u.p.fse[2][lane], c = e & 0xFF;
+                        if (c > 52) e2 = 1;
+                        else mlt = make_uint2(ML_BASE[c], (e >> 16) | ((uint32_t)ML_BITS[c] << 16) | (((e >> 8) & 0xFF) << 24));
+                    }
+                    if (__any(e1 | e2)) FAIL();
                 }
-                __syncthreads();
-                if (L.ctl[C_ERR] == 3) {
-                    restart = true;
-                    break;
-                }
-                if (L.ctl[C_ERR]) FAIL();
-                nseq = L.ctl[C_I];
-                sq_used = L.ctl[C_J];
-                tables_built = true;
                 {
                     PHASE(2);
                     uint32_t total = 0;
                     const uint32_t ok = zero_run_chain(sq + sq_used, sqn - sq_used, reinterpret_cast<uint2*>(dst + ws_pairs), nseq,
-                                                       log_ll, log_of, log_ml, regen, lane, &total);
+                                                       llt, mlt, lgl, lgm, regen, lane, &total);
                     PHASE(3);
                     if (ok == 0) FAIL();
                     if (ok == 2) {  // not a pure zero-run block after all: decode the frame again, in order
@@ -1483,14 +1664,67 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
 
 }  // namespace
 
-hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, hipStream_t s)
+hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, const void* seq_dtables,
+                              hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     if (dbg)
-        hipLaunchKernelGGL(zstd_decode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg);
+        hipLaunchKernelGGL(zstd_decode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
+                           reinterpret_cast<const SeqDTables*>(seq_dtables));
     else
-        hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg);
+        hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
+                           reinterpret_cast<const SeqDTables*>(seq_dtables));
     return hipGetLastError();
+}
+
+// host: decoding tables of the predefined LL / ML distributions (RFC 8878 3.1.1.3.2.2), built the way
+// fse_build builds them on the device, in the compact form of SeqDTables (uploaded once per context)
+size_t seq_dtables_bytes() { return sizeof(SeqDTables); }
+
+void seq_dtables_build(void* host_buffer)
+{
+    static const int16_t ll_norm[36] = { 4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1 };
+    static const int16_t ml_norm[53] = { 1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                         1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1 };
+    static const uint32_t ll_base[36] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64,
+                                          128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536 };
+    static const uint8_t ll_bits[36] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
+    static const uint32_t ml_base[53] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28,
+                                          29, 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051,
+                                          4099, 8195, 16387, 32771, 65539 };
+    static const uint8_t ml_bits[53] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                         1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
+    SeqDTables* t = static_cast<SeqDTables*>(host_buffer);
+    auto build = [](uint2* out, const int16_t* norm, int nsym, const uint32_t* base, const uint8_t* bits) {
+        const int log = 6, size = 1 << log, mask = size - 1;
+        int sym[64], next[64], high = size - 1;
+        for (int s = 0; s < nsym; ++s) {
+            if (norm[s] == -1) {
+                sym[high--] = s;
+                next[s] = 1;
+            } else {
+                next[s] = norm[s];
+            }
+        }
+        const int step = (size >> 1) + (size >> 3) + 3;
+        int pos = 0;
+        for (int s = 0; s < nsym; ++s)
+            for (int i = 0; i < norm[s]; ++i) {
+                sym[pos] = s;
+                pos = (pos + step) & mask;
+                while (pos > high) pos = (pos + step) & mask;
+            }
+        for (int u = 0; u < size; ++u) {
+            const int s = sym[u], ns = next[s]++;
+            int hb = 0;
+            while ((2 << hb) <= ns) ++hb;
+            const int nb = log - hb;
+            const uint32_t nbase = (uint32_t)((ns << nb) - size);
+            out[u] = make_uint2(base[s], nbase | ((uint32_t)bits[s] << 16) | ((uint32_t)nb << 24));
+        }
+    };
+    build(t->ll, ll_norm, 36, ll_base, ll_bits);
+    build(t->ml, ml_norm, 53, ml_base, ml_bits);
 }
 
 }  // namespace vbzhip

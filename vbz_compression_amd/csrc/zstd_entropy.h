@@ -24,7 +24,10 @@
 
 namespace vbzhip {
 
-constexpr int HUF_MAX_BITS = 11;      // zstd's HUF_TABLELOG_DEFAULT: literal codes are at most 11 bits
+#ifndef VBZ_HUF_MAX_BITS
+#define VBZ_HUF_MAX_BITS 11
+#endif
+constexpr int HUF_MAX_BITS = VBZ_HUF_MAX_BITS;      // zstd's HUF_TABLELOG_DEFAULT: literal codes are at most 11 bits
 constexpr int HUF_ABS_MAX_BITS = 12;  // HUF_TABLELOG_MAX
 constexpr uint32_t HUF_NO_SYMBOL = 0xF0F0F0F0u;
 
