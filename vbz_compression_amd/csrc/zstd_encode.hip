@@ -48,20 +48,31 @@ struct EncLds
     uint32_t ctable[256];  // code | nbBits << 16
     uint8_t nbBits[256];
     uint16_t code[256];
-    HufBuildWksp hw;
-    FseWeightWksp fw;
     uint8_t weights[260];
     uint8_t tree[136];
     int32_t treeSize;
     uint32_t mode;      // 0 raw, 1 rle, 2 huffman
     uint32_t huffLog;
     uint32_t rankcnt[16];   // symbols per code length
-    uint32_t ssize[WAVE];   // compressed bytes of each stream of the current pass
-    uint32_t sbeg[WAVE];    // first byte (region offset) of each stream of the current pass
-    uint32_t scnt[WAVE];    // symbols in each stream
-    uint32_t sbits[WAVE];   // sum of code lengths of each stream
-    uint32_t sout[WAVE];    // output offset of each stream
-    uint32_t obuf[OBUF_WORDS]; // bit buffer of the stream being packed
+    // A region is planned (table construction) before anything of it is sized or packed, and the next region is
+    // planned only after this one is written: the two workspaces share their LDS (16 waves per CU instead of 13).
+    union
+    {
+        struct
+        {
+            HufBuildWksp hw;
+            FseWeightWksp fw;
+        };
+        struct
+        {
+            uint32_t ssize[WAVE];   // compressed bytes of each stream of the current pass
+            uint32_t sbeg[WAVE];    // first byte (region offset) of each stream of the current pass
+            uint32_t scnt[WAVE];    // symbols in each stream
+            uint32_t sbits[WAVE];   // sum of code lengths of each stream
+            uint32_t sout[WAVE];    // output offset of each stream
+            uint32_t obuf[OBUF_WORDS]; // bit buffer of the stream being packed
+        };
+    };
     uint32_t bopos[MAXBLK]; // output offset of each block of the current pass
     uint32_t passBytes;
     uint32_t seqOff, seqBytes;  // zero-run sequences block: where its sequences section starts / its size
