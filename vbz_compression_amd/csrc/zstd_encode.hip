@@ -68,14 +68,9 @@ struct EncLds
             uint32_t ssize[WAVE];   // compressed bytes of each stream of the current pass
             uint32_t sbeg[WAVE];    // first byte (region offset) of each stream of the current pass
             uint32_t scnt[WAVE];    // symbols in each stream
-            uint32_t sbits[WAVE];   // sum of code lengths of each stream
-            uint32_t sout[WAVE];    // output offset of each stream
             uint32_t obuf[OBUF_WORDS]; // bit buffer of the stream being packed
         };
     };
-    uint32_t bopos[MAXBLK]; // output offset of each block of the current pass
-    uint32_t passBytes;
-    uint32_t seqOff, seqBytes;  // zero-run sequences block: where its sequences section starts / its size
     SeqCTables seq;             // encoding tables of the predefined LL / ML distributions
 };
 
@@ -743,124 +738,17 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             // empty streams (single-stream blocks, lanes past the last block) sit at the end of their block
             L.sbeg[lane] = active ? (cnt ? boff + (uint32_t)q * seg : boff + bs) : pbe;
             L.scnt[lane] = cnt;
-            L.sbits[lane] = 0;
+            L.ssize[lane] = 0;
             wave_lds_sync();
-            // --- size sweep: the wave reads the pass's bytes once, coalesced, and sums the code lengths
-            // of every stream (a lane keeps a running sum while it stays inside one stream)
-            {
-                uint32_t sid = 0, acc = 0;
-                uint32_t cur_end = L.sbeg[0] + L.scnt[0];
-                for (uint32_t pos0 = pb0; pos0 < pbe; pos0 += 4 * WAVE * 16) {
-                    uint4 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {  // four independent 16-byte loads in flight per lane
-                        const uint32_t pos = pos0 + (uint32_t)u * WAVE * 16 + (uint32_t)lane * 16;
-                        v[u] = make_uint4(0u, 0u, 0u, 0u);
-                        if (pos < pbe) __builtin_memcpy(&v[u], rin + pos, 16);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t pos = pos0 + (uint32_t)u * WAVE * 16 + (uint32_t)lane * 16;
-                        if (pos >= pbe) continue;
-                        const uint32_t w[4] = { v[u].x, v[u].y, v[u].z, v[u].w };
-                        // advance to the stream that holds `pos` (streams are contiguous and ordered)
-                        while (pos >= cur_end && sid < WAVE - 1) {
-                            if (acc) atomicAdd(&L.sbits[sid], acc);
-                            acc = 0;
-                            ++sid;
-                            cur_end = L.sbeg[sid] + L.scnt[sid];
-                        }
-                        if (pos + 16 <= cur_end) {
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) {
-                                const uint32_t pk = pos + (uint32_t)k;
-                                if (pk < pbe) {
-                                    while (pk >= cur_end && sid < WAVE - 1) {
-                                        if (acc) atomicAdd(&L.sbits[sid], acc);
-                                        acc = 0;
-                                        ++sid;
-                                        cur_end = L.sbeg[sid] + L.scnt[sid];
-                                    }
-                                    acc += L.nbBits[(w[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                                }
-                            }
-                        }
-                    }
-                }
-                if (acc) atomicAdd(&L.sbits[sid], acc);
-            }
-            wave_lds_sync();
+            (void)pb0;
             PHASE(3);
-            const uint32_t sbytes = (active && cnt) ? (L.sbits[lane] >> 3) + 1 : 0;
-            L.ssize[lane] = sbytes;
-            wave_lds_sync();
-            // --- the zero-run block carries a sequences section behind its literals: encode it first
-            uint32_t seqBytes = 1;  // a plain block ends with Number_of_Sequences = 0
-            if (seqmode) {
-                if (lane == 0) {
-                    const uint32_t lit = treeSize + (S < 256 ? 0 : 6) + L.ssize[0] + L.ssize[1] + L.ssize[2] + L.ssize[3];
-                    const uint32_t big = S > lit ? S : lit;
-                    L.seqOff = opos + 3 + (3 + (big >= 1024) + (big >= 16384)) + lit;
-                }
-                wave_lds_sync();
-                NEED((uint64_t)(L.seqOff - opos) + 8 + 8ull * nrec);
-                seqBytes = encode_zero_run_sequences(L, out + L.seqOff, rec, nrec, lane);
-            }
-            // --- block layout (lane 0), then headers (first lane of each block)
-            if (lane == 0) {
-                uint32_t o = opos;
-                for (uint32_t j = 0; j < nb; ++j) {
-                    L.bopos[j] = o;
-                    const uint32_t jb = b0 + j;
-                    const uint32_t jbs = base + (jb < extra ? 1u : 0u);
-                    const uint32_t lit = (jb == 0 ? treeSize : 0) + (jbs < 256 ? 0 : 6) + L.ssize[4 * j] + L.ssize[4 * j + 1] +
-                                         L.ssize[4 * j + 2] + L.ssize[4 * j + 3];
-                    const uint32_t big = jbs > lit ? jbs : lit;
-                    const uint32_t lh = 3 + (big >= 1024) + (big >= 16384);
-                    o += 3 + lh + lit + seqBytes;
-                }
-                L.passBytes = o - opos;
-            }
-            wave_lds_sync();
-            const uint32_t passBytes = L.passBytes;
-            NEED(passBytes);
-            if (active) {
-                const uint32_t j = (uint32_t)(lane >> 2);
-                const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
-                const uint32_t tsz = bj == 0 ? treeSize : 0;
-                const uint32_t lit = tsz + (single ? 0 : 6) + s0 + s1 + s2 + s3;
-                const uint32_t big = bs > lit ? bs : lit;
-                const uint32_t lh = 3 + (big >= 1024) + (big >= 16384);
-                uint8_t* bp = out + L.bopos[j];
-                if (q == 0) {
-                    const uint32_t last = (lastRegion && bj + 1 == nblk) ? 1u : 0u;
-                    put_le(bp, ((lh + lit + seqBytes) << 3) | (2u << 1) | last, 3);
-                    const uint64_t type = bj == 0 ? 2 : 3;  // Compressed_Literals_Block / Treeless
-                    if (lh == 3) put_le(bp + 3, type | ((single ? 0ull : 1ull) << 2) | ((uint64_t)bs << 4) | ((uint64_t)lit << 14), 3);
-                    else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)bs << 4) | ((uint64_t)lit << 18), 4);
-                    else put_le(bp + 3, type | (3ull << 2) | ((uint64_t)bs << 4) | ((uint64_t)lit << 22), 5);
-                    uint8_t* tp = bp + 3 + lh;
-                    for (uint32_t i = 0; i < tsz; ++i) tp[i] = L.tree[i];
-                    if (!single) {
-                        put_le(tp + tsz, s0, 2);
-                        put_le(tp + tsz + 2, s1, 2);
-                        put_le(tp + tsz + 4, s2, 2);
-                    }
-                    if (!seqmode) bp[3 + lh + lit] = 0;  // Number_of_Sequences = 0
-                }
-                // where this lane's stream starts in the output (offset from `out`)
-                L.sout[lane] = L.bopos[j] + 3 + lh + tsz + (single ? 0 : 6) + (q > 0 ? s0 : 0) + (q > 1 ? s1 : 0) + (q > 2 ? s2 : 0);
-            }
-            wave_lds_sync();
-            PHASE(4);
-            // --- encode: the wave packs one stream at a time, 1024 symbols per step, from the end of the
-            // stream to its start (RFC 8878 4.2.2: the last symbol is written first).  Lane l takes the 16
-            // symbols that end 16*l before the step's end; a wave prefix sum of the lanes' bit counts gives
-            // every lane its bit offset; the bits are OR-ed into an LDS buffer that is written out as
-            // coalesced dwords.
+            // --- encode: the wave packs one stream at a time, in frame order, STEP_SYMS symbols per step, from
+            // the end of the stream to its start (RFC 8878 4.2.2: the last symbol is written first).  Lane l takes
+            // the STEP_LANE symbols that end STEP_LANE*l before the step's end; a wave prefix sum of the lanes'
+            // bit counts gives every lane its bit offset; the bits are OR-ed into an LDS buffer that is written
+            // out as coalesced dwords.  Nothing is sized in advance: a stream starts where the previous one
+            // ended, and a block's headers (whose length only depends on its uncompressed size) are filled in
+            // when its last stream is done.
             {
                 for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;
                 wave_lds_sync();
@@ -894,13 +782,32 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         }
                     }
                 };
+                // block geometry (wave-uniform): header length from the block's uncompressed size alone
+                auto blk_bs = [&](uint32_t j) { return base + ((b0 + j) < extra ? 1u : 0u); };
+                auto blk_lh = [&](uint32_t j) {
+                    const uint32_t jbs = blk_bs(j);
+                    const uint32_t worst = ((b0 + j) == 0 ? treeSize : 0u) + 6u + ((jbs * 11u + 7u) >> 3) + 4u;  // every code <= 11 bits
+                    const uint32_t big = jbs > worst ? jbs : worst;
+                    return 3u + (big >= 1024u ? 1u : 0u) + (big >= 16384u ? 1u : 0u);
+                };
+                uint32_t ocur = opos;        // where the current block starts
+                uint32_t spos = 0;           // where the current stream starts
+                uint32_t curblk = 0xFFFFFFFFu;
                 if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
                 uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
                 uint32_t flushed = 0;     // bytes of the stream already written to memory
                 while (st < 4 * nb) {
+                    if ((st >> 2) != curblk) {  // first stream of a block: reserve its headers, place the tree
+                        curblk = st >> 2;
+                        const uint32_t tsz = (b0 + curblk) == 0 ? treeSize : 0u;
+                        const uint32_t hl = 3u + blk_lh(curblk) + tsz + (blk_bs(curblk) < 256u ? 0u : 6u);
+                        if ((uint64_t)ocur + hl > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
+                        for (uint32_t i = lane; i < tsz; i += WAVE) out[ocur + 3u + blk_lh(curblk) + i] = L.tree[i];
+                        spos = ocur + hl;
+                    }
                     const uint32_t scnt = L.scnt[st];
                     const uint32_t sb = L.sbeg[st];
-                    uint8_t* sop = out + L.sout[st];
+                    uint8_t* sop = out + spos;
                     // next work item
                     uint32_t nst = st, ndone = done + STEP_SYMS;
                     if (ndone >= scnt) {
@@ -924,6 +831,9 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     }
                     const uint32_t incl = wave_incl_scan_u32(T);
                     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+                    const uint32_t allbits = base_bits + total;
+                    const uint32_t full = allbits >> 5;
+                    if ((uint64_t)spos + flushed + 4ull * full + 8 > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
                     const uint32_t pos = base_bits + incl - T;
                     uint32_t word = pos >> 5;
                     uint32_t accbits = pos & 31;
@@ -945,8 +855,6 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     }
                     if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
                     wave_lds_sync();
-                    const uint32_t allbits = base_bits + total;
-                    const uint32_t full = allbits >> 5;
                     for (uint32_t i = lane; i < full; i += WAVE) {
                         const uint32_t v = L.obuf[i];
                         __builtin_memcpy(sop + flushed + 4 * i, &v, 4);
@@ -959,13 +867,51 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     wave_lds_sync();
                     if (nst != st) {
                         // stream finished: end mark and the last partial word
+                        const uint32_t nbytes = (base_bits + 1 + 7) >> 3;
                         if (lane == 0) {
                             const uint32_t v = carry | (1u << base_bits);
-                            const uint32_t nbytes = (base_bits + 1 + 7) >> 3;
                             for (uint32_t k = 0; k < nbytes; ++k) sop[flushed + k] = (uint8_t)(v >> (8 * k));
+                            L.ssize[st] = flushed + nbytes;
                         }
+                        spos += flushed + nbytes;
                         base_bits = 0;
                         flushed = 0;
+                        if ((nst >> 2) != curblk) {
+                            // block finished: sequences section (or its one-byte stand-in), then the headers
+                            wave_lds_sync();
+                            uint32_t seqBytes = 1;  // a plain block ends with Number_of_Sequences = 0
+                            if (seqmode) {
+                                if ((uint64_t)spos + 8 + 8ull * nrec > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
+                                seqBytes = encode_zero_run_sequences(L, out + spos, rec, nrec, lane);
+                                wave_lds_sync();
+                                for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;  // it used the bit buffer
+                                wave_lds_sync();
+                            } else {
+                                if ((uint64_t)spos + 1 > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
+                                if (lane == 0) out[spos] = 0;
+                            }
+                            if (lane == 0) {
+                                const uint32_t j = curblk, jb = b0 + j, jbs = blk_bs(j);
+                                const bool jsingle = jbs < 256u;
+                                const uint32_t lh = blk_lh(j), tsz = jb == 0 ? treeSize : 0u;
+                                const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
+                                const uint32_t lit = tsz + (jsingle ? 0u : 6u) + s0 + s1 + s2 + s3;
+                                uint8_t* bp = out + ocur;
+                                const uint32_t last = (lastRegion && jb + 1 == nblk) ? 1u : 0u;
+                                put_le(bp, ((lh + lit + seqBytes) << 3) | (2u << 1) | last, 3);
+                                const uint64_t type = jb == 0 ? 2 : 3;  // Compressed_Literals_Block / Treeless
+                                if (lh == 3) put_le(bp + 3, type | ((jsingle ? 0ull : 1ull) << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 14), 3);
+                                else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 18), 4);
+                                else put_le(bp + 3, type | (3ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 22), 5);
+                                if (!jsingle) {
+                                    uint8_t* tp = bp + 3 + lh + tsz;
+                                    put_le(tp, s0, 2);
+                                    put_le(tp + 2, s1, 2);
+                                    put_le(tp + 4, s2, 2);
+                                }
+                            }
+                            ocur = spos + seqBytes;
+                        }
                     } else {
                         if (lane == 0) L.obuf[0] = carry;
                         wave_lds_sync();
@@ -975,8 +921,8 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     st = nst;
                     done = ndone;
                 }
+                opos = ocur;
             }
-            opos += passBytes;
             wave_lds_sync();
             PHASE(5);
         }
