@@ -210,7 +210,7 @@ def test_zstd_ratio_close_to_libzstd_on_signal():
     frames = G.compress(reads, opts)
     gpu = sum(len(f) for f in frames)
     ref = sum(len(O.compress(a, O.options(True, 2, 1, 1))) for a in reads)
-    assert abs(gpu / ref - 1.0) < 0.02, (gpu, ref)
+    assert abs(gpu / ref - 1.0) < 0.01, (gpu, ref)  # ratio within 1 % of the reference
 
 
 def test_zstd_decode_rejects_corruption():
@@ -490,4 +490,5 @@ def test_hdf5_filter_32020_calling_convention():
         assert svb_mine.tobytes() == svb_ref.tobytes()
         total_ref += len(chunk)
         total_gpu += len(mine)
-    assert abs(total_gpu / total_ref - 1.0) < 0.03, (total_gpu, total_ref)
+    print("real reads: gpu %d B, reference %d B" % (total_gpu, total_ref))
+    assert abs(total_gpu / total_ref - 1.0) < 0.01, (total_gpu, total_ref)
