@@ -835,12 +835,23 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
     }
     fetch_batch(p, nextbyte, pend);
 
-    // two symbols from 32 fresh bits
+    // two symbols from 32 fresh bits.  The two ring dwords that hold them are kept in registers (w0 = D[k],
+    // w1 = D[k+1]) with the next one (w2 = D[k+2]) requested a pair ahead: a pair consumes at most 22 bits, so k
+    // advances by at most one and the ring read is off the dependent chain (two LDS round trips per pair, not three).
+    int32_t tprev = n >> 5;
+    uint32_t w0 = ring[((((uint32_t)tprev) & (uint32_t)(RING - 1)) + 1u) * WAVE];
+    uint32_t w1 = ring[(((uint32_t)tprev) & (uint32_t)(RING - 1)) * WAVE];
+    uint32_t w2 = ring[(((uint32_t)tprev - 1u) & (uint32_t)(RING - 1)) * WAVE];
 #define HUF_PAIR(e1, e2)                                                               \
     do {                                                                               \
-        const uint32_t slot__ = ((uint32_t)n >> 5) & (uint32_t)(RING - 1);             \
-        const uint32_t d1__ = ring[slot__ * WAVE], d0__ = ring[(slot__ + 1) * WAVE];   \
-        uint32_t x__ = __builtin_amdgcn_alignbit(d0__, d1__, (uint32_t)n);             \
+        const int32_t t__ = n >> 5;                                                    \
+        const bool adv__ = t__ != tprev;                                               \
+        const uint32_t a__ = adv__ ? w1 : w0, b__ = adv__ ? w2 : w1;                   \
+        w0 = a__;                                                                      \
+        w1 = b__;                                                                      \
+        tprev = t__;                                                                   \
+        w2 = ring[(((uint32_t)t__ - 1u) & (uint32_t)(RING - 1)) * WAVE];               \
+        uint32_t x__ = __builtin_amdgcn_alignbit(a__, b__, (uint32_t)n);               \
         e1 = T[x__ >> sL];                                                             \
         x__ <<= (e1 >> 8);                                                             \
         e2 = T[x__ >> sL];                                                             \
