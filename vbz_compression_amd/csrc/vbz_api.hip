@@ -168,11 +168,11 @@ void dbg_end(vbz_gpu_ctx* c, uint32_t n, const char* what, unsigned long long* d
     std::vector<unsigned long long> h((size_t)n * 8);
     hipStreamSynchronize(c->stream);
     hipMemcpy(h.data(), d, (size_t)n * 64, hipMemcpyDeviceToHost);
-    double sum[6] = { 0, 0, 0, 0, 0, 0 };
+    double sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     for (uint32_t i = 0; i < n; ++i)
-        for (int k = 0; k < 6; ++k) sum[k] += (double)h[(size_t)i * 8 + k];
+        for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)i * 8 + k];
     fprintf(stderr, "vbz_hip phase cycles/read (%s, n=%u):", what, n);
-    for (int k = 0; k < 6; ++k) fprintf(stderr, " p%d=%.0f", k, sum[k] / n);
+    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.0f", k, sum[k] / n);
     fprintf(stderr, "\n");
 }
 
@@ -362,7 +362,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         // decode it and then fail in the svb stage with a stream error
         HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, c->seqdtab.p, s), "zstd_decode launch");
     }
-    dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable", dbg);
+    dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable header queue", dbg);
     ReadBatch d = rb;
     d.src = (const uint8_t*)c->scratch.p;
     d.src_off = svb_off;

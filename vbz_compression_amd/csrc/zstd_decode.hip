@@ -1073,6 +1073,110 @@ __device__ __noinline__ uint32_t zero_run_chain(const uint8_t* bs_, uint32_t bsn
     return 1u;
 }
 
+// all lanes.  The same walk as zero_run_chain, split at the encoder's checkpoints (zstd_encode.hip, CP_MAGIC): lane
+// j decodes sequences [j * spacing, (j + 1) * spacing) from (unread bits, LL state, ML state) = checkpoint j - 1
+// (lane 0: from the top of the stream).  The bit stream is staged in LDS (the ring's area, idle while headers are
+// parsed), table entries come from the lanes that hold them (ds_bpermute).  The result is accepted only if every
+// segment ends exactly where the next one started and the last one consumes the stream: then it is the serial
+// walk.  Returns 1 = pairs written, 2 = not a pure zero-run block, 3 = checkpoints unusable (walk serially).
+__device__ __noinline__ uint32_t zero_run_chain_segments(const uint8_t* bs, uint32_t bsn, uint2* ws, uint32_t nseq, uint2 llt, uint2 mlt,
+                                                         uint32_t regen, const uint8_t* cp, uint32_t ncp, uint32_t spacing, int lane,
+                                                         uint32_t* total_out)
+{
+    constexpr uint32_t CAP = (uint32_t)sizeof(L.u.inbuf) - 16u;
+    if (bsn == 0 || bsn > CAP || ncp + 1 > (uint32_t)WAVE || spacing == 0) return 3u;
+    if ((uint64_t)(ncp + 1) * spacing < nseq || (uint64_t)ncp * spacing >= nseq) return 3u;
+    uint32_t* lds = &L.u.inbuf[0][0];
+    __syncthreads();
+    for (uint32_t i = lane; 4 * i < bsn + 8; i += WAVE) {
+        uint32_t v = 0;
+        if (4 * i + 4 <= bsn) __builtin_memcpy(&v, bs + 4 * i, 4);
+        else for (uint32_t k = 0; 4 * i + k < bsn && k < 4; ++k) v |= (uint32_t)bs[4 * i + k] << (8 * k);
+        lds[i] = v;
+    }
+    __syncthreads();
+    auto extract = [&](uint32_t pos, uint32_t nb) -> uint32_t {  // bits [pos, pos + nb) of the stream, nb <= 32
+        const uint32_t d0 = lds[pos >> 5], d1 = lds[(pos >> 5) + 1];
+        const uint32_t x = __builtin_amdgcn_alignbit(d1, d0, pos & 31);
+        return nb >= 32 ? x : (x & ((1u << nb) - 1u));
+    };
+    const uint32_t nseg = ncp + 1;
+    const bool active = (uint32_t)lane < nseg;
+    uint32_t P = 0, sl = 0, sm = 0, bad = 0, impure = 0;
+    if (lane == 0) {
+        const uint32_t top = lds[(bsn - 1) >> 2] >> (8 * ((bsn - 1) & 3)) & 0xFF;
+        if (top == 0) bad = 1;
+        else {
+            P = (bsn - 1) * 8 + (uint32_t)hbit(top);
+            if (P < 12) bad = 1;
+            else {
+                sl = extract(P - 6, 6);
+                sm = extract(P - 12, 6);
+                P -= 12;
+            }
+        }
+    } else if (active) {
+        uint32_t w;
+        __builtin_memcpy(&w, cp + 4 * (lane - 1), 4);
+        P = w & 0xFFFFFu;
+        sl = (w >> 20) & 63u;
+        sm = w >> 26;
+        if (P > 8 * bsn) bad = 1;
+    }
+    if (__any(bad)) return (uint32_t)__shfl((int)bad, 0, 64) ? 0u : 3u;  // a bad end mark is the frame's fault
+    const uint32_t P0 = P, sl0 = sl, sm0 = sm;
+    const uint32_t first = (uint32_t)lane * spacing;
+    uint32_t sum_ll = 0, sum_all = 0;
+    for (uint32_t s = 0; s < spacing; ++s) {
+        const uint32_t i = first + s;
+        const bool on = active && i < nseq && !bad;
+        const uint32_t elx = (uint32_t)__shfl((int)llt.x, (int)sl, 64), ely = (uint32_t)__shfl((int)llt.y, (int)sl, 64);
+        const uint32_t emx = (uint32_t)__shfl((int)mlt.x, (int)sm, 64), emy = (uint32_t)__shfl((int)mlt.y, (int)sm, 64);
+        if (on) {
+            const uint32_t lnb = (ely >> 16) & 0xFF, mnb = (emy >> 16) & 0xFF;
+            const uint32_t eb = lnb + mnb;
+            const bool more = i + 1 < nseq;
+            const uint32_t snl = more ? ely >> 24 : 0u, snm = more ? emy >> 24 : 0u;
+            if (eb + snl + snm > P) {
+                bad = 1;
+            } else {
+                const uint32_t v = eb ? extract(P - eb, eb) : 0u;
+                P -= eb;
+                const uint32_t mlen = emx + (lnb >= 32 ? 0u : (v >> lnb));
+                const uint32_t llen = elx + (lnb >= 32 ? v : (v & ((1u << lnb) - 1u)));
+                if (llen == 0) impure = 1;
+                ws[i] = make_uint2(llen, mlen);
+                sum_ll += llen;
+                sum_all += llen + mlen;
+                if (sum_all > BLOCK_MAX) bad = 1;
+                if (more) {
+                    const uint32_t sb = snl + snm;
+                    const uint32_t v2 = sb ? extract(P - sb, sb) : 0u;
+                    P -= sb;
+                    sl = (ely & 0xFFFF) + (v2 >> snm);
+                    sm = (emy & 0xFFFF) + (v2 & ((1u << snm) - 1u));
+                }
+            }
+        }
+    }
+    // every segment must end in the state the next one started from; the last one at the start of the stream
+    const uint32_t nP = (uint32_t)__shfl_down((int)P0, 1, 64), nsl = (uint32_t)__shfl_down((int)sl0, 1, 64),
+                   nsm = (uint32_t)__shfl_down((int)sm0, 1, 64);
+    if (active) {
+        if ((uint32_t)lane + 1 < nseg) bad |= (P != nP || sl != nsl || sm != nsm) ? 1u : 0u;
+        else bad |= P != 0 ? 1u : 0u;
+    }
+    if (__any(bad)) return 3u;  // the serial walk decides whether the frame or only the trailer is wrong
+    if (__any(impure)) return 2u;
+    const uint32_t tll = (uint32_t)__shfl((int)wave_incl_scan_u32(active ? sum_ll : 0u), 63, 64);
+    const uint32_t tall = (uint32_t)__shfl((int)wave_incl_scan_u32(active ? sum_all : 0u), 63, 64);
+    if (tll > regen) return 0u;
+    if ((uint64_t)tall + (regen - tll) > BLOCK_MAX) return 0u;
+    *total_out = tall + (regen - tll);
+    __syncthreads();
+    return 1u;
+}
+
 __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint32_t n, int lane)
 {
     for (uint32_t i = lane; i < n; i += WAVE) lds[i] = g[i];
@@ -1087,7 +1191,7 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
 template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs)
 {
-    unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long tph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
@@ -1171,6 +1275,23 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const uint32_t block_max = L.ctl[C_C];
     const uint32_t has_checksum = L.ctl[C_D];
 
+    // the encoder's checkpoint trailer (a skippable frame that ends the buffer), if any: see zero_run_chain_segments
+    const uint8_t* cp_tab = nullptr;
+    uint32_t cp_count = 0, cp_spacing = 0;
+    if (n >= 64) {
+        uint32_t tb;
+        __builtin_memcpy(&tb, src + n - 4, 4);
+        if (tb >= 20 && tb <= 8 + 4 + 4 * 63 + 4 && tb + 16 <= n) {
+            uint32_t m[3];
+            __builtin_memcpy(m, src + n - tb, 12);
+            const uint32_t cnt = m[2] >> 16;
+            if (m[0] == 0x184D2A5Bu && m[1] == tb - 8 && tb == 16 + 4 * cnt && cnt >= 1) {
+                cp_tab = src + n - tb + 12;
+                cp_count = cnt;
+                cp_spacing = m[2] & 0xFFFFu;
+            }
+        }
+    }
     const uint32_t first_block = pos;
     uint32_t opos = 0, ntask = 0;
     for (int attempt = 0;; ++attempt) {
@@ -1192,15 +1313,35 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     bool have_ll = false, have_of = false, have_ml = false;
     int log_ll = 0, log_of = 0, log_ml = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;  // lane 0 only
+    // the 24 bytes at the head of the next block, requested as soon as this block's size is known (lane i holds
+    // byte i): by the time the block is done they have arrived
+    uint32_t pf_byte = 0;
+    bool pf_ok = false;
+    bool cp_avail = cp_count != 0;
 
     for (;;) {
         if (pos + 3 > n) FAIL();
-        // one staged read covers the block header, the literals header and (treeless blocks) the jump table
-        stage_bytes(L.u.p.hbuf, src + pos, (n - pos) < 24 ? (n - pos) : 24, lane);
+        PHASE(0);
+        // 24 staged bytes cover the block header, the literals header and (treeless blocks) the jump table
+        if (pf_ok) {
+            __syncthreads();
+            if (lane < 24) L.u.p.hbuf[lane] = (uint8_t)pf_byte;
+            __syncthreads();
+        } else {
+            stage_bytes(L.u.p.hbuf, src + pos, (n - pos) < 24 ? (n - pos) : 24, lane);
+        }
         const uint32_t bh = L.u.p.hbuf[0] | ((uint32_t)L.u.p.hbuf[1] << 8) | ((uint32_t)L.u.p.hbuf[2] << 16);
         pos += 3;
         const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
         if (btype == 3) FAIL();
+        pf_ok = false;
+        if (!last) {
+            const uint64_t nextpos = (uint64_t)pos + (btype == 1 ? 1u : bsize);
+            if (nextpos + 3 <= n) {
+                pf_byte = (lane < 24 && nextpos + (uint32_t)lane < n) ? src[nextpos + (uint32_t)lane] : 0u;
+                pf_ok = true;
+            }
+        }
         if (btype == 0) {  // Raw_Block
             if (bsize > block_max || pos + bsize > n || (uint64_t)opos + bsize > fcs) FAIL();
             for (uint32_t i = lane; i < bsize; i += WAVE) dst[opos + i] = src[pos + i];
@@ -1246,7 +1387,16 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     jt[2] = h[lh + 4] | ((uint32_t)h[lh + 5] << 8);
                 }
             }
+            // ---- sequences section header (3.1.1.3.2.1): its first bytes are requested now, used further down
+            const uint32_t lit_end = lh + csize;  // offset of the sequences section in the block
+            if (lit_end >= bsize) FAIL();
+            const uint8_t* sq = blk + lit_end;
+            const uint32_t sqn = bsize - lit_end;
+            uint64_t sq8;  // sq[0..7]; bytes past the block are never looked at (the arena is readable 16 bytes past its end)
+            __builtin_memcpy(&sq8, sq, 8);
+#define SQB(i) ((uint32_t)(sq8 >> (8 * (i))) & 0xFFu)
             __syncthreads();
+            PHASE(6);
             if (ltype == 2) {
                 PHASE(0);
                 // tree description: at most 129 bytes; the weights are decoded by wave-uniform code, the wave fills the table
@@ -1284,12 +1434,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 cur_log = (int)tlog;
                 PHASE(5);
             }
-            // ---- sequences section header (3.1.1.3.2.1)
-            const uint32_t lit_end = lh + csize;  // offset of the sequences section in the block
-            if (lit_end >= bsize) FAIL();
-            const uint8_t* sq = blk + lit_end;
-            const uint32_t sqn = bsize - lit_end;
-            uint32_t nseq = sq[0], sq_used = 1;
+            uint32_t nseq = SQB(0), sq_used = 1;
             const bool has_seq = nseq != 0;
             if (!has_seq && sqn != 1) FAIL();
             if ((uint64_t)opos + regen > fcs) FAIL();
@@ -1308,14 +1453,14 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 uint32_t go = 0;
                 if (lane == 0 && sqn >= 4) {
                     const uint32_t used0 = nseq < 128 ? 1u : (nseq < 255 ? 2u : 3u);
-                    const uint32_t ns0 = nseq < 128 ? nseq : (nseq < 255 ? ((nseq - 128) << 8) + sq[1] : sq[1] + ((uint32_t)sq[2] << 8) + 0x7F00);
+                    const uint32_t ns0 = nseq < 128 ? nseq : (nseq < 255 ? ((nseq - 128) << 8) + SQB(1) : SQB(1) + (SQB(2) << 8) + 0x7F00);
                     if (used0 + 2 < sqn) {
-                        const uint32_t modes = sq[used0];
+                        const uint32_t modes = SQB(used0);
                         const uint32_t llm = modes >> 6, ofm = (modes >> 4) & 3;
                         const uint32_t ofsym_at = used0 + 1 + (llm == 1 ? 1u : 0u);
                         ws_lit = (fcs + 15u) & ~15u;
                         ws_pairs = ws_lit + (ltype >= 2 ? ((regen + 7u) & ~7u) : 0u);
-                        go = (ofm == 1 && llm != 2 && ofsym_at < sqn && sq[ofsym_at] == 0 && rep0 == 1 &&
+                        go = (ofm == 1 && llm != 2 && ofsym_at < sqn && SQB(ofsym_at) == 0 && rep0 == 1 &&
                               (uint64_t)ws_pairs + 8ull * ns0 + 8 <= cap) ? 1u : 0u;
                         // predefined LL and ML tables (what zstd_encode.hip writes): nothing to build
                         if (go && modes == 0x10u && dtabs != nullptr) go = 2u | (used0 << 2) | (ns0 << 4);
@@ -1374,6 +1519,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 }
                 __syncthreads();
             }
+            PHASE(7);
             if (!has_seq) {
                 if (ltype == 0) {
                     for (uint32_t i = lane; i < regen; i += WAVE) dst[opos + i] = lit_src[i];
@@ -1468,8 +1614,15 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 {
                     PHASE(2);
                     uint32_t total = 0;
-                    const uint32_t ok = zero_run_chain(sq + sq_used, sqn - sq_used, reinterpret_cast<uint2*>(dst + ws_pairs), nseq,
-                                                       llt, mlt, lgl, lgm, regen, lane, &total);
+                    uint32_t ok = 3;
+                    if (fast_tabs && cp_avail) {
+                        cp_avail = false;  // the trailer describes one sequences section
+                        ok = zero_run_chain_segments(sq + sq_used, sqn - sq_used, reinterpret_cast<uint2*>(dst + ws_pairs), nseq, llt, mlt,
+                                                     regen, cp_tab, cp_count, cp_spacing, lane, &total);
+                    }
+                    if (ok == 3)
+                        ok = zero_run_chain(sq + sq_used, sqn - sq_used, reinterpret_cast<uint2*>(dst + ws_pairs), nseq, llt, mlt, lgl, lgm,
+                                            regen, lane, &total);
                     PHASE(3);
                     if (ok == 0) FAIL();
                     if (ok == 2) {  // not a pure zero-run block after all: decode the frame again, in order
@@ -1663,11 +1816,20 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         if (pos + 4 > n) FAIL();
         pos += 4;  // xxh64 of the content: not verified
     }
-    if (pos != n) FAIL();   // one frame per buffer (what vbz writes)
+    // skippable frames behind the frame are legal and ignored (RFC 8878 3.1.2); a second data frame is not what
+    // vbz writes and is rejected
+    while (n - pos >= 8) {
+        uint32_t m[2];
+        __builtin_memcpy(m, src + pos, 8);
+        if ((m[0] & 0xFFFFFFF0u) != 0x184D2A50u || (uint64_t)pos + 8 + m[1] > n) break;
+        pos += 8 + m[1];
+    }
+    if (pos != n) FAIL();
     if (opos != fcs) FAIL();
     if (lane == 0) b.result[r] = fcs;
     if (TIMED && lane == 0)
-        for (int k = 0; k < 6; ++k) dbg[(size_t)r * 8 + k] = tph[k];
+        for (int k = 0; k < 8; ++k) dbg[(size_t)r * 8 + k] = tph[k];
+#undef SQB
 #undef PHASE
 #undef FLUSH
 #undef FAIL

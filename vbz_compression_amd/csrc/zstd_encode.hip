@@ -72,6 +72,8 @@ struct EncLds
         };
     };
     SeqCTables seq;             // encoding tables of the predefined LL / ML distributions
+    uint32_t cp[64];            // decoder checkpoints of the sequences section (see CP_MAGIC)
+    uint32_t cpCount, cpSpacing;
 };
 
 __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
@@ -444,6 +446,17 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
     nrec = rec_total;
 }
 
+// Decoder checkpoints.  The LL / ML state chain of a sequences section is serial for a decoder that starts at
+// the top of the bit stream; the encoder knows every intermediate state, so it publishes one checkpoint per
+// CP spacing sequences -- (unread bits, LL state, ML state) before sequence k * spacing -- in a zstd *skippable
+// frame* behind the frame (RFC 8878 3.1.2: decoders skip it; libzstd's ZSTD_decompress and
+// ZSTD_getFrameContentSize are unaffected).  zstd_decode.hip walks the segments in parallel, one lane each, and
+// accepts the result only if every segment ends exactly in the next checkpoint, so a wrong or missing trailer
+// costs speed, never correctness.  Layout: magic 0x184D2A5B, u32 size, { u16 spacing, u16 count,
+// count x u32 (unread bits | LL state << 20 | ML state << 26), u32 total trailer bytes }.
+constexpr uint32_t CP_MAGIC = 0x184D2A5Bu;
+constexpr uint32_t CP_MIN_SPACING = 32;
+
 // all lanes.  Sequences section (RFC 8878 3.1.1.3.2) for the records of tokenise_zero_runs: LL and ML with the
 // predefined distributions, OF in RLE mode with code 0 (repeat offset 1); same bit order as libzstd's
 // ZSTD_encodeSequences (last sequence first).  Per chunk of 64 sequences: every lane turns one record into
@@ -474,6 +487,12 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
     const uint32_t* dnb = lane == 0 ? L.seq.ml_dnb : L.seq.ll_dnb;
     const int32_t* dfs = lane == 0 ? L.seq.ml_dfs : L.seq.ll_dfs;
     uint32_t base_bits = 0, flushed = 0;
+    uint32_t spacing = CP_MIN_SPACING;  // at most 63 checkpoints + the start = 64 decoder lanes
+    while ((nseq + spacing - 1) / spacing > 64) spacing *= 2;
+    if (lane == 0) {
+        L.cpSpacing = spacing;
+        L.cpCount = (nseq - 1) / spacing;
+    }
     for (uint32_t t0 = 0; t0 < nseq; t0 += WAVE) {
         const uint32_t cnt = (nseq - t0) < (uint32_t)WAVE ? (nseq - t0) : (uint32_t)WAVE;
         const uint32_t t = t0 + (uint32_t)lane;
@@ -502,7 +521,7 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
                     piece = (st & ((1u << nbo) - 1u)) | (nbo << 16);
                     st = stab[(int32_t)(st >> nbo) + dfs[c]];
                 }
-                pieces[lane * WAVE + j] = piece;
+                pieces[lane * WAVE + j] = piece | ((st & 63u) << 24);  // + the state the decoder is in before this sequence
             }
         }
         wave_lds_sync();
@@ -511,9 +530,9 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
         if (t < nseq) {
             const uint32_t pm = pieces[lane], pl = pieces[WAVE + lane];
             v = (uint64_t)(pm & 0xFFFF);
-            len = pm >> 16;
+            len = (pm >> 16) & 0xFF;
             v |= (uint64_t)(pl & 0xFFFF) << len;
-            len += pl >> 16;
+            len += (pl >> 16) & 0xFF;
             v |= (uint64_t)lex << len;
             len += lnb;
             v |= (uint64_t)mex << len;
@@ -522,6 +541,11 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
         const uint32_t incl = wave_incl_scan_u32(len);
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
         const uint32_t pos = base_bits + incl - len;
+        if (t < nseq) {
+            const uint32_t n = nseq - 1 - t;  // checkpoint: everything up to and including this sequence's bits is unread
+            if (n != 0 && n % spacing == 0)
+                L.cp[n / spacing - 1] = (8u * flushed + base_bits + incl) | ((pieces[WAVE + lane] >> 24) << 20) | ((pieces[lane] >> 24) << 26);
+        }
         if (len) {
             const uint32_t w = pos >> 5, sh = pos & 31;
             const uint64_t lo = v << sh;                 // len <= 44, sh <= 31: may spill into a third word
@@ -574,7 +598,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                                                            const uint32_t* src_cap, const SeqCTables* seqtab)
 {
     __shared__ EncLds L;
-    unsigned long long tph[6] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long tph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
@@ -610,6 +634,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         for (uint32_t i = lane; i < sizeof(SeqCTables) / 4; i += WAVE) l[i] = g[i];
     }
     uint32_t opos = 0;
+    bool frame_cp = false;  // a sequences section with checkpoints was written
     NEED(hdr + 9 + (N == 0 ? 3 : 0));
     if (lane == 0) {
         if (hdr) put_le(out, orig_size[r], 4);
@@ -675,6 +700,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             }
             for (uint32_t i = lane; i < S; i += WAVE) bp[3 + lh + i] = rin[i];
             const uint32_t sb = encode_zero_run_sequences(L, bp + 3 + lh + S, rec, nrec, lane);
+            frame_cp = true;
             if (lane == 0) put_le(bp, ((lh + S + sb) << 3) | (2u << 1) | (lastRegion ? 1u : 0u), 3);
             opos += 3 + lh + S + sb;
             continue;
@@ -883,6 +909,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                             if (seqmode) {
                                 if ((uint64_t)spos + 8 + 8ull * nrec > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
                                 seqBytes = encode_zero_run_sequences(L, out + spos, rec, nrec, lane);
+                                frame_cp = true;
                                 wave_lds_sync();
                                 for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;  // it used the bit buffer
                                 wave_lds_sync();
@@ -927,9 +954,24 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             PHASE(5);
         }
     }
+    if (frame_cp) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
+        wave_lds_sync();
+        const uint32_t count = L.cpCount, tb = 8u + 4u + 4u * count + 4u;
+        if (count != 0 && (uint64_t)opos + tb <= cap) {
+            uint8_t* tp = out + opos;
+            if (lane == 0) {
+                put_le(tp, CP_MAGIC, 4);
+                put_le(tp + 4, tb - 8u, 4);
+                put_le(tp + 8, L.cpSpacing | (count << 16), 4);
+                put_le(tp + 12 + 4 * count, tb, 4);
+            }
+            if ((uint32_t)lane < count) put_le(tp + 12 + 4 * lane, L.cp[lane], 4);
+            opos += tb;
+        }
+    }
     if (lane == 0) b.result[r] = opos;
     if (TIMED && lane == 0)
-        for (int k = 0; k < 6; ++k) dbg[(size_t)r * 8 + k] = tph[k];
+        for (int k = 0; k < 8; ++k) dbg[(size_t)r * 8 + k] = tph[k];
 #undef PHASE
 #undef NEED
 }
