@@ -213,6 +213,53 @@ def test_zstd_ratio_close_to_libzstd_on_signal():
     assert abs(gpu / ref - 1.0) < 0.01, (gpu, ref)  # ratio within 1 % of the reference
 
 
+def test_checkpoint_trailer_is_optional_and_untrusted():
+    """The encoder appends a skippable frame with decoder checkpoints (zstd_encode.hip, CP_MAGIC).  It must be
+    invisible to the reference's decoder, optional for ours, and never trusted: a wrong trailer costs speed only."""
+    import gpu_util as G
+
+    opts = G.codec().options(True, 2, 1, 1)
+    reads = [O.synth_signal(5, i, O.synth_read_length(5, i)) for i in range(3)]
+    frames = G.compress(reads, opts)
+    rng = np.random.default_rng(3)
+    variants, want = [], []
+    for a, f in zip(reads, frames):
+        assert not isinstance(f, int), f
+        tb = int(f[-4:].view("<u4")[0])
+        head = f[len(f) - tb : len(f) - tb + 12].view("<u4")
+        assert head[0] == 0x184D2A5B and head[1] == tb - 8 and tb == 16 + 4 * (int(head[2]) >> 16)
+        back = O.decompress(f, a.nbytes, O.options(True, 2, 1, 1))           # the reference path (libzstd) skips it
+        assert not isinstance(back, int) and back.tobytes() == a.tobytes()
+        body = f[: len(f) - tb]
+        cands = [f, body]                                                       # as written; without the trailer
+        for _ in range(6):                                                      # damaged checkpoints, spacing, count
+            g = f.copy()
+            at = len(f) - tb + 8 + int(rng.integers(0, tb - 12))
+            g[at] ^= 1 << int(rng.integers(0, 8))
+            cands.append(g)
+        junk = np.concatenate([np.array([0x5B, 0x2A, 0x4D, 0x18, 20, 0, 0, 0], np.uint8), rng.integers(0, 256, 20, dtype=np.uint8)])
+        cands.append(np.concatenate([body, junk]))                             # some other skippable frame behind
+        cands.append(np.concatenate([f, junk]))                                # ... and behind the trailer
+        for c in cands:
+            variants.append(np.ascontiguousarray(c))
+            want.append(a)
+    got = G.decompress(variants, [w.nbytes for w in want], opts)
+    for v, w, g in zip(variants, want, got):
+        lz = O.decompress(v, w.nbytes, O.options(True, 2, 1, 1))
+        if isinstance(lz, int):      # damage that breaks the skippable frame's own header: both must refuse
+            assert isinstance(g, int), (g, lz)
+        else:
+            assert not isinstance(g, int), g
+            assert g.tobytes() == w.tobytes()
+    # frames libzstd wrote, with skippable frames behind them; and a second data frame, which vbz never writes
+    svb = O.svb_compress(reads[0], 2, True, 1)
+    zf = O.zstd_compress(svb, 1)
+    junk = np.concatenate([np.array([0x50, 0x2A, 0x4D, 0x18, 5, 0, 0, 0], np.uint8), rng.integers(0, 256, 5, dtype=np.uint8)])
+    got = G.zstd_decompress([np.concatenate([zf, junk]), np.concatenate([zf, junk, junk]), np.concatenate([zf, zf])], [len(svb)] * 3)
+    assert got[0].tobytes() == svb.tobytes() and got[1].tobytes() == svb.tobytes()
+    assert isinstance(got[2], int)
+
+
 def test_zstd_decode_rejects_corruption():
     import gpu_util as G
 
