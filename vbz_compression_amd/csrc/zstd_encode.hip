@@ -356,8 +356,12 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
 // morphological open of the zero mask, computed with shifts on a 64-bit window per lane; positions come from
 // wave prefix sums.  Only the FSE state chain of the sequences is serial (lane 0, ~RMIN+ bytes per step).
 #ifndef VBZ_RMIN
-#define VBZ_RMIN 16
+#define VBZ_RMIN 12
 #endif
+#ifndef VBZ_DATA_BLOCKS
+#define VBZ_DATA_BLOCKS 15
+#endif
+constexpr uint32_t DATA_BLOCKS = VBZ_DATA_BLOCKS;  // blocks of the data-byte region when the control bytes take one block
 constexpr uint32_t RMIN = VBZ_RMIN;  // shortest zero run that becomes a match (break-even is ~13 bytes); >= 8, <= 24
 static_assert(RMIN >= 8 && RMIN <= 24, "the tokeniser handles at most two run ends per 16 positions and a 64-bit window");
 constexpr uint32_t TOK_PAYLOAD = 60 * 16;
@@ -652,6 +656,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     uint32_t T = (N + 13) / 14;
     T = T < MIN_BLOCK ? MIN_BLOCK : (T > BLOCK_MAX ? BLOCK_MAX : T);
 
+    bool keys_one_block = false;
     for (int region = 0; region < 2; ++region) {
         const uint32_t r0 = region == 0 ? 0 : K;
         const uint32_t r1 = region == 0 ? (K ? K : N) : N;
@@ -660,6 +665,12 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         const bool lastRegion = (r1 == N);
         const uint8_t* rin = in + r0;
         uint32_t nblk = (S + T - 1) / T;
+        if (region == 1 && keys_one_block) {
+            // the control bytes took one block (4 streams): the data bytes get the other 15 x 4 lanes of the decoder
+            uint32_t Td = (S + DATA_BLOCKS - 1) / DATA_BLOCKS;
+            Td = Td < MIN_BLOCK ? MIN_BLOCK : (Td > BLOCK_MAX ? BLOCK_MAX : Td);
+            nblk = (S + Td - 1) / Td;
+        }
         // control-byte region of a library-owned svb stream: turn long zero runs into sequences.  The
         // literals are compacted in place, the run records go to the unused tail of the scratch slot.
         bool seqmode = false;
@@ -678,6 +689,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     rec = reinterpret_cast<const uint2*>(ws);
                     S = Lit;      // from here on the region is its literal stream: one block
                     nblk = 1;
+                    keys_one_block = true;
                 }
             }
         }
