@@ -102,12 +102,22 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
     uint64_t F = 0;  // bytes of the aligned space already flushed (multiple of 16)
     uint64_t P = A;  // next byte position in the aligned space; stage[] holds [F, P)
 
+    // the next tile's 16 bytes per lane are requested before this tile is processed (one load always in flight)
+    uint4 qnext = make_uint4(0u, 0u, 0u, 0u);
+    {
+        const uint32_t i0 = (uint32_t)tid * VPL;
+        if (in_aligned && i0 < n && n - i0 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i0 * ELEM);
+    }
     for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
         const uint32_t i0 = t0 + (uint32_t)tid * VPL;
         const int valid = i0 >= n ? 0 : (n - i0 >= (uint32_t)VPL ? VPL : (int)(n - i0));
         int32_t x[VPL];
+        const uint4 q = qnext;
+        {
+            const uint32_t i1 = i0 + TILE;
+            if (in_aligned && i1 < n && n - i1 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i1 * ELEM);
+        }
         if (valid == VPL && in_aligned) {
-            uint4 q = *reinterpret_cast<const uint4*>(in + (size_t)i0 * ELEM);
             const uint32_t w[4] = { q.x, q.y, q.z, q.w };
             if (ELEM == 4) {
 #pragma unroll
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
                 }
             }
         }
-        __syncthreads();
+        wg_lds_barrier();
         const uint32_t endidx = (uint32_t)(P - F) + tot;
         const uint32_t nch = endidx >> 4;
         for (uint32_t c = tid; c < nch; c += WG) {
@@ -192,13 +202,13 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         const uint32_t rem = endidx & 15u;
         uint8_t keep = 0;
         if ((uint32_t)tid < rem) keep = stage[16u * nch + tid];
-        __syncthreads();
+        wg_lds_barrier();
         if (nch > 0 && (uint32_t)tid < rem) stage[tid] = keep;
         F += 16ull * nch;
         P += tot;
         // the scan at the top of the next tile contains the barrier that orders these LDS writes
     }
-    __syncthreads();
+    wg_lds_barrier();
     {   // tail: bytes [F, P) still in LDS
         const uint32_t rem = (uint32_t)(P - F);
         const uint32_t lo = (F == 0) ? A : 0u;
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
         const uint32_t nch = (mis + tot + 15u) >> 4;
         for (uint32_t c = tid; c < nch; c += WG)
             *reinterpret_cast<uint4*>(stage + 16u * c) = *reinterpret_cast<const uint4*>(ga + 16ull * c);
-        __syncthreads();
+        wg_lds_barrier();
         uint32_t o = mis + ex;
         // int16 zig-zag path: SIMD body vs scalar tail of the reference (sse3.h:494-540 vs 542-572)
         const bool body = I16ZZ && ((i0 >> 3) < (count >> 3)) && (dataBytes - (pos + ex) >= 32u);
@@ -325,7 +335,7 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
             base = run + block_excl_scan_u32(acc, wsum, ttot);
             run += ttot;
         } else {
-            __syncthreads();  // stage is overwritten by the next tile
+            wg_lds_barrier();  // stage is overwritten by the next tile
         }
         if (valid == VPL && out_aligned) {
             uint32_t w[4];

@@ -91,6 +91,14 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding global
+// loads AND stores (s_waitcnt vmcnt(0)), which serialises a tile loop on memory latency; the streaming kernels
+// only ever exchange data through LDS, so they wait for LDS alone and keep their global accesses in flight.
+__device__ __forceinline__ void wg_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
     const int lane = threadIdx.x & 63;
@@ -103,13 +111,13 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 }
 
 // exclusive scan over a 256-thread workgroup; wsum = 4 words of LDS; returns the exclusive prefix,
-// `total` gets the workgroup sum.  Contains two barriers.
+// `total` gets the workgroup sum.  Contains two (LDS-only) barriers.
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* wsum, uint32_t& total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t inc = wave_incl_scan_u32(v);
     if (lane == 63) wsum[w] = inc;
-    __syncthreads();
+    wg_lds_barrier();
     uint32_t base = 0, tot = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -117,7 +125,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* ws
         base += (k < w) ? s : 0u;
         tot += s;
     }
-    __syncthreads();
+    wg_lds_barrier();
     total = tot;
     return base + inc - v;
 }

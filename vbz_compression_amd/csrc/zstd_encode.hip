@@ -481,15 +481,17 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
     }
     hdr = (uint32_t)__shfl((int)hdr, 0, 64);
     uint8_t* out = dst + hdr;
-    // LDS scratch inside the (idle) bit buffer of the stream packer: [0..127] bit words, then codes / pieces
+    // LDS scratch inside the (idle) bit buffer of the stream packer: bit words of one chunk
     uint32_t* bits = L.obuf;                 // 128 words: 64 sequences x 44 bits + carry
-    uint32_t* codes = L.obuf + 128;          // [64] : ml code | ll code << 8
-    uint32_t* pieces = L.obuf + 192;         // [2][64] : value | nbits << 16 of the ML / LL state step
     for (int i = lane; i < 128; i += WAVE) bits[i] = 0;
-    uint32_t st = 0;                         // lane 0: match-length state, lane 1: literal-length state
-    const uint16_t* stab = lane == 0 ? L.seq.ml_state : L.seq.ll_state;
-    const uint32_t* dnb = lane == 0 ? L.seq.ml_dnb : L.seq.ll_dnb;
-    const int32_t* dfs = lane == 0 ? L.seq.ml_dfs : L.seq.ll_dfs;
+    // The two FSE state chains (match length, literal length) are serial; they run as wave-uniform code on the
+    // scalar unit with everything they look up held across the lanes of vector registers: the state tables (64
+    // entries each), the per-symbol deltas, the chunk's codes; each step's output lands in lane j of pmv / plv.
+    const uint32_t t_mstate = L.seq.ml_state[lane], t_lstate = L.seq.ll_state[lane];
+    const uint32_t t_mdnb = lane < SEQ_ML_SYMS ? L.seq.ml_dnb[lane] : 0u, t_ldnb = lane < SEQ_LL_SYMS ? L.seq.ll_dnb[lane] : 0u;
+    const uint32_t t_mdfs = lane < SEQ_ML_SYMS ? (uint32_t)L.seq.ml_dfs[lane] : 0u, t_ldfs = lane < SEQ_LL_SYMS ? (uint32_t)L.seq.ll_dfs[lane] : 0u;
+    auto rl = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+    uint32_t stM = 0, stL = 0;               // encoder states (table value: decoder state + 64), wave-uniform
     uint32_t base_bits = 0, flushed = 0;
     uint32_t spacing = CP_MIN_SPACING;  // at most 63 checkpoints + the start = 64 decoder lanes
     while ((nseq + spacing - 1) / spacing > 64) spacing *= 2;
@@ -500,7 +502,7 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
     for (uint32_t t0 = 0; t0 < nseq; t0 += WAVE) {
         const uint32_t cnt = (nseq - t0) < (uint32_t)WAVE ? (nseq - t0) : (uint32_t)WAVE;
         const uint32_t t = t0 + (uint32_t)lane;
-        uint32_t lex = 0, lnb = 0, mex = 0, mnb = 0;
+        uint32_t lex = 0, lnb = 0, mex = 0, mnb = 0, codes = 0;
         if (t < nseq) {
             const uint32_t n = nseq - 1 - t;
             const uint2 cur = rec[n];
@@ -510,29 +512,33 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
             uint32_t lc, mc;
             seq_ll_code(ll, &lc, &lex, &lnb);
             seq_ml_code(ml, &mc, &mex, &mnb);
-            codes[lane] = mc | (lc << 8);
+            codes = mc | (lc << 8);
         }
-        wave_lds_sync();
-        if (lane < 2) {
-            for (uint32_t j = 0; j < cnt; ++j) {
-                const uint32_t c = (codes[j] >> (8 * lane)) & 0xFF;
-                uint32_t piece = 0;
-                if (t0 + j == 0) {  // FSE_initCState2: the first symbol only selects the state
-                    const uint32_t nbo = (dnb[c] + (1u << 15)) >> 16;
-                    st = stab[(int32_t)(((nbo << 16) - dnb[c]) >> nbo) + dfs[c]];
-                } else {            // FSE_encodeSymbol
-                    const uint32_t nbo = (st + dnb[c]) >> 16;
-                    piece = (st & ((1u << nbo) - 1u)) | (nbo << 16);
-                    st = stab[(int32_t)(st >> nbo) + dfs[c]];
-                }
-                pieces[lane * WAVE + j] = piece | ((st & 63u) << 24);  // + the state the decoder is in before this sequence
+        uint32_t pmv = 0, plv = 0;  // lane j: value | nbits << 16 | decoder state before this sequence << 24
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const uint32_t cc = rl(codes, j), mc = cc & 0xFF, lc = cc >> 8;
+            const uint32_t dm = rl(t_mdnb, mc), dl = rl(t_ldnb, lc);
+            const uint32_t fm = rl(t_mdfs, mc), fl = rl(t_ldfs, lc);
+            uint32_t pieceM = 0, pieceL = 0;
+            if (t0 + j == 0) {  // FSE_initCState2: the first symbol only selects the state
+                const uint32_t nm = (dm + (1u << 15)) >> 16, nl = (dl + (1u << 15)) >> 16;
+                stM = rl(t_mstate, (uint32_t)((int32_t)(((nm << 16) - dm) >> nm) + (int32_t)fm));
+                stL = rl(t_lstate, (uint32_t)((int32_t)(((nl << 16) - dl) >> nl) + (int32_t)fl));
+            } else {            // FSE_encodeSymbol
+                const uint32_t nm = (stM + dm) >> 16, nl = (stL + dl) >> 16;
+                pieceM = (stM & ((1u << nm) - 1u)) | (nm << 16);
+                pieceL = (stL & ((1u << nl) - 1u)) | (nl << 16);
+                stM = rl(t_mstate, (uint32_t)((int32_t)(stM >> nm) + (int32_t)fm));
+                stL = rl(t_lstate, (uint32_t)((int32_t)(stL >> nl) + (int32_t)fl));
             }
+            const bool here = (uint32_t)lane == j;
+            pmv = here ? (pieceM | ((stM & 63u) << 24)) : pmv;
+            plv = here ? (pieceL | ((stL & 63u) << 24)) : plv;
         }
-        wave_lds_sync();
         uint64_t v = 0;
         uint32_t len = 0;
         if (t < nseq) {
-            const uint32_t pm = pieces[lane], pl = pieces[WAVE + lane];
+            const uint32_t pm = pmv, pl = plv;
             v = (uint64_t)(pm & 0xFFFF);
             len = (pm >> 16) & 0xFF;
             v |= (uint64_t)(pl & 0xFFFF) << len;
@@ -548,7 +554,7 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
         if (t < nseq) {
             const uint32_t n = nseq - 1 - t;  // checkpoint: everything up to and including this sequence's bits is unread
             if (n != 0 && n % spacing == 0)
-                L.cp[n / spacing - 1] = (8u * flushed + base_bits + incl) | ((pieces[WAVE + lane] >> 24) << 20) | ((pieces[lane] >> 24) << 26);
+                L.cp[n / spacing - 1] = (8u * flushed + base_bits + incl) | ((plv >> 24) << 20) | ((pmv >> 24) << 26);
         }
         if (len) {
             const uint32_t w = pos >> 5, sh = pos & 31;
@@ -574,13 +580,12 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
         wave_lds_sync();
     }
     // final states (match length, then literal length) and the end mark
-    const uint32_t stLL = (uint32_t)__shfl((int)st, 1, 64);
     uint32_t nbytes = 0;
     if (lane == 0) {
         uint64_t acc = bits[0];
         uint32_t nbit = base_bits;
-        acc |= (uint64_t)(st & 63u) << nbit; nbit += SEQ_DEF_LOG;
-        acc |= (uint64_t)(stLL & 63u) << nbit; nbit += SEQ_DEF_LOG;
+        acc |= (uint64_t)(stM & 63u) << nbit; nbit += SEQ_DEF_LOG;
+        acc |= (uint64_t)(stL & 63u) << nbit; nbit += SEQ_DEF_LOG;
         acc |= 1ull << nbit; nbit += 1;
         nbytes = (nbit + 7) >> 3;
         for (uint32_t i = 0; i < nbytes; ++i) out[flushed + i] = (uint8_t)(acc >> (8 * i));
