@@ -566,34 +566,45 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
         const uint32_t lowbit = 8 * (1 + hdr);
         const uint32_t lastbyte = bits(8 * hb, 8);
         if (hdr >= hb || lastbyte == 0) return -1;
-        uint32_t P = 8 * hb + (uint32_t)hbit(lastbyte);  // unread bits are [lowbit, P)
-        bool over = false;
-        auto rd = [&](uint32_t nb) -> uint32_t {  // nb <= 6; past the start: zero fill, over = true
-            const uint32_t have = P - lowbit;
-            uint32_t v;
-            if (nb <= have) {
-                P -= nb;
-                v = nb ? bits(P, nb) : 0u;
-            } else {
-                v = (have ? bits(lowbit, have) : 0u) << (nb - have);
-                P = lowbit;
-                over = true;
+        const uint32_t P = 8 * hb + (uint32_t)hbit(lastbyte);  // unread bits are [lowbit, P)
+        uint32_t dw = d;  // the stream alone: bits below its start read as zero (libzstd's zero fill past the start)
+        {
+            const uint32_t lo = 32u * (uint32_t)lane;
+            if (lo + 32 <= lowbit) dw = 0;
+            else if (lo < lowbit) dw &= ~((1u << (lowbit - lo)) - 1u);
+        }
+        int32_t left = (int32_t)(P - lowbit);
+        int32_t idx = (int32_t)((P - 1) >> 5);
+        const uint32_t r0 = P - 32u * (uint32_t)idx;  // 1..32 unread bits in the top dword
+        uint64_t buf = (uint64_t)(lane_get(dw, (uint32_t)idx) << (32u - r0)) << 32;
+        uint32_t have = r0;
+        --idx;
+        auto rd = [&](uint32_t nb) -> uint32_t {  // nb <= 6
+            if (have <= 32) {
+                const uint32_t nd = idx >= 0 ? lane_get(dw, (uint32_t)idx) : 0u;
+                --idx;
+                buf |= (uint64_t)nd << (32u - have);
+                have += 32;
             }
+            const uint32_t v = (uint32_t)((buf >> 1) >> (63u - nb));
+            buf <<= nb;
+            have -= nb;
+            left -= (int32_t)nb;
             return v;
         };
         uint32_t s1 = rd(log), s2 = rd(log);
-        if (over) return -1;
+        if (left < 0) return -1;
         for (;;) {
             if (nw > 253) return -1;
             uint32_t e = lane_get(tab, s1);
             L.weights[nw++] = (uint8_t)e;
             s1 = (e >> 16) + rd((e >> 8) & 0xFF);
-            if (over) { L.weights[nw++] = (uint8_t)lane_get(tab, s2); break; }
+            if (left < 0) { L.weights[nw++] = (uint8_t)lane_get(tab, s2); break; }
             if (nw > 253) return -1;
             e = lane_get(tab, s2);
             L.weights[nw++] = (uint8_t)e;
             s2 = (e >> 16) + rd((e >> 8) & 0xFF);
-            if (over) { L.weights[nw++] = (uint8_t)lane_get(tab, s1); break; }
+            if (left < 0) { L.weights[nw++] = (uint8_t)lane_get(tab, s1); break; }
         }
     }
     __syncthreads();
@@ -922,6 +933,42 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
         const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(ll + ml);
         const uint32_t tl = (uint32_t)__shfl((int)il, 63, 64), tt = (uint32_t)__shfl((int)it, 63, 64);
         if ((uint64_t)lposw + tl > regen || (uint64_t)oposw + tt > fcs) return 0xFFFFFFFFu;
+        // Common case (zero runs, a chunk's literals and output fit the LDS area): build the chunk's output in LDS --
+        // zero fill, every lane drops its literals in place, runs of a non-zero byte are written out -- and copy it
+        // to memory with 16-byte stores.  Otherwise the lanes write to memory directly.
+        const uint32_t lit_room = (tl + 15u) & ~15u;
+        if (ltype != 1 && lit_room + tt + 16u <= lds_cap) {
+            uint8_t* lds_out = lds_lit + lit_room;
+            __syncthreads();
+            for (uint32_t j = lane; 4 * j < tl; j += WAVE) {
+                uint32_t v;
+                __builtin_memcpy(&v, litp + lposw + 4 * j, 4);  // may read 3 bytes past the literals (staging slack)
+                reinterpret_cast<uint32_t*>(lds_lit)[j] = v;
+            }
+            for (uint32_t j = 16u * (uint32_t)lane; j < tt; j += 16u * WAVE) *reinterpret_cast<uint4*>(lds_out + j) = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+            const uint32_t lo = il - ll, oo = it - (ll + ml);
+            uint8_t lastb = 0;
+            for (uint32_t k = 0; k < ll; ++k) {
+                lastb = lds_lit[lo + k];
+                lds_out[oo + k] = lastb;
+            }
+            if (lastb != 0)
+                for (uint32_t k = 0; k < ml; ++k) lds_out[oo + ll + k] = lastb;
+            __syncthreads();
+            uint8_t* g = dst + oposw;
+            for (uint32_t j = 16u * (uint32_t)lane; j < tt; j += 16u * WAVE) {
+                if (j + 16u <= tt) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(lds_out + j);
+                    __builtin_memcpy(g + j, &v, 16);
+                } else {
+                    for (uint32_t k = j; k < tt; ++k) g[k] = lds_out[k];
+                }
+            }
+            lposw += tl;
+            oposw += tt;
+            continue;
+        }
         const uint32_t my_lit = lposw + il - ll;
         uint32_t my_out = oposw + it - (ll + ml);
         uint8_t lastb = rle_byte;
