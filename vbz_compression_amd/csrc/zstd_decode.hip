@@ -922,13 +922,12 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
 {
     const uint8_t rle_byte = ltype == 1 ? litp[0] : 0;
     uint32_t lposw = 0, oposw = opos;
+    uint2 pnext = (uint32_t)lane < nseq ? pairs[lane] : make_uint2(0u, 0u);  // one chunk of pairs is always in flight
     for (uint32_t base = 0; base < nseq; base += WAVE) {
-        const uint32_t i = base + (uint32_t)lane;
-        uint32_t ll = 0, ml = 0;
-        if (i < nseq) {
-            const uint2 v = pairs[i];
-            ll = v.x;
-            ml = v.y;
+        const uint32_t ll = pnext.x, ml = pnext.y;
+        {
+            const uint32_t i1 = base + WAVE + (uint32_t)lane;
+            pnext = i1 < nseq ? pairs[i1] : make_uint2(0u, 0u);
         }
         const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(ll + ml);
         const uint32_t tl = (uint32_t)__shfl((int)il, 63, 64), tt = (uint32_t)__shfl((int)it, 63, 64);
@@ -937,25 +936,54 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
         // zero fill, every lane drops its literals in place, runs of a non-zero byte are written out -- and copy it
         // to memory with 16-byte stores.  Otherwise the lanes write to memory directly.
         const uint32_t lit_room = (tl + 15u) & ~15u;
-        if (ltype != 1 && lit_room + tt + 16u <= lds_cap) {
-            uint8_t* lds_out = lds_lit + lit_room;
-            __syncthreads();
+        if (ltype != 1 && 5u * lit_room + tt + 16u <= lds_cap) {
+            // LDS: the chunk's literals, one dword per literal (to become its shift), the chunk's output
+            uint32_t* lds_sh = reinterpret_cast<uint32_t*>(lds_lit + lit_room);
+            uint8_t* lds_out = lds_lit + 5u * lit_room;
+            wave_lds_sync();  // one wave: LDS hand-over only, global accesses stay in flight
             for (uint32_t j = lane; 4 * j < tl; j += WAVE) {
                 uint32_t v;
                 __builtin_memcpy(&v, litp + lposw + 4 * j, 4);  // may read 3 bytes past the literals (staging slack)
                 reinterpret_cast<uint32_t*>(lds_lit)[j] = v;
             }
+            for (uint32_t j = 4u * (uint32_t)lane; j < lit_room; j += 4u * WAVE) *reinterpret_cast<uint4*>(lds_sh + j) = make_uint4(0u, 0u, 0u, 0u);
             for (uint32_t j = 16u * (uint32_t)lane; j < tt; j += 16u * WAVE) *reinterpret_cast<uint4*>(lds_out + j) = make_uint4(0u, 0u, 0u, 0u);
-            __syncthreads();
+            wave_lds_sync();
+            // a literal lands (sum of the match lengths in front of it) further down than it sits in the literal
+            // stream: mark the first literal of every sequence with the match length before it, prefix-sum the marks
+            // over the literals -- every lane then moves the same number of literals, however they are spread
             const uint32_t lo = il - ll, oo = it - (ll + ml);
-            uint8_t lastb = 0;
-            for (uint32_t k = 0; k < ll; ++k) {
-                lastb = lds_lit[lo + k];
-                lds_out[oo + k] = lastb;
+            const uint32_t mprev = (uint32_t)__shfl_up((int)ml, 1, 64);
+            if (ll != 0 && lane != 0) lds_sh[lo] = mprev;
+            wave_lds_sync();
+            uint32_t carry = 0;
+            for (uint32_t j0 = 0; j0 < tl; j0 += 8u * WAVE) {
+                const uint32_t j = j0 + 8u * (uint32_t)lane;
+                uint32_t sh[8], run = 0;
+                const uint4 a0 = j < lit_room ? *reinterpret_cast<const uint4*>(lds_sh + j) : make_uint4(0u, 0u, 0u, 0u);
+                const uint4 a1 = j + 4 < lit_room ? *reinterpret_cast<const uint4*>(lds_sh + j + 4) : make_uint4(0u, 0u, 0u, 0u);
+                const uint32_t dl[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    run += dl[k];
+                    sh[k] = run;
+                }
+                const uint32_t inc = wave_incl_scan_u32(run);
+                const uint32_t before = carry + inc - run;
+                uint2 lb = make_uint2(0u, 0u);
+                if (j < lit_room) lb = *reinterpret_cast<const uint2*>(lds_lit + j);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (j + k < tl) lds_out[j + k + before + sh[k]] = (uint8_t)((k < 4 ? lb.x : lb.y) >> (8 * (k & 3)));
+                carry += (uint32_t)__shfl((int)inc, 63, 64);
             }
-            if (lastb != 0)
-                for (uint32_t k = 0; k < ml; ++k) lds_out[oo + ll + k] = lastb;
-            __syncthreads();
+            wave_lds_sync();
+            if (ll != 0) {  // a run of a non-zero byte (never what zstd_encode.hip writes)
+                const uint8_t lastb = lds_lit[il - 1];
+                if (lastb != 0)
+                    for (uint32_t k = 0; k < ml; ++k) lds_out[oo + ll + k] = lastb;
+            }
+            wave_lds_sync();
             uint8_t* g = dst + oposw;
             for (uint32_t j = 16u * (uint32_t)lane; j < tt; j += 16u * WAVE) {
                 if (j + 16u <= tt) {
