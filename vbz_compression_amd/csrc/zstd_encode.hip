@@ -867,11 +867,13 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     uint32_t ent[STEP_LANE];
                     uint32_t T = 0;
 #pragma unroll
-                    for (int k = 0; k < STEP_LANE; ++k) {
-                        const uint32_t e = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                        ent[k] = k >= skip ? e : 0u;
-                        T += ent[k] >> 16;
+                    for (int k = 0; k < STEP_LANE; ++k) ent[k] = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
+                    if (skip != 0) {  // only the last step of a stream has lanes in front of its start
+#pragma unroll
+                        for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
                     }
+#pragma unroll
+                    for (int k = 0; k < STEP_LANE; ++k) T += ent[k] >> 16;
                     const uint32_t incl = wave_incl_scan_u32(T);
                     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
                     const uint32_t allbits = base_bits + total;
