@@ -368,6 +368,225 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
     if (tid == 0) b.result[r] = (bad || pos != dataBytes) ? E_STREAM : count * ELEM;
 }
 
+// ------------------------------------------------------------------------------------------------
+// v1 nibble ("half") codec for 1-byte integers: reference vbz/v1/vbz_streamvbyte_impl.h:20-216
+//   code 0: value 0, no data; 1: one nibble; 2: two nibbles; 3: four nibbles (low 16 bits of the value);
+//   nibbles are appended low nibble first.  Same tiling as the byte codec, but offsets are in nibbles: a lane
+//   assembles its <= 32 nibbles in registers and ORs them into a zeroed LDS stage (two lanes can share a byte).
+// ------------------------------------------------------------------------------------------------
+template <bool ZZ>
+__global__ __launch_bounds__(WG) void svb_half_encode_kernel(ReadBatch b, uint32_t hdr)
+{
+    constexpr int VPL = 8;
+    constexpr int TILE = WG * VPL;
+    constexpr int STAGE_W = (TILE * 2 + 64) / 4;  // a tile emits at most 4 nibbles per value
+    __shared__ __attribute__((aligned(16))) uint32_t stage[STAGE_W];
+    __shared__ uint32_t wsum[4];
+
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    if (b.gate && b.gate[r] >= E_FIRST) {
+        if (tid == 0) b.result[r] = b.gate[r];
+        return;
+    }
+    const uint32_t n = b.src_size[r];  // one byte per value
+    const uint32_t cap = b.dst_cap[r];
+    const uint32_t keyLen = (n + 3u) >> 2;
+    {   // the reference requires the worst case of the byte codec (vbz/vbz.cpp:171-174)
+        const uint64_t worst = (uint64_t)keyLen + 4ull * n + hdr;
+        if (worst > cap) {
+            if (tid == 0) b.result[r] = worst > 0xFFFFFFF0ull ? E_INPUT_SIZE : E_DESTINATION_SIZE;
+            return;
+        }
+    }
+    const uint8_t* in = b.src + b.src_off[r];
+    uint8_t* out = b.dst + b.dst_off[r];
+    if (hdr) {
+        if (tid < 4) out[tid] = (uint8_t)(n >> (8 * tid));
+        out += 4;
+    }
+    uint8_t* keys = out;
+    uint8_t* data = out + keyLen;
+    for (int i = tid; i < STAGE_W; i += WG) stage[i] = 0;
+    wg_lds_barrier();
+
+    uint64_t flushed = 0;  // data bytes already written
+    uint32_t held = 0;     // nibbles held in stage[] (they start at nibble 0 of the stage)
+    for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+        const uint32_t i0 = t0 + (uint32_t)tid * VPL;
+        const int valid = i0 >= n ? 0 : (n - i0 >= (uint32_t)VPL ? VPL : (int)(n - i0));
+        int32_t prev = 0;
+        if (ZZ && valid > 0 && i0 > 0) prev = load_elem(in + i0 - 1, 1);
+        uint32_t keybits = 0, nibs = 0;
+        unsigned __int128 acc = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            if (k < valid) {
+                const int32_t x = load_elem(in + i0 + k, 1);
+                uint32_t u = (uint32_t)x;
+                if (ZZ) {
+                    const uint32_t d = (uint32_t)x - (uint32_t)prev;  // streamvbyte zigzag_delta_encode
+                    u = (d << 1) ^ (uint32_t)((int32_t)d >> 31);
+                    prev = x;
+                }
+                const uint32_t code = u == 0 ? 0u : (u < 16u ? 1u : (u < 256u ? 2u : 3u));
+                const uint32_t nn = (1u << code) >> 1;
+                const uint32_t bits = nn == 4 ? (u & 0xFFFFu) : (u & ((1u << (4 * nn)) - 1u));
+                acc |= (unsigned __int128)bits << (4 * nibs);
+                nibs += nn;
+                keybits |= code << (2 * k);
+            }
+        }
+        if (valid > 0) {
+            uint8_t* kp = keys + (i0 >> 2);
+            kp[0] = (uint8_t)keybits;
+            if (valid > 4) kp[1] = (uint8_t)(keybits >> 8);
+        }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(nibs, wsum, tot);
+        if (nibs) {
+            const uint32_t o = held + ex;  // nibble offset in the stage
+            const uint32_t sh = 4 * (o & 7);
+            const unsigned __int128 lo = acc << sh;
+            const uint32_t top = sh ? (uint32_t)(acc >> (128 - sh)) : 0u;
+            const uint32_t w[5] = { (uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)(lo >> 64), (uint32_t)(lo >> 96), top };
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (w[k]) atomicOr(&stage[(o >> 3) + k], w[k]);
+        }
+        wg_lds_barrier();
+        // write the complete 16-byte chunks, keep the rest (including a half-filled byte) at the front
+        const uint32_t endn = held + tot;
+        const uint32_t nch = endn >> 5;  // 32 nibbles per chunk
+        for (uint32_t c = tid; c < nch; c += WG) {
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + 4 * c);
+            __builtin_memcpy(data + flushed + 16ull * c, &v, 16);
+        }
+        const uint32_t remw = ((endn & 31u) + 7u) >> 3;  // words still in use behind the chunks
+        uint32_t keep = 0;
+        if ((uint32_t)tid < remw) keep = stage[4 * nch + tid];
+        wg_lds_barrier();
+        for (uint32_t i = tid; i < ((endn + 7u) >> 3) + 1u && i < (uint32_t)STAGE_W; i += WG) stage[i] = 0;
+        wg_lds_barrier();
+        if ((uint32_t)tid < remw) stage[tid] = keep;
+        flushed += 16ull * nch;
+        held = endn & 31u;
+        wg_lds_barrier();
+    }
+    const uint32_t tailBytes = (held + 1u) >> 1;
+    if ((uint32_t)tid < tailBytes) data[flushed + tid] = (uint8_t)(stage[tid >> 2] >> (8 * (tid & 3)));
+    if (tid == 0) b.result[r] = hdr + keyLen + (uint32_t)flushed + tailBytes;
+}
+
+template <bool ZZ>
+__global__ __launch_bounds__(WG) void svb_half_decode_kernel(ReadBatch b)
+{
+    constexpr int VPL = 8;
+    constexpr int TILE = WG * VPL;
+    constexpr int STAGE = TILE * 2 + 64;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
+    __shared__ uint32_t wsum[4];
+
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (b.gate && b.gate[r] >= E_FIRST) {
+        if (tid == 0) b.result[r] = b.gate[r];
+        return;
+    }
+    const uint32_t in_size = b.src_size[r];
+    if (in_size >= E_FIRST) {
+        if (tid == 0) b.result[r] = in_size;
+        return;
+    }
+    const uint32_t count = b.dst_cap[r];  // exact decoded byte count = value count
+    // half validate_stream (vbz/v1/vbz_streamvbyte_impl.h)
+    if (in_size == 0 || count == 0) {
+        if (tid == 0) b.result[r] = (in_size == count) ? 0u : E_STREAM;
+        return;
+    }
+    const uint32_t keyLen = (count + 3u) >> 2;
+    if (keyLen > in_size) {
+        if (tid == 0) b.result[r] = E_STREAM;
+        return;
+    }
+    const uint8_t* in = b.src + b.src_off[r];
+    const uint8_t* data = in + keyLen;
+    uint8_t* out = b.dst + b.dst_off[r];
+    const uint32_t dataBytes = in_size - keyLen;
+    const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
+
+    uint64_t posn = 0;  // nibbles consumed so far
+    uint32_t run = 0;   // running value of the delta chain
+    bool bad = false;
+    for (uint32_t t0 = 0; t0 < count; t0 += TILE) {
+        const uint32_t i0 = t0 + (uint32_t)tid * VPL;
+        const int valid = i0 >= count ? 0 : (count - i0 >= (uint32_t)VPL ? VPL : (int)(count - i0));
+        uint32_t keybits = 0;
+        if (valid > 0) {
+            const uint8_t* kp = in + (i0 >> 2);
+            keybits = kp[0];
+            if (valid > 4) keybits |= (uint32_t)kp[1] << 8;
+        }
+        uint32_t nibs = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+            if (k < valid) nibs += (1u << ((keybits >> (2 * k)) & 3u)) >> 1;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(nibs, wsum, tot);
+        if (((posn + tot + 1u) >> 1) > dataBytes) {  // stream shorter than its control bytes claim
+            bad = true;
+            break;
+        }
+        // stage the bytes that hold nibbles [posn, posn + tot): aligned 16-byte chunks, coalesced
+        const uint8_t* g0 = data + (posn >> 1);
+        const uint32_t mis = (uint32_t)((uintptr_t)g0 & 15u);
+        const uint8_t* ga = g0 - mis;
+        const uint32_t nbytes = (uint32_t)(((posn + tot + 1u) >> 1) - (posn >> 1));
+        const uint32_t nch = (mis + nbytes + 15u) >> 4;
+        for (uint32_t c = tid; c < nch; c += WG)
+            *reinterpret_cast<uint4*>(stage + 16u * c) = *reinterpret_cast<const uint4*>(ga + 16ull * c);
+        wg_lds_barrier();
+        uint32_t o = 2u * mis + (uint32_t)(posn & 1u) + ex;  // nibble offset in the stage
+        uint32_t s[VPL];
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            uint32_t v = 0;
+            if (k < valid) {
+                const uint32_t nn = (1u << ((keybits >> (2 * k)) & 3u)) >> 1;
+                if (nn) {
+                    const uint32_t w0 = stage32[o >> 3];
+                    const uint32_t w1 = stage32[(o >> 3) + 1];
+                    v = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (4u * (o & 7u)));
+                    v &= 0xFFFFu >> (16u - 4u * nn);
+                    o += nn;
+                }
+            }
+            if (ZZ) {
+                v = (v >> 1) ^ (0u - (v & 1u));
+                acc += v;
+                s[k] = acc;
+            } else {
+                s[k] = v;
+            }
+        }
+        uint32_t base = 0;
+        if (ZZ) {
+            uint32_t ttot;
+            base = run + block_excl_scan_u32(acc, wsum, ttot);
+            run += ttot;
+        } else {
+            wg_lds_barrier();  // stage is overwritten by the next tile
+        }
+#pragma unroll
+        for (int k = 0; k < VPL; ++k)
+            if (k < valid) out[i0 + k] = (uint8_t)(base + s[k]);
+        posn += tot;
+    }
+    if (tid == 0) b.result[r] = (bad || ((posn + 1u) >> 1) != dataBytes) ? E_STREAM : count;
+}
+
 template <typename K>
 hipError_t launch1(K kernel, const ReadBatch& b, hipStream_t s)
 {
@@ -378,10 +597,16 @@ hipError_t launch1(K kernel, const ReadBatch& b, hipStream_t s)
 
 }  // namespace
 
-hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, hipStream_t s)
+hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     dim3 g(b.n_reads), t(WG);
+    if (half) {  // v1, 1-byte integers: the nibble codec
+        if (integer_size != 1) return hipErrorInvalidValue;
+        if (zigzag) hipLaunchKernelGGL((svb_half_encode_kernel<true>), g, t, 0, s, b, hdr);
+        else hipLaunchKernelGGL((svb_half_encode_kernel<false>), g, t, 0, s, b, hdr);
+        return hipGetLastError();
+    }
     if (integer_size == 2 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<2, true, true>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
     else if (integer_size == 2) hipLaunchKernelGGL((svb_encode_kernel<2, false, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
     else if (integer_size == 4 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<4, true, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
@@ -392,8 +617,12 @@ hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, 
     return hipGetLastError();
 }
 
-hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, hipStream_t s)
+hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, bool half, hipStream_t s)
 {
+    if (half) {
+        if (integer_size != 1) return hipErrorInvalidValue;
+        return zigzag ? launch1(svb_half_decode_kernel<true>, b, s) : launch1(svb_half_decode_kernel<false>, b, s);
+    }
     if (integer_size == 2 && zigzag) return launch1(svb_decode_kernel<2, true, true>, b, s);
     if (integer_size == 2) return launch1(svb_decode_kernel<2, false, false>, b, s);
     if (integer_size == 4 && zigzag) return launch1(svb_decode_kernel<4, true, false>, b, s);

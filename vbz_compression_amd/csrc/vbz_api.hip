@@ -176,6 +176,9 @@ void dbg_end(vbz_gpu_ctx* c, uint32_t n, const char* what, unsigned long long* d
     fprintf(stderr, "\n");
 }
 
+// v1 codes 1-byte integers with the nibble codec (vbz/v1/vbz_streamvbyte.cpp:22-113)
+bool half_codec(const CompressionOptions* o) { return o->vbz_version == 1 && o->integer_size == 1; }
+
 bool valid_int_size(const CompressionOptions* o)  // vbz/vbz.cpp:44-50
 {
     return o->integer_size == 0 || o->integer_size == 1 || o->integer_size == 2 || o->integer_size == 4;
@@ -243,7 +246,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     }
     if (o->integer_size != 0 && o->zstd_compression_level == 0) {  // vbz.cpp:171-192: svb straight into dst
         Timed t(c, "svb_encode");
-        HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, s), "svb_encode launch");
+        HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, half_codec(o), s), "svb_encode launch");
         return 0;
     }
     if (o->integer_size == 0) {  // zstd only
@@ -274,7 +277,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     a.gate = gate;
     {
         Timed t(c, "svb_encode");
-        HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, s), "svb_encode launch");
+        HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, half_codec(o), s), "svb_encode launch");
     }
     ReadBatch z = rb;
     z.src = (const uint8_t*)c->scratch.p;
@@ -331,7 +334,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     }
     if (o->zstd_compression_level == 0) {
         Timed t(c, "svb_decode");
-        HIPCHK(c, launch_svb_decode(rb, (int)o->integer_size, o->perform_delta_zig_zag, s), "svb_decode launch");
+        HIPCHK(c, launch_svb_decode(rb, (int)o->integer_size, o->perform_delta_zig_zag, half_codec(o), s), "svb_decode launch");
         return 0;
     }
     if (o->integer_size == 0) {  // vbz.cpp:259-262: content larger than the destination -> DESTINATION_SIZE
@@ -370,15 +373,9 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     d.gate = gate;
     {
         Timed t(c, "svb_decode");
-        HIPCHK(c, launch_svb_decode(d, (int)o->integer_size, o->perform_delta_zig_zag, s), "svb_decode launch");
+        HIPCHK(c, launch_svb_decode(d, (int)o->integer_size, o->perform_delta_zig_zag, half_codec(o), s), "svb_decode launch");
     }
     return 0;
-}
-
-bool device_supported(const CompressionOptions* o)
-{
-    // the v1 nibble codec (1-byte integers only) is not implemented on the device yet
-    return !(o->vbz_version == 1 && o->integer_size == 1);
 }
 
 }  // namespace
@@ -479,7 +476,7 @@ int vbz_gpu_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compre
 {
     if (!c || !bt || !o) return -1;
     (void)hipSetDevice(c->device);
-    if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1) || !device_supported(o)) {
+    if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1)) {
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
     }
@@ -490,7 +487,7 @@ int vbz_gpu_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Comp
 {
     if (!c || !bt || !o) return -1;
     (void)hipSetDevice(c->device);
-    if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1) || !device_supported(o)) {
+    if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1)) {
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
     }
@@ -516,9 +513,9 @@ int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int inte
 {
     if (!c || !bt) return -1;
     (void)hipSetDevice(c->device);
-    if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || (version == 1 && integer_size == 1) || version > 1) return -2;
+    if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || version > 1 || version < 0) return -2;
     Timed t(c, "svb_encode");
-    HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, c->stream), "svb_encode launch");
+    HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, version == 1 && integer_size == 1, c->stream), "svb_encode launch");
     return 0;
 }
 
@@ -526,9 +523,9 @@ int vbz_gpu_svb_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int in
 {
     if (!c || !bt) return -1;
     (void)hipSetDevice(c->device);
-    if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || (version == 1 && integer_size == 1) || version > 1) return -2;
+    if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || version > 1 || version < 0) return -2;
     Timed t(c, "svb_decode");
-    HIPCHK(c, launch_svb_decode(to_rb(bt), integer_size, zigzag != 0, c->stream), "svb_decode launch");
+    HIPCHK(c, launch_svb_decode(to_rb(bt), integer_size, zigzag != 0, version == 1 && integer_size == 1, c->stream), "svb_decode launch");
     return 0;
 }
 
@@ -748,10 +745,6 @@ vbz_size_t vbz_compress(void const* source, vbz_size_t source_size, void* destin
     } else if (o->zstd_compression_level == 0 && source_size > destination_capacity) {
         return VBZ_DESTINATION_SIZE_ERROR;
     }
-    if (!device_supported(o)) {
-        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
-        return VBZ_DEVICE_ERROR;
-    }
     const vbz_size_t bound = vbz_max_compressed_size(source_size, o);
     const vbz_size_t dev_cap = destination_capacity < bound ? destination_capacity : bound;
     return run_one(true, source, source_size, destination, destination_capacity, dev_cap, o, 0);
@@ -764,10 +757,6 @@ vbz_size_t vbz_decompress(void const* source, vbz_size_t source_size, void* dest
     // the reference checks the version only after the zstd stage (vbz.cpp:282-290); an invalid version
     // can never succeed, so it is reported up front
     if (o->integer_size != 0 && o->vbz_version > 1) return VBZ_VERSION_ERROR;
-    if (!device_supported(o)) {
-        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
-        return VBZ_DEVICE_ERROR;
-    }
     return run_one(false, source, source_size, destination, destination_size, destination_size, o, 0);
 }
 
@@ -784,10 +773,6 @@ vbz_size_t vbz_compress_sized(void const* source, vbz_size_t source_size, void* 
     } else if (o->zstd_compression_level == 0 && source_size > destination_capacity - 4) {
         return VBZ_DESTINATION_SIZE_ERROR;
     }
-    if (!device_supported(o)) {
-        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
-        return VBZ_DEVICE_ERROR;
-    }
     const vbz_size_t bound = vbz_max_compressed_size(source_size, o);
     const vbz_size_t dev_cap = destination_capacity < bound ? destination_capacity : bound;
     return run_one(true, source, source_size, destination, destination_capacity, dev_cap, o, 1);
@@ -802,10 +787,6 @@ vbz_size_t vbz_decompress_sized(void const* source, vbz_size_t source_size, void
     memcpy(&original, source, 4);
     if (destination_capacity < original) return VBZ_DESTINATION_SIZE_ERROR;
     if (o->integer_size != 0 && o->vbz_version > 1) return VBZ_VERSION_ERROR;
-    if (!device_supported(o)) {
-        set_error(nullptr, "vbz_version 1 with integer_size 1 (nibble codec) is not implemented on the device");
-        return VBZ_DEVICE_ERROR;
-    }
     return run_one(false, source, source_size, destination, destination_capacity, destination_capacity, o, 1);
 }
 

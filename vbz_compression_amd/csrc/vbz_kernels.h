@@ -38,8 +38,9 @@ struct ReadBatch
 // integer_size in {1,2,4}; zigzag; half = v1 nibble codec (not implemented on the device yet).
 // hdr: 0, or 4 to prepend / skip the sized header (u32 LE original size) in front of the svb stream.
 // strict_cap: apply the reference's worst-case capacity rule (keys + 4 bytes per value) to dst_cap.
-hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, hipStream_t s);
-hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, hipStream_t s);
+// half: the v1 nibble codec for 1-byte integers (vbz/v1/vbz_streamvbyte_impl.h)
+hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, hipStream_t s);
+hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, bool half, hipStream_t s);
 
 // ---- zstd-format entropy stage (zstd_encode.hip / zstd_decode.hip) -----------------------------
 // encode: frame content = src read; key_elem = integer size whose key section (ceil(n/4) bytes, n
