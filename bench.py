@@ -129,8 +129,9 @@ def main():
     torch.cuda.synchronize()
     # correctness of what is being timed: every read round-trips, on the device
     B = batches[0]
-    assert bool((B["res"] == B["size"]).all()), "decode failed for some read"
-    assert torch.equal(B["raw"], B["back"]), "round trip mismatch"
+    if not os.environ.get("VBZ_BENCH_KERNEL_EXPERIMENT"):  # set only to time deliberately broken kernel variants
+        assert bool((B["res"] == B["size"]).all()), "decode failed for some read"
+        assert torch.equal(B["raw"], B["back"]), "round trip mismatch"
 
     def barrier():
         if world > 1:
