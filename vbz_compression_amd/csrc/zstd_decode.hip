@@ -60,7 +60,7 @@ struct DecLds
 };
 // one wave per workgroup: the frame's LDS state.  At namespace scope so that functions that are real calls
 // (not inlined, to keep the kernel's register footprint down) still address it as LDS.
-__shared__ DecLds L;
+__shared__ __attribute__((aligned(16))) DecLds L;
 
 // ctl slots
 enum { C_ERR = 0, C_A, C_B, C_C, C_D, C_E, C_F, C_G, C_H, C_I, C_J, C_K };
@@ -1255,7 +1255,7 @@ __device__ __noinline__ uint32_t zero_run_chain_segments(const uint8_t* bs, uint
 __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint32_t n, int lane)
 {
     for (uint32_t i = lane; i < n; i += WAVE) lds[i] = g[i];
-    __syncthreads();
+    wave_lds_sync();
 }
 
 #ifndef VBZ_DEC_WAVES
@@ -1398,14 +1398,22 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         if (pos + 3 > n) FAIL();
         PHASE(0);
         // 24 staged bytes cover the block header, the literals header and (treeless blocks) the jump table
-        if (pf_ok) {
-            __syncthreads();
+        if (pf_ok) {  // (one wave: LDS hand-overs need no vmcnt drain, the requests below stay in flight)
+            wave_lds_sync();
             if (lane < 24) L.u.p.hbuf[lane] = (uint8_t)pf_byte;
-            __syncthreads();
+            wave_lds_sync();
         } else {
             stage_bytes(L.u.p.hbuf, src + pos, (n - pos) < 24 ? (n - pos) : 24, lane);
         }
-        const uint32_t bh = L.u.p.hbuf[0] | ((uint32_t)L.u.p.hbuf[1] << 8) | ((uint32_t)L.u.p.hbuf[2] << 16);
+        // the 24 bytes in registers (one LDS round trip); hwin(o) = the eight bytes from offset o <= 16
+        const uint64_t H0 = *reinterpret_cast<const uint64_t*>(L.u.p.hbuf), H1 = *reinterpret_cast<const uint64_t*>(L.u.p.hbuf + 8),
+                       H2 = *reinterpret_cast<const uint64_t*>(L.u.p.hbuf + 16);
+        auto hwin = [&](uint32_t o) -> uint64_t {
+            const uint64_t a = o < 8 ? H0 : H1, c = o < 8 ? H1 : H2;
+            const uint32_t sh = 8u * (o & 7u);
+            return sh ? ((a >> sh) | (c << (64u - sh))) : a;
+        };
+        const uint32_t bh = (uint32_t)H0 & 0xFFFFFFu;
         pos += 3;
         const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
         if (btype == 3) FAIL();
@@ -1435,19 +1443,18 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             uint32_t ltype, lh = 0, regen = 0, csize = 0, streams = 1, tree_used = 0, nw = 0, tlog = 0;
             uint32_t jt[3] = { 0, 0, 0 };  // jump table when it sits right behind the header (treeless blocks)
             {
-                const uint8_t* h = L.u.p.hbuf + 3;
-                const uint32_t fmt = (h[0] >> 2) & 3;
-                ltype = h[0] & 3;
+                const uint64_t v = hwin(3);  // h[0..7] of the literals section
+                const uint32_t h0 = (uint32_t)v & 0xFF;
+                const uint32_t fmt = (h0 >> 2) & 3;
+                ltype = h0 & 3;
                 if (ltype < 2) {
-                    if (fmt == 0 || fmt == 2) { lh = 1; regen = h[0] >> 3; }
-                    else if (fmt == 1) { lh = 2; regen = (h[0] >> 4) | ((uint32_t)h[1] << 4); }
-                    else { lh = 3; regen = (h[0] >> 4) | ((uint32_t)h[1] << 4) | ((uint32_t)h[2] << 12); }
+                    if (fmt == 0 || fmt == 2) { lh = 1; regen = h0 >> 3; }
+                    else if (fmt == 1) { lh = 2; regen = ((uint32_t)v & 0xFFFFu) >> 4; }
+                    else { lh = 3; regen = ((uint32_t)v & 0xFFFFFFu) >> 4; }
                     if (lh > bsize) FAIL();
                     csize = ltype == 0 ? regen : 1;
                 } else {
                     if (bsize < 5) FAIL();  // libzstd: srcSize >= 5 for compressed literals
-                    const uint64_t v = h[0] | ((uint64_t)h[1] << 8) | ((uint64_t)h[2] << 16) | ((uint64_t)h[3] << 24) |
-                                       ((uint64_t)h[4] << 32);
                     if (fmt < 2) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; streams = fmt == 0 ? 1 : 4; }
                     else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; streams = 4; }
                     else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; streams = 4; }
@@ -1457,9 +1464,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 if ((uint64_t)lh + csize > bsize) FAIL();
                 if (ltype == 3 && !huf_valid) FAIL();
                 if (ltype == 3) {
-                    jt[0] = h[lh] | ((uint32_t)h[lh + 1] << 8);
-                    jt[1] = h[lh + 2] | ((uint32_t)h[lh + 3] << 8);
-                    jt[2] = h[lh + 4] | ((uint32_t)h[lh + 5] << 8);
+                    const uint64_t j = hwin(3 + lh);
+                    jt[0] = (uint32_t)j & 0xFFFFu;
+                    jt[1] = (uint32_t)(j >> 16) & 0xFFFFu;
+                    jt[2] = (uint32_t)(j >> 32) & 0xFFFFu;
                 }
             }
             // ---- sequences section header (3.1.1.3.2.1): its first bytes are requested now, used further down
@@ -1470,7 +1478,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             uint64_t sq8;  // sq[0..7]; bytes past the block are never looked at (the arena is readable 16 bytes past its end)
             __builtin_memcpy(&sq8, sq, 8);
 #define SQB(i) ((uint32_t)(sq8 >> (8 * (i))) & 0xFFu)
-            __syncthreads();
+            wave_lds_sync();
             PHASE(6);
             if (ltype == 2) {
                 PHASE(0);
@@ -1592,7 +1600,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     }
                     ntask += 4;
                 }
-                __syncthreads();
+                wave_lds_sync();
             }
             PHASE(7);
             if (!has_seq) {
