@@ -875,6 +875,26 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
             fetch_batch(p, nextbyte, pend);
         }
         // ---- one period: groups of 16 symbols, each stored with one 16-byte write
+        if (PERIOD == 32 && cnt >= 32) {
+            // a whole period: 32 bytes leave with two adjacent 16-byte stores (one full 32-byte sector per lane)
+            uint32_t ow[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                uint32_t e1, e2, e3, e4;
+                HUF_PAIR(e1, e2);
+                n -= (int32_t)((e1 >> 8) + (e2 >> 8));
+                HUF_PAIR(e3, e4);
+                n -= (int32_t)((e3 >> 8) + (e4 >> 8));
+                ow[q] = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((e3 & 0xFFu) << 16) | (e4 << 24);
+            }
+            typedef __attribute__((address_space(1), aligned(1))) u32x4 gs4;
+            const u32x4 ov0 = { ow[0], ow[1], ow[2], ow[3] }, ov1 = { ow[4], ow[5], ow[6], ow[7] };
+            *(gs4*)o = ov0;
+            *(gs4*)(o + 16) = ov1;
+            o += 32;
+            cnt -= 32;
+            continue;
+        }
 #pragma unroll
         for (int g = 0; g < PERIOD / 16; ++g) {
             if (cnt >= 16) {
