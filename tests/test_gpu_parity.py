@@ -200,6 +200,41 @@ def test_zstd_decode_libzstd_frames():
         assert _same(g, np.ascontiguousarray(w)), (len(w), len(f))
 
 
+def test_zstd_decode_foreign_zero_run_frames():
+    """Frames libzstd writes for data that looks like a control-byte region (long zero runs between short bursts):
+    their sequences are mostly 'repeat offset 1' matches, which is what the decoder's out-of-order zero-run path
+    keys on -- with libzstd's own FSE tables, literal lengths of zero, other offsets in between.  Whatever path a
+    block takes (parallel placement, serial chain, restart in order), the bytes must be libzstd's."""
+    import gpu_util as G
+
+    if O.lib().vbo_zstd_version() is None:
+        pytest.skip("no libzstd on this box")
+    rng = np.random.default_rng(77)
+    contents = []
+    for n, p_burst in ((30000, 0.01), (120000, 0.004), (250000, 0.02), (5000, 0.05)):
+        a = np.zeros(n, np.uint8)
+        starts = np.nonzero(rng.random(n) < p_burst)[0]
+        for s0 in starts:
+            ln = min(int(rng.integers(1, 12)), n - int(s0))
+            a[int(s0) : int(s0) + ln] = rng.integers(1, 86, ln, dtype=np.uint8)
+        contents.append(a)
+        b = a.copy()
+        m = min(4000, n - n // 3)
+        b[n // 3 : n // 3 + m] = np.tile(rng.integers(0, 256, 40, dtype=np.uint8), 100)[:m]   # real matches in the middle
+        contents.append(b)
+    c = np.full(60000, 7, np.uint8)                                                              # runs of a non-zero byte
+    c[rng.integers(0, 60000, 300)] = rng.integers(0, 256, 300, dtype=np.uint8)
+    contents.append(c)
+    frames, want = [], []
+    for a in contents:
+        for level in (1, 2, 3, 5):
+            frames.append(O.zstd_compress(a, level))
+            want.append(a)
+    got = G.zstd_decompress(frames, [len(w) for w in want])
+    for f, w, g in zip(frames, want, got):
+        assert _same(g, w), (len(w), len(f))
+
+
 def test_zstd_decode_shipped_fast5_chunks():
     # decode pins: python/test/test_vbz_filter.py:57-73 (frames written by the reference itself)
     import gpu_util as G
