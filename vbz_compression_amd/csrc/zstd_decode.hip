@@ -131,95 +131,6 @@ struct BitReader  // backward bit stream (RFC 8878 4.1): bits are consumed from 
     __device__ __forceinline__ bool finished() const { return !over && avail == 0 && nextbyte == 0; }
 };
 
-// Same stream, but the bytes arrive in 16-byte chunks requested one chunk ahead, so a serial consumer
-// (lane 0 walking the FSE states of a sequences section) never waits for memory.
-struct BitReaderPF
-{
-    const uint8_t* p;
-    uint32_t nextbyte;
-    uint64_t buf;
-    int32_t avail;
-    bool over;
-    uint32_t c0, c1, c2, c3;  // current chunk, c3 = highest addresses = consumed first
-    int cw;                   // dwords left in the current chunk
-    uint32_t n0, n1, n2, n3;  // the chunk below it, already requested
-    bool nvalid;
-
-    __device__ __forceinline__ void request()
-    {
-        nvalid = nextbyte >= 16;
-        if (nvalid) {
-            uint4 v;
-            __builtin_memcpy(&v, p + nextbyte - 16, 16);
-            n0 = v.x; n1 = v.y; n2 = v.z; n3 = v.w;
-            nextbyte -= 16;
-        }
-    }
-    __device__ __forceinline__ bool init(const uint8_t* ptr, uint32_t n)
-    {
-        over = false;
-        p = ptr;
-        buf = 0;
-        avail = 0;
-        nextbyte = 0;
-        cw = 0;
-        nvalid = false;
-        c0 = c1 = c2 = c3 = n0 = n1 = n2 = n3 = 0;
-        if (n == 0) return false;
-        const uint32_t last = ptr[n - 1];
-        if (last == 0) return false;
-        const int hb = 31 - __clz((int)last);
-        nextbyte = n - 1;
-        buf = hb ? ((uint64_t)(last & ((1u << hb) - 1u)) << (64 - hb)) : 0ull;
-        avail = hb;
-        request();
-        refill();
-        return true;
-    }
-    __device__ __forceinline__ void refill()
-    {
-        if (avail > 32) return;
-        uint32_t w = 0;
-        int got = 32;
-        if (cw == 0 && nvalid) {
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-            cw = 4;
-            request();
-        }
-        if (cw > 0) {
-            w = c3;
-            c3 = c2; c2 = c1; c1 = c0;
-            --cw;
-        } else if (nextbyte >= 4) {
-            __builtin_memcpy(&w, p + nextbyte - 4, 4);
-            nextbyte -= 4;
-        } else if (nextbyte > 0) {
-            for (uint32_t k = 0; k < nextbyte; ++k) w |= (uint32_t)p[k] << (8 * (k + 4 - nextbyte));
-            got = 8 * (int)nextbyte;
-            nextbyte = 0;
-        } else {
-            return;
-        }
-        buf |= (uint64_t)w << (32 - avail);
-        avail += got;
-    }
-    __device__ __forceinline__ uint32_t read(int nb)  // nb <= 32
-    {
-        refill();
-        const uint32_t v = nb ? (uint32_t)(buf >> (64 - nb)) : 0u;
-        if (nb > avail) {
-            over = true;
-            buf = 0;
-            avail = 0;
-        } else {
-            buf <<= nb;
-            avail -= nb;
-        }
-        return v;
-    }
-    __device__ __forceinline__ bool finished() const { return !over && avail == 0 && nextbyte == 0 && cw == 0 && !nvalid; }
-};
-
 __device__ __forceinline__ int hbit(uint32_t v) { return 31 - __clz((int)v); }
 // wave-uniform helpers: values the compiler keeps in scalar registers, and reads of one lane of a vector register
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
