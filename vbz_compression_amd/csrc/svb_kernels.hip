@@ -176,6 +176,19 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         uint32_t tot;
         const uint32_t ex = block_excl_scan_u32(L, wsum, tot);
         uint32_t o = (uint32_t)(P - F) + ex;
+        if (I16ZZ && t0 + TILE <= n) {
+            // full tile, one or two bytes per value: both bytes are always written and a one-byte value's second
+            // byte is overwritten by the lane's next value (a later instruction) -- no branches; only the lane's
+            // last value must not touch the next lane's first byte
+#pragma unroll
+            for (int k = 0; k < VPL - 1; ++k) {
+                stage[o] = (uint8_t)u[k];
+                stage[o + 1] = (uint8_t)(u[k] >> 8);
+                o += 1u + (u[k] > 0xFFu ? 1u : 0u);
+            }
+            stage[o] = (uint8_t)u[VPL - 1];
+            if (u[VPL - 1] > 0xFFu) stage[o + 1] = (uint8_t)(u[VPL - 1] >> 8);
+        } else {
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             if (k < valid) {
@@ -187,6 +200,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
                     if (v > 0xFFFFFFu) stage[o++] = (uint8_t)(v >> 24);
                 }
             }
+        }
         }
         wg_lds_barrier();
         const uint32_t endidx = (uint32_t)(P - F) + tot;
