@@ -81,18 +81,19 @@ __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
     for (int i = 0; i < n; ++i) p[i] = (uint8_t)(v >> (8 * i));
 }
 
-// histogram of in[0..n) into L.hist using all 64 lanes; zero bytes are counted in registers
+// histogram of in[0..n) into L.hist using all 64 lanes.  LDS atomics on a shared bin serialise, so four lane
+// groups count into four private copies (in the table-construction workspace, idle at this point) that are summed at
+// the end; every byte is one branch-free ds_add.
 __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane)
 {
-    for (int i = lane; i < 256; i += WAVE) L.hist[i] = 0;
+    static_assert(sizeof(HufBuildWksp) >= 4 * 256 * sizeof(uint32_t), "the sub-histograms live in the tree workspace");
+    uint32_t* sub = reinterpret_cast<uint32_t*>(&L.hw);
+    for (int i = lane; i < 4 * 256; i += WAVE) sub[i] = 0;
     wave_lds_sync();
-    uint32_t zeros = 0;
+    uint32_t* mine = sub + 256 * (lane & 3);
     const uint32_t head = (uint32_t)((16u - ((uintptr_t)in & 15u)) & 15u);
     const uint32_t h = head < n ? head : n;
-    if ((uint32_t)lane < h) {
-        uint8_t v = in[lane];
-        if (v) atomicAdd(&L.hist[v], 1u); else zeros++;
-    }
+    if ((uint32_t)lane < h) atomicAdd(&mine[in[lane]], 1u);
     const uint32_t nvec = (n - h) >> 4;
     const uint4* vp = reinterpret_cast<const uint4*>(in + h);
     for (uint32_t c0 = 0; c0 < nvec; c0 += 4 * WAVE) {
@@ -110,23 +111,15 @@ __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int l
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        uint32_t v = (w[k] >> (8 * j)) & 0xFFu;
-                        if (v) atomicAdd(&L.hist[v], 1u); else zeros++;
-                    }
+                    for (int j = 0; j < 4; ++j) atomicAdd(&mine[(w[k] >> (8 * j)) & 0xFFu], 1u);
                 }
             }
         }
     }
     const uint32_t tail0 = h + (nvec << 4);
-    if (tail0 + (uint32_t)lane < n) {
-        uint8_t v = in[tail0 + lane];
-        if (v) atomicAdd(&L.hist[v], 1u); else zeros++;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) zeros += __shfl_xor(zeros, d, 64);
+    if (tail0 + (uint32_t)lane < n) atomicAdd(&mine[in[tail0 + lane]], 1u);
     wave_lds_sync();
-    if (lane == 0) L.hist[0] += zeros;
+    for (int i = lane; i < 256; i += WAVE) L.hist[i] = sub[i] + sub[256 + i] + sub[512 + i] + sub[768 + i];
     wave_lds_sync();
 }
 
