@@ -20,6 +20,8 @@
  *     (reference vbz/vbz.cpp:321-329 turns VBZ_INPUT_SIZE_ERROR into 2).
  *   - the zstd stage is this library's own encoder: frames are standard zstd (RFC 8878) and decode
  *     with any libzstd / the reference's vbz_decompress, but are not byte-identical to libzstd's.
+ *     A compressed buffer may end in one zstd skippable frame (magic 0x184D2A5B, <= 272 bytes) with
+ *     checkpoints for this library's parallel decoder; libzstd skips it (RFC 8878 3.1.2).
  */
 #ifndef VBZ_H_MI355X
 #define VBZ_H_MI355X
