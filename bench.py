@@ -36,7 +36,7 @@ def cpu_baseline(min_seconds=8.0, n_reads=2048):
     opts = O.options(True, 2, 1, 1)
     one = O.bench_roundtrip(min(n_reads, 64), 1, 1.0, opts)
     allc = O.bench_roundtrip(n_reads, cores, min_seconds, opts)
-    return {
+    out = {
         "value": round(allc["raw_bytes"] / allc["best_s"] / 1e6, 1),
         "unit": "MB/s",
         "cores": cores,
@@ -48,6 +48,25 @@ def cpu_baseline(min_seconds=8.0, n_reads=2048):
         "ratio": round(allc["raw_bytes"] / allc["comp_bytes"], 4),
         "encode_share": round(allc["enc_thread_s"] / (allc["enc_thread_s"] + allc["dec_thread_s"]), 3),
     }
+    # BASELINE.json's target is stated against a single socket: time one socket's hardware threads as well
+    # (the worker pthreads inherit the affinity set here)
+    try:
+        socket0 = []
+        for cpu in sorted(os.sched_getaffinity(0)):
+            with open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % cpu) as f:
+                if int(f.read()) == 0:
+                    socket0.append(cpu)
+        if socket0 and len(socket0) < cores:
+            saved = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, socket0)
+            try:
+                s0 = O.bench_roundtrip(n_reads, len(socket0), min_seconds / 2, opts)
+            finally:
+                os.sched_setaffinity(0, saved)
+            out["single_socket"] = {"value": round(s0["raw_bytes"] / s0["best_s"] / 1e6, 1), "unit": "MB/s", "cores": len(socket0)}
+    except OSError:
+        pass
+    return out
 
 
 def committed_traffic(kernel):
@@ -229,6 +248,8 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
+            if "single_socket" in out["cpu_baseline"]:
+                out["vs_single_socket_cpu"] = round(out["value"] / out["cpu_baseline"]["single_socket"]["value"], 2)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
