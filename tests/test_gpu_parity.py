@@ -398,6 +398,24 @@ def test_c_abi_cross_codec_round_trips():
                             assert g.tobytes() == r.tobytes()   # no entropy stage: byte-identical output
 
 
+def test_config3_uint32_ten_million_elements():
+    """BASELINE.json configs[3]: uint32, no zig-zag (UD=32020,5,0,0,4,0,3), one 10M-element buffer through the
+    single-buffer C ABI: many passes of blocks in one frame, every code length; cross-decoded both ways."""
+    from vbz_compression_amd import _lib, vbz
+
+    a = O.synth_u32(5, 3, 10_000_000)
+    go = _lib.CompressionOptions(False, 4, 3, 0)
+    oo = O.options(False, 4, 3, 0)
+    g = vbz.compress_raw(a, go, sized=True)
+    assert not isinstance(g, int), g
+    back = O.decompress(g, a.nbytes, oo, sized=True)
+    assert not isinstance(back, int) and back.tobytes() == a.tobytes()
+    r = O.compress(a, oo, sized=True)
+    mine = vbz.decompress_raw(r, a.nbytes, go, sized=True)
+    assert not isinstance(mine, int) and mine.tobytes() == a.tobytes()
+    assert abs(len(g) / len(r) - 1.0) < 0.03, (len(g), len(r))   # no control-byte sequences on this path: Huffman only
+
+
 def test_c_abi_error_behaviour():
     from vbz_compression_amd import _lib, vbz
 
