@@ -111,12 +111,28 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
     for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
         const uint32_t i0 = t0 + (uint32_t)tid * VPL;
         const int valid = i0 >= n ? 0 : (n - i0 >= (uint32_t)VPL ? VPL : (int)(n - i0));
-        int32_t x[VPL];
         const uint4 q = qnext;
         {
             const uint32_t i1 = i0 + TILE;
             if (in_aligned && i1 < n && n - i1 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i1 * ELEM);
         }
+        uint32_t u[VPL];
+        if (I16ZZ && in_aligned && t0 + TILE <= n) {
+            // full int16 tile: wrap-around delta and 16-bit zig-zag (sse3.h:432-440) on two samples per instruction
+            typedef short s16x2 __attribute__((ext_vector_type(2)));
+            const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+            uint32_t pw = (uint32_t)__shfl_up((int)w[3], 1, 64);  // its top half: the sample in front of this lane's first
+            if (lane == 0) pw = i0 == 0 ? 0u : ((uint32_t)(uint16_t)load_elem(in + (size_t)(i0 - 1) * ELEM, ELEM) << 16);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t prevw = __builtin_amdgcn_alignbit(w[k], k ? w[k - 1] : pw, 16);
+                const s16x2 d = __builtin_bit_cast(s16x2, w[k]) - __builtin_bit_cast(s16x2, prevw);
+                const uint32_t zz = __builtin_bit_cast(uint32_t, (s16x2)((d << (s16x2)1) ^ (d >> (s16x2)15)));
+                u[(2 * k) % VPL] = zz & 0xFFFFu;
+                u[(2 * k + 1) % VPL] = zz >> 16;
+            }
+        } else {
+        int32_t x[VPL];
         if (valid == VPL && in_aligned) {
             const uint32_t w[4] = { q.x, q.y, q.z, q.w };
             if (ELEM == 4) {
@@ -133,7 +149,6 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
 #pragma unroll
             for (int k = 0; k < VPL; ++k) x[k] = k < valid ? load_elem(in + (size_t)(i0 + k) * ELEM, ELEM) : 0;
         }
-        uint32_t u[VPL];
         if (ZZ) {
             // previous sample: neighbouring lane's last value; wave lane 0 re-reads it from memory
             int32_t prev = __shfl_up(x[VPL - 1], 1, 64);
@@ -153,6 +168,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         } else {
 #pragma unroll
             for (int k = 0; k < VPL; ++k) u[k] = (uint32_t)x[k];
+        }
         }
         uint32_t keybits = 0, L = 0;
 #pragma unroll
