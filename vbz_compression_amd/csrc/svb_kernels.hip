@@ -171,6 +171,17 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         }
         }
         uint32_t keybits = 0, L = 0;
+        if (I16ZZ && in_aligned && t0 + TILE <= n) {  // full tile of one- or two-byte values
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const uint32_t code = u[k] >> 8 ? 1u : 0u;
+                keybits |= code << (2 * k);
+                L += code;
+            }
+            L += VPL;
+            const uint16_t kk = (uint16_t)keybits;
+            __builtin_memcpy(keys + (i0 >> 2), &kk, 2);
+        } else {
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             uint32_t code = (u[k] > 0xFFu) + (u[k] > 0xFFFFu) + (u[k] > 0xFFFFFFu);
@@ -179,8 +190,9 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
                 L += code + 1;
             }
         }
+        }
         // control bytes: VPL/4 per lane, contiguous across the wave
-        if (valid > 0) {
+        if (!(I16ZZ && in_aligned && t0 + TILE <= n) && valid > 0) {
             uint8_t* kp = keys + (i0 >> 2);
             if (VPL == 8 && valid > 4) {
                 uint16_t kk = (uint16_t)keybits;
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         uint32_t tot;
         const uint32_t ex = block_excl_scan_u32(L, wsum, tot);
         uint32_t o = (uint32_t)(P - F) + ex;
-        if (I16ZZ && t0 + TILE <= n) {
+        if (I16ZZ && in_aligned && t0 + TILE <= n) {
             // full tile, one or two bytes per value: both bytes are always written and a one-byte value's second
             // byte is overwritten by the lane's next value (a later instruction) -- no branches; only the lane's
             // last value must not touch the next lane's first byte
