@@ -351,6 +351,20 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
         const bool body = I16ZZ && ((i0 >> 3) < (count >> 3)) && (dataBytes - (pos + ex) >= 32u);
         uint32_t s[VPL];
         uint32_t acc = 0;
+        // full tile of one- and two-byte codes (what the encoder writes for int16): values stay below 2^16, where the
+        // body and the tail of the reference agree, so the lane just picks up its bytes
+        if (I16ZZ && t0 + TILE <= count && !__any((keybits & 0xAAAAu) != 0)) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const uint32_t two = (keybits >> (2 * k)) & 1u;
+                const uint32_t lo = stage[o], hi = stage[o + 1];
+                uint32_t v = lo | (two ? hi << 8 : 0u);
+                o += 1u + two;
+                v = (v >> 1) ^ (0u - (v & 1u));
+                acc += v;
+                s[k] = acc;
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
             uint32_t v = 0;
@@ -370,6 +384,7 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
             } else {
                 s[k] = v;
             }
+        }
         }
         uint32_t base = 0;
         if (ZZ) {
