@@ -797,22 +797,25 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 auto load_chunk = [&](uint32_t sbeg, uint32_t scount, uint32_t dn, uint32_t (&w)[STEP_DW]) {
 #pragma unroll
                     for (int k = 0; k < STEP_DW; ++k) w[k] = 0;
-                    const int64_t hi = (int64_t)sbeg + scount - dn - STEP_LANE * (int64_t)lane;
-                    const int64_t lo = hi - STEP_LANE;
-                    if (hi > (int64_t)sbeg) {
-                        if ((int64_t)r0 + lo >= 0) {
+                    // symbols of the stream at or below the end of this lane's chunk (streams are at most 128 KB:
+                    // 32-bit arithmetic relative to the stream's start)
+                    const int32_t room = (int32_t)(scount - dn) - STEP_LANE * lane;
+                    if (room > 0) {
+                        const uint8_t* p = rin + sbeg + room - STEP_LANE;  // may start before the stream:
+                        const bool headroom = (uint64_t)r0 + sbeg >= (uint32_t)STEP_LANE;  // ... but not before the input buffer
+                        if (room >= STEP_LANE || headroom) {
                             uint4 v0;
-                            __builtin_memcpy(&v0, rin + lo, 16);       // may start before the stream:
+                            __builtin_memcpy(&v0, p, 16);              // those bytes are masked when used
                             w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
-                            if (STEP_DW == 8) {                        // those bytes are masked when used
+                            if (STEP_DW == 8) {
                                 uint4 v1;
-                                __builtin_memcpy(&v1, rin + lo + 16, 16);
+                                __builtin_memcpy(&v1, p + 16, 16);
                                 w[4 % STEP_DW] = v1.x; w[5 % STEP_DW] = v1.y; w[6 % STEP_DW] = v1.z; w[7 % STEP_DW] = v1.w;
                             }
-                        } else {  // never read in front of the input buffer
+                        } else {
 #pragma unroll
                             for (int k = 0; k < STEP_LANE; ++k) {
-                                const uint32_t byte = (lo + k >= (int64_t)sbeg) ? (uint32_t)rin[lo + k] : 0u;
+                                const uint32_t byte = (room - STEP_LANE + k >= 0) ? (uint32_t)p[k] : 0u;
                                 w[k >> 2] |= byte << (8 * (k & 3));
                             }
                         }
@@ -842,7 +845,6 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         spos = ocur + hl;
                     }
                     const uint32_t scnt = L.scnt[st];
-                    const uint32_t sb = L.sbeg[st];
                     uint8_t* sop = out + spos;
                     // next work item
                     uint32_t nst = st, ndone = done + STEP_SYMS;
@@ -854,8 +856,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, nxt);
                     // this lane's symbols: positions [lo, hi) of the region, packed from hi-1 down to lo;
                     // the first `skip` of its 32 bytes lie before the stream (or the lane is past its start)
-                    const int64_t hi = (int64_t)sb + scnt - done - STEP_LANE * (int64_t)lane;
-                    const int64_t room = hi - (int64_t)sb;
+                    const int32_t room = (int32_t)(scnt - done) - STEP_LANE * lane;
                     const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
                     uint32_t ent[STEP_LANE];
                     uint32_t T = 0;
