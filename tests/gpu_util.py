@@ -5,6 +5,9 @@ import torch
 from vbz_compression_amd import _lib, batch
 
 _codec = None
+SRC_ALIGN = 64   # tests may lower these to exercise unaligned arena offsets
+DST_ALIGN = 64
+SRC_SKEW = 0     # extra bytes in front of the first buffer
 
 
 def codec():
@@ -14,9 +17,12 @@ def codec():
     return _codec
 
 
-def _pack(bufs, align=64):
+def _pack(bufs, align=None):
+    align = SRC_ALIGN if align is None else align
     sizes = [int(b.nbytes) for b in bufs]
     off, total = batch.layout(sizes, align)
+    off = off + SRC_SKEW
+    total += SRC_SKEW
     arena = np.zeros(total + 64, np.uint8)
     for b, o in zip(bufs, off.tolist()):
         arena[o : o + b.nbytes] = np.frombuffer(np.ascontiguousarray(b).tobytes(), np.uint8)
@@ -31,7 +37,7 @@ def run_stage(fn, bufs, caps, **kw):
     src = torch.from_numpy(arena).to(dev)
     src_off = off.to(dev)
     src_size = torch.tensor(sizes, dtype=torch.int64).to(torch.int32).to(dev)
-    doff, dtotal = batch.layout([int(x) + 32 for x in caps], 64)
+    doff, dtotal = batch.layout([int(x) + 32 for x in caps], DST_ALIGN)
     dst = torch.zeros(dtotal + 64, dtype=torch.uint8, device=dev)
     dst_off = doff.to(dev)
     caps64 = torch.tensor([int(x) for x in caps], dtype=torch.int64)
