@@ -6,12 +6,17 @@
 // literals, treeless blocks, raw blocks: SURVEY.md section 8a "zstd frame features") as well as the
 // frames of zstd_encode.hip.  oracle/zstd_restate.c is its serial CPU mirror.
 //
-// One wavefront per frame.  Parallelism comes from the format's independent Huffman bit streams:
-// the wave walks the block headers (lane 0 parses from an LDS copy of the header bytes), queues every
-// literals stream of literals-only blocks as a "task", and when 64 tasks are pending (or a block with
-// sequences needs its history) all 64 lanes decode one stream each, table look-ups in LDS.  Frames
-// from zstd_encode.hip keep all 64 lanes busy; libzstd frames offer 4 streams per 128 KiB block.
-// Blocks with sequences are executed in order: lane 0 walks the three FSE state machines, the wave
+// One wavefront per frame, 8 waves per CU.  Parallelism comes from the format's independent Huffman bit streams:
+// the wave walks the block headers (all lanes parse the same staged bytes; the next block's header is
+// requested a block ahead), queues every literals stream of literals-only blocks as a "task", and when 64
+// tasks are pending (or a block with sequences needs its history) all 64 lanes decode one stream each, table
+// look-ups in LDS.  Frames from zstd_encode.hip keep all 64 lanes busy; libzstd frames offer 4 streams per
+// 128 KiB block.  Serial pieces of the format run as wave-uniform code on the scalar unit with their tables
+// held across the lanes of vector registers (Huffman weights, FSE state chains).
+// Blocks whose sequences are all "repeat offset 1" runs (the control-byte block of zstd_encode.hip) are
+// decoded out of order: state chains first (in parallel segments when the encoder's checkpoints are
+// present), their literal streams with everybody else's, the runs placed afterwards from prefix sums.
+// Other blocks with sequences are executed in order: lane 0 walks the three FSE state machines, the wave
 // copies literals and matches cooperatively.
 // Algorithmic HBM bytes per svb byte: ~0.67 read + 1 written.
 #include "vbz_kernels.h"

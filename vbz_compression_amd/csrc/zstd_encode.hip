@@ -5,22 +5,27 @@
 // vbz_decompress -- decodes to exactly the svb stream it was given.  It is NOT byte-identical to
 // libzstd's output: libzstd's level-1 match finder is a serial hash-chain walk with no parallel
 // form, and on nanopore signal >= 98 % of its output bytes are Huffman-coded literals anyway
-// (SURVEY.md section 0.4).  This encoder therefore emits literals-only blocks and spends its effort
-// where the bytes are:
+// (SURVEY.md section 0.4).  This encoder therefore spends its effort where the bytes are:
 //
 //   * the svb stream is cut into two REGIONS, control bytes and data bytes, because their byte
-//     statistics differ completely (control bytes are ~96 % 0x00); each region gets its own
+//     statistics differ completely (control bytes are mostly 0x00); each region gets its own
 //     Huffman table, built exactly the way libzstd builds it (zstd_entropy.h), so the table and
 //     the code lengths are the ones the reference would have produced for those bytes;
-//   * each region is cut into <= 16 near-equal BLOCKS of 4 Huffman streams each; the first block of
-//     a region carries the tree description, the others are "treeless" (reuse the table), which the
-//     format allows.  A frame thus exposes up to 64 independent bit streams: one per lane of the
-//     wavefront that owns the frame, for the encoder here and for the decoder (zstd_decode.hip);
+//   * the data-byte region is cut into near-equal BLOCKS of 4 Huffman streams each; the first block
+//     carries the tree description, the others are "treeless" (reuse the table), which the format
+//     allows.  A frame thus exposes up to 64 independent bit streams: one per lane of the wavefront
+//     that decodes the frame (zstd_decode.hip);
+//   * the control-byte region becomes one block whose long zero runs are zstd SEQUENCES (copy from
+//     offset 1 = repeat offset 1, which costs no bits) -- what libzstd's match finder gets out of
+//     that region, found here with a bit-parallel tokeniser instead of a hash chain -- followed by
+//     a skippable frame with decoder checkpoints (CP_MAGIC below);
 //   * raw and RLE blocks are used where Huffman coding does not pay (tiny or constant regions), which
 //     also reproduces the reference's known answers for tiny inputs (vbz/test/vbz_test.cpp:238).
 //
-// One wavefront (64 lanes) per frame: histogram with LDS atomics -> lane 0 builds the table ->
-// every lane sizes its stream (sum of code lengths) -> offsets -> every lane bit-packs its stream.
+// One wavefront (64 lanes) per frame, 16 waves per CU.  Per region: histogram (LDS atomics into four
+// private copies) -> table construction (wave-cooperative, the inherently serial parts on one lane or
+// on the scalar unit) -> packing: the wave packs one stream at a time, 1024 symbols per step, with a
+// prefix sum of bit counts; streams are written in frame order and block headers are filled in last.
 // Algorithmic HBM bytes per svb byte: 1 read + ~0.67 written.
 #include "vbz_kernels.h"
 #include "zstd_entropy.h"
@@ -347,7 +352,7 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
 // so the offset costs no bits: OF table in RLE mode, code 0), its first zero stays a literal, and the
 // literals (everything outside the run tails) are Huffman coded as before.  Which bytes are run tails is a
 // morphological open of the zero mask, computed with shifts on a 64-bit window per lane; positions come from
-// wave prefix sums.  Only the FSE state chain of the sequences is serial (lane 0, ~RMIN+ bytes per step).
+// wave prefix sums.  Only the FSE state chains of the sequences are serial (wave-uniform code on the scalar unit).
 #ifndef VBZ_RMIN
 #define VBZ_RMIN 12
 #endif
@@ -457,7 +462,7 @@ constexpr uint32_t CP_MIN_SPACING = 32;
 // all lanes.  Sequences section (RFC 8878 3.1.1.3.2) for the records of tokenise_zero_runs: LL and ML with the
 // predefined distributions, OF in RLE mode with code 0 (repeat offset 1); same bit order as libzstd's
 // ZSTD_encodeSequences (last sequence first).  Per chunk of 64 sequences: every lane turns one record into
-// codes and extra bits; lanes 0 and 1 walk the two independent FSE state chains (match length / literal
+// codes and extra bits; wave-uniform scalar code walks the two independent FSE state chains (match length / literal
 // length) and leave each step's output bits in LDS; every lane then assembles the <= 44 bits of its sequence,
 // a wave prefix sum places them, and the chunk is written out as dwords.  Returns the bytes written.
 __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uint2* rec, uint32_t nseq, int lane)
