@@ -83,7 +83,14 @@ struct EncLds
 
 __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
 {
-    for (int i = 0; i < n; ++i) p[i] = (uint8_t)(v >> (8 * i));
+    for (int i = 0; i < n; ++i) {
+        uint32_t byte = (uint32_t)(v >> (8 * i)) & 0xFFu;
+        // One plain byte store per byte.  Without this barrier hipcc (ROCm 7.2, gfx950) fuses the stores of a 3-byte
+        // block header into a 16-bit store built with v_lshrrev_b32_sdwa + v_bitop3_b16, and the second byte came out
+        // wrong on hardware for some builds (caught by the libzstd cross-decode test).
+        asm volatile("" : "+v"(byte));
+        p[i] = (uint8_t)byte;
+    }
 }
 
 // histogram of in[0..n) into L.hist using all 64 lanes.  LDS atomics on a shared bin serialise, so four lane
