@@ -15,6 +15,9 @@ SOURCES = ["svb_kernels.hip", "zstd_encode.hip", "zstd_decode.hip", "helpers.hip
 HEADERS = ["vbz_kernels.h", "zstd_entropy.h", "../../include/vbz.h", "../../include/vbz_gpu.h", "../../include/vbz_hdf_plugin.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+# The SDWA peephole is off: a byte-1 SDWA shift feeding v_bitop3_b16 produced a wrong block-header byte on hardware
+# (see put_le in zstd_encode.hip); the kernels measure the same with and without the peephole.
+FLAGS += ["-mllvm", "-amdgpu-sdwa-peephole=false"]
 FLAGS += os.environ.get("VBZ_HIPCC_EXTRA", "").split()
 
 
