@@ -351,6 +351,37 @@ def test_zstd_decode_rejects_corruption():
             assert _same(g, mine)
 
 
+def test_zstd_decode_rejects_corruption_of_own_frames():
+    """Bit flips in frames of this library's encoder (zero-run sequences, treeless blocks, checkpoint trailer): the
+    decoder must agree with the strict restatement -- same bytes or both refuse -- whichever of its paths a damaged
+    frame ends up on."""
+    import gpu_util as G
+
+    rng = np.random.default_rng(91)
+    a = O.synth_signal(5, 11, 60000)
+    svb = O.svb_compress(a, 2, True, 1)
+    frame = G.compress([a], G.codec().options(True, 2, 1, 1))[0]
+    assert O.zstd_restate_decompress(frame, len(svb)).tobytes() == svb.tobytes()
+    frames = []
+    for _ in range(150):
+        bad = frame.copy()
+        for _ in range(int(rng.integers(1, 3))):
+            # half of the damage goes to the first 3 KB (headers, tree, sequences), the rest anywhere
+            hi = 3000 if rng.random() < 0.5 else len(bad)
+            bad[int(rng.integers(0, hi))] ^= 1 << int(rng.integers(0, 8))
+        frames.append(bad)
+    got = G.zstd_decompress(frames, [len(svb)] * len(frames))
+    agree = 0
+    for f, g in zip(frames, got):
+        mine = O.zstd_restate_decompress(f, len(svb))
+        if mine is None:
+            assert isinstance(g, int), "accepted a frame the strict decoder refuses"
+        else:
+            assert _same(g, mine)
+            agree += 1
+    assert agree >= 1   # some flips only hit bytes that do not matter (trailer, padding)
+
+
 # ------------------------------------------------------------------------------------------------
 # the whole path through the drop-in C ABI (host pointers)
 # ------------------------------------------------------------------------------------------------
