@@ -447,6 +447,22 @@ def test_config3_uint32_ten_million_elements():
     assert abs(len(g) / len(r) - 1.0) < 0.03, (len(g), len(r))   # no control-byte sequences on this path: Huffman only
 
 
+def test_cpp_caller_relinked_against_libvbz_hip(tmp_path):
+    """a C++ translation unit written against the reference's interface (here: a small
+    caller in the idiom of vbz/test/vbz_test.cpp) builds against include/vbz.h and runs after linking -lvbz_hip."""
+    import subprocess
+
+    from vbz_compression_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "c_caller")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "host", "c_caller.cpp"),
+                           "-L", libdir, "-lvbz_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", (r.returncode, r.stdout, r.stderr)
+
+
 def test_c_abi_error_behaviour():
     from vbz_compression_amd import _lib, vbz
 
