@@ -847,6 +847,9 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
                 uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
                 uint32_t flushed = 0;     // bytes of the stream already written to memory
+#ifdef VBZ_X_NOPACK
+                st = 4 * nb;
+#endif
                 while (st < 4 * nb) {
                     if ((st >> 2) != curblk) {  // first stream of a block: reserve its headers, place the tree
                         curblk = st >> 2;
