@@ -442,7 +442,6 @@ __global__ __launch_bounds__(WG) void svb_half_encode_kernel(ReadBatch b, uint32
 
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
     if (b.gate && b.gate[r] >= E_FIRST) {
         if (tid == 0) b.result[r] = b.gate[r];
         return;

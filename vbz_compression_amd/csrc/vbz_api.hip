@@ -81,8 +81,8 @@ bool ensure(vbz_gpu_ctx* c, DevBuf& b, size_t bytes)
 {
     if (bytes <= b.cap) return true;
     if (b.p) {
-        hipStreamSynchronize(c->stream);  // earlier work may still use the old buffer
-        hipFree(b.p);
+        (void)hipStreamSynchronize(c->stream);  // earlier work may still use the old buffer
+        (void)hipFree(b.p);
         b.p = nullptr;
         b.cap = 0;
     }
@@ -105,7 +105,7 @@ hipEvent_t get_event(vbz_gpu_ctx* c)
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 
@@ -118,14 +118,14 @@ struct Timed  // records a pair of events around one kernel launch when profilin
     {
         if (c->profiling) {
             start = get_event(c);
-            hipEventRecord(start, c->stream);
+            (void)hipEventRecord(start, c->stream);
         }
     }
     ~Timed()
     {
         if (start) {
             hipEvent_t stop = get_event(c);
-            hipEventRecord(stop, c->stream);
+            (void)hipEventRecord(stop, c->stream);
             c->pending.push_back({ name, start, stop });
         }
     }
@@ -134,10 +134,10 @@ struct Timed  // records a pair of events around one kernel launch when profilin
 void drain_profile(vbz_gpu_ctx* c)
 {
     if (c->pending.empty()) return;
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) {
         float ms = 0;
-        hipEventElapsedTime(&ms, p.start, p.stop);
+        (void)hipEventElapsedTime(&ms, p.start, p.stop);
         bool found = false;
         for (auto& e : c->prof)
             if (e.name == p.name || strcmp(e.name, p.name) == 0) {
@@ -158,7 +158,7 @@ unsigned long long* dbg_begin(vbz_gpu_ctx* c, uint32_t n)
 {
     if (!c->phase_timing) return nullptr;
     if (!ensure(c, c->dbg, (size_t)n * 64)) return nullptr;
-    hipMemsetAsync(c->dbg.p, 0, (size_t)n * 64, c->stream);
+    (void)hipMemsetAsync(c->dbg.p, 0, (size_t)n * 64, c->stream);
     return (unsigned long long*)c->dbg.p;
 }
 
@@ -166,8 +166,8 @@ void dbg_end(vbz_gpu_ctx* c, uint32_t n, const char* what, unsigned long long* d
 {
     if (!d) return;
     std::vector<unsigned long long> h((size_t)n * 8);
-    hipStreamSynchronize(c->stream);
-    hipMemcpy(h.data(), d, (size_t)n * 64, hipMemcpyDeviceToHost);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(h.data(), d, (size_t)n * 64, hipMemcpyDeviceToHost);
     double sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     for (uint32_t i = 0; i < n; ++i)
         for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)i * 8 + k];
@@ -449,16 +449,16 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) {
-        hipEventDestroy(p.start);
-        hipEventDestroy(p.stop);
+        (void)hipEventDestroy(p.start);
+        (void)hipEventDestroy(p.stop);
     }
-    for (auto e : c->event_pool) hipEventDestroy(e);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab })
-        if (b->p) hipFree(b->p);
-    if (c->pinned) hipHostFree(c->pinned);
-    if (c->own_stream) hipStreamDestroy(c->stream);
+        if (b->p) (void)hipFree(b->p);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 

@@ -833,6 +833,7 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
                 while (cnt > 0) {
                     uint32_t e1, e2;
                     HUF_PAIR(e1, e2);
+                    (void)e2;  // only the first symbol of the pair is taken
                     n -= (int32_t)(e1 >> 8);
                     *o++ = (uint8_t)e1;
                     --cnt;
