@@ -100,14 +100,19 @@ __device__ __forceinline__ void wg_lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (gfx9: no LDS crossbar
+// traffic, six additions): after the four row_shr steps every 16-lane row holds its own scan, row_bcast:15 adds the
+// last lane of rows 0 and 2 into rows 1 and 3, row_bcast:31 adds lane 31 into the upper half.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+#define VBZ_DPP_ADD(ctrl, rowmask) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xF, false)
+    VBZ_DPP_ADD(0x111, 0xF);  // row_shr:1
+    VBZ_DPP_ADD(0x112, 0xF);  // row_shr:2
+    VBZ_DPP_ADD(0x114, 0xF);  // row_shr:4
+    VBZ_DPP_ADD(0x118, 0xF);  // row_shr:8
+    VBZ_DPP_ADD(0x142, 0xA);  // row_bcast:15 -> rows 1, 3
+    VBZ_DPP_ADD(0x143, 0xC);  // row_bcast:31 -> rows 2, 3
+#undef VBZ_DPP_ADD
     return v;
 }
 
