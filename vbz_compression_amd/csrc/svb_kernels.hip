@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
             // full int16 tile: wrap-around delta and 16-bit zig-zag (sse3.h:432-440) on two samples per instruction
             typedef short s16x2 __attribute__((ext_vector_type(2)));
             const uint32_t w[4] = { q.x, q.y, q.z, q.w };
-            uint32_t pw = (uint32_t)__shfl_up((int)w[3], 1, 64);  // its top half: the sample in front of this lane's first
+            uint32_t pw = wave_prev_lane_u32(w[3]);  // its top half: the sample in front of this lane's first
             if (lane == 0) pw = i0 == 0 ? 0u : ((uint32_t)(uint16_t)load_elem(in + (size_t)(i0 - 1) * ELEM, ELEM) << 16);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         }
         if (ZZ) {
             // previous sample: neighbouring lane's last value; wave lane 0 re-reads it from memory
-            int32_t prev = __shfl_up(x[VPL - 1], 1, 64);
+            int32_t prev = (int32_t)wave_prev_lane_u32((uint32_t)x[VPL - 1]);
             if (lane == 0) prev = (i0 == 0 || valid == 0) ? 0 : load_elem(in + (size_t)(i0 - 1) * ELEM, ELEM);
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {

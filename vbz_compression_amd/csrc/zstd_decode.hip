@@ -890,7 +890,7 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
             // stream: mark the first literal of every sequence with the match length before it, prefix-sum the marks
             // over the literals -- every lane then moves the same number of literals, however they are spread
             const uint32_t lo = il - ll, oo = it - (ll + ml);
-            const uint32_t mprev = (uint32_t)__shfl_up((int)ml, 1, 64);
+            const uint32_t mprev = wave_prev_lane_u32(ml);
             if (ll != 0 && lane != 0) lds_sh[lo] = mprev;
             wave_lds_sync();
             uint32_t carry = 0;
