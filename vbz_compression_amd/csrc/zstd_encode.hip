@@ -176,12 +176,20 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
         c[j] = s <= maxSym ? L.hist[s] : 0u;
         rank[j] = 0;
     }
-    for (uint32_t t = 0; t <= maxSym; ++t) {
-        const uint32_t ct = L.hist[t];  // same address in every lane: an LDS broadcast
+    for (uint32_t t0 = 0; t0 <= maxSym; t0 += 8) {
+        // eight counts per trip, the same addresses in every lane: two 16-byte LDS broadcasts, one round trip
+        const uint4 h0 = *reinterpret_cast<const uint4*>(&L.hist[t0]), h1 = *reinterpret_cast<const uint4*>(&L.hist[t0 + 4]);
+        const uint32_t ct8[8] = { h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w };
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t s = (uint32_t)lane + 64u * j;
-            rank[j] += (ct > c[j]) || (ct == c[j] && t < s);
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t t = t0 + (uint32_t)u, ct = ct8[u];
+            if (t <= maxSym) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t s = (uint32_t)lane + 64u * j;
+                    rank[j] += (ct > c[j]) || (ct == c[j] && t < s);
+                }
+            }
         }
     }
     uint32_t mine = 0;
@@ -611,7 +619,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab)
 {
-    __shared__ EncLds L;
+    __shared__ __attribute__((aligned(16))) EncLds L;
     unsigned long long tph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
