@@ -157,22 +157,22 @@ void drain_profile(vbz_gpu_ctx* c)
 unsigned long long* dbg_begin(vbz_gpu_ctx* c, uint32_t n)
 {
     if (!c->phase_timing) return nullptr;
-    if (!ensure(c, c->dbg, (size_t)n * 64)) return nullptr;
-    (void)hipMemsetAsync(c->dbg.p, 0, (size_t)n * 64, c->stream);
+    if (!ensure(c, c->dbg, (size_t)n * PHASE_SLOTS * 8)) return nullptr;
+    (void)hipMemsetAsync(c->dbg.p, 0, (size_t)n * PHASE_SLOTS * 8, c->stream);
     return (unsigned long long*)c->dbg.p;
 }
 
 void dbg_end(vbz_gpu_ctx* c, uint32_t n, const char* what, unsigned long long* d)
 {
     if (!d) return;
-    std::vector<unsigned long long> h((size_t)n * 8);
+    std::vector<unsigned long long> h((size_t)n * PHASE_SLOTS);
     (void)hipStreamSynchronize(c->stream);
-    (void)hipMemcpy(h.data(), d, (size_t)n * 64, hipMemcpyDeviceToHost);
-    double sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    (void)hipMemcpy(h.data(), d, (size_t)n * PHASE_SLOTS * 8, hipMemcpyDeviceToHost);
+    double sum[PHASE_SLOTS] = {};
     for (uint32_t i = 0; i < n; ++i)
-        for (int k = 0; k < 8; ++k) sum[k] += (double)h[(size_t)i * 8 + k];
+        for (int k = 0; k < PHASE_SLOTS; ++k) sum[k] += (double)h[(size_t)i * PHASE_SLOTS + k];
     fprintf(stderr, "vbz_hip phase cycles/read (%s, n=%u):", what, n);
-    for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.0f", k, sum[k] / n);
+    for (int k = 0; k < PHASE_SLOTS; ++k) fprintf(stderr, " p%d=%.0f", k, sum[k] / n);
     fprintf(stderr, "\n");
 }
 
@@ -365,7 +365,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         // decode it and then fail in the svb stage with a stream error
         HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, c->seqdtab.p, s), "zstd_decode launch");
     }
-    dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable header queue", dbg);
+    dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable header queue | general sequences: flush tables records literals matches", dbg);
     ReadBatch d = rb;
     d.src = (const uint8_t*)c->scratch.p;
     d.src_off = svb_off;

@@ -17,6 +17,7 @@ constexpr uint32_t E_VERSION = 0xFFFFFFFAu;
 constexpr uint32_t E_OOM = 0xFFFFFFF9u;
 constexpr uint32_t E_DEVICE = 0xFFFFFFF8u;
 constexpr uint32_t E_FIRST = E_DEVICE;
+constexpr int PHASE_SLOTS = 12;  // per-read cycle counters of the timed kernel builds (debug aid)
 
 // One batch of independent reads ("reads" in the reference's vocabulary: one HDF5 chunk each).
 // All pointers are device pointers.  `result[i]` receives the bytes produced or an error code.

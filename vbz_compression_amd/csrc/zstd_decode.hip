@@ -46,7 +46,7 @@ struct DecLds
     uint16_t huf[2][HUF_SLOT];   // two Huffman decoding tables: symbol | nbBits << 8 (a 12-bit table spans both)
     // The input rings of the stream decoders share their LDS with everything that is only needed while
     // headers are parsed or sequences are executed.  Frames that carry sequences (fse tables must survive
-    // from block to block) decode their literal streams with the ring-less path instead.
+    // from block to block) park those tables in registers while the rings are in use (flush_tasks).
     union
     {
         uint32_t inbuf[VBZ_DEC_RING_DECL + 1][WAVE];  // per-lane rings of compressed input ([slot][lane]), slot 0 mirrors the last
@@ -61,6 +61,7 @@ struct DecLds
     uint32_t wfse[64];       // FSE table of the Huffman weights (accuracy log <= 6)
     uint8_t weights[256];
     uint32_t t_src[WAVE], t_size[WAVE], t_out[WAVE], t_cnt[WAVE], t_tab[WAVE];  // pending stream tasks
+    uint32_t t_bit[WAVE], t_end[WAVE];  // split streams only: bits consumed where a lane's piece starts and ends
     uint32_t ctl[24];
 };
 // one wave per workgroup: the frame's LDS state.  At namespace scope so that functions that are real calls
@@ -662,51 +663,6 @@ __device__ __forceinline__ void fetch_batch(gcu8* p, uint32_t& nextbyte, uint32_
     }
 }
 
-// ring-less variant: every lane reads its stream straight from memory, 4 bytes at a time.  Used while
-// FSE tables are live in the LDS the rings would need (frames with sequences, i.e. libzstd's frames).
-__device__ __noinline__ bool flush_tasks_direct(const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
-{
-    bool bad = false;
-    if ((uint32_t)lane < ntask) {
-        const uint8_t* p = src + L.t_src[lane];
-        const uint32_t n = L.t_size[lane];
-        uint8_t* o = dst + L.t_out[lane];
-        uint32_t cnt = L.t_cnt[lane];
-        const uint32_t tab = L.t_tab[lane];
-        const int log = (int)(tab >> 16);
-        const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
-        BitReader br;
-        if (!br.init(p, n)) {
-            bad = true;
-        } else {
-            while (cnt >= 4) {
-                uint32_t e0, e1, e2, e3;
-                br.refill();
-                e0 = T[br.peek(log)]; br.skip((int)(e0 >> 8));
-                e1 = T[br.peek(log)]; br.skip((int)(e1 >> 8));
-                br.refill();
-                e2 = T[br.peek(log)]; br.skip((int)(e2 >> 8));
-                e3 = T[br.peek(log)]; br.skip((int)(e3 >> 8));
-                const uint32_t w = (e0 & 0xFF) | ((e1 & 0xFF) << 8) | ((e2 & 0xFF) << 16) | (e3 << 24);
-                __builtin_memcpy(o, &w, 4);
-                o += 4;
-                cnt -= 4;
-            }
-            while (cnt > 0) {
-                br.refill();
-                const uint32_t e = T[br.peek(log)];
-                br.skip((int)(e >> 8));
-                *o++ = (uint8_t)e;
-                --cnt;
-            }
-            if (!br.finished()) bad = true;
-        }
-    }
-    ntask = 0;
-    __syncthreads();  // makes the decoded bytes visible to the whole wave (vmcnt drain)
-    return __any(bad);
-}
-
 // all lanes: decode the queued Huffman streams, one per lane.  Returns true if any stream is corrupt.
 //
 // A lane's compressed bytes arrive through its LDS ring ([slot][lane], filled 64 bytes at a time one period
@@ -716,7 +672,10 @@ __device__ __noinline__ bool flush_tasks_direct(const uint8_t* src, uint8_t* dst
 // RING - k % RING, slot 0 mirroring slot RING) makes the pair one ds_read2st64_b32 at slot (n >> 5) % RING.
 // 32 fresh bits are good for two symbols (codes are at most 11 bits), so a pair of symbols costs one ring read,
 // two table reads and about a dozen ALU operations, with no conditional refill.
-__device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, uint32_t& ntask, int lane)
+//
+// split: the tasks are pieces of longer streams (huf_split_plan): a lane starts with t_bit bits consumed and must end
+// at exactly t_end.
+__device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, uint32_t& ntask, bool split, int lane)
 {
     bool bad = false;
     const bool mine = (uint32_t)lane < ntask;
@@ -735,9 +694,16 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
     uint32_t* ring = &L.u.inbuf[0][0] + lane;  // slot s of this lane: ring[s * WAVE]
 
     int32_t n = -1;  // minus the number of bits consumed
-    uint32_t nextbyte = 0, widx = 0;
+    uint32_t nextbyte = 0, widx = 0, end_bits = 8u * nbytes;
     uint32_t pend[BATCH];
-    if (mine) {
+    if (split) {
+        // the ring holds dwords k0, k0 + 1, ... (counted from the end of the stream), k0 a multiple of BATCH
+        const uint32_t c0 = L.t_bit[lane];
+        end_bits = L.t_end[lane];
+        n = -(int32_t)c0;
+        widx = ((c0 - 1u) >> 5) & ~(uint32_t)(BATCH - 1);
+        nextbyte = mine ? nbytes - 4u * widx : 0u;
+    } else if (mine) {
         const uint32_t last = nbytes ? p[nbytes - 1] : 0;
         if (last == 0) {
             bad = true;
@@ -843,10 +809,187 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
     }
 #undef HUF_PAIR
 #undef RING_PUT
-    if (mine && !bad && n != -(int32_t)(8u * nbytes)) bad = true;  // every bit of the stream must be consumed, none beyond
+    if (mine && !bad && n != -(int32_t)end_bits) bad = true;  // every bit of the stream must be consumed, none beyond
     ntask = 0;
     __syncthreads();  // also makes the decoded bytes visible to the whole wave (vmcnt drain)
     return __any(bad);
+}
+
+// ---- long Huffman streams, split ----------------------------------------------------------------------
+// libzstd writes the literals of a block as four streams of up to 32 KB: four busy lanes, sixty idle ones, and the
+// longest dependent chain of the whole frame.  Huffman codes resynchronise: a decoder started at an arbitrary bit
+// falls into step with the real code boundaries after a few dozen symbols.  So every stream is cut into 16 pieces of
+// equal bit length, one lane each:
+//   pass 0  a lane starts SPLIT_RUNUP bits before its piece and walks to the first code boundary inside it: its
+//           presumed start;
+//   pass 1  from there it walks its piece to the first boundary inside the next one, counting symbols;
+//   check   a lane's end must be the next lane's start; a lane for which it is not walks again from the right bit
+//           (repeated until all agree: lane 0 starts at a known bit, so this ends, normally at once);
+//   then the counts give every piece its place in the output and the pieces are decoded like 64 short streams.
+// Nothing is trusted: the pieces must chain from the end mark to the first bit of the stream and their symbol
+// counts must add up to the stream's regenerated size, else the streams are decoded the ordinary way (which also
+// is what reports a corrupt stream).
+constexpr uint32_t SPLIT_MIN_BYTES = 1024;  // shorter streams are not worth the extra passes
+constexpr uint32_t SPLIT_RUNUP = 768;       // bits
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// all lanes.  No output: walks from c0 bits consumed to the first code boundary at or beyond `stop`.
+// Returns {that boundary, symbols walked}; boundary 0xFFFFFFFF = the table has a hole (never for a valid tree).
+__device__ __noinline__ uint2 huf_dry_walk(const uint8_t* stream, uint32_t nbytes, bool act, uint32_t c0, uint32_t stop, uint32_t tab, int lane)
+{
+    gcu8* p = (gcu8*)stream;
+    const uint32_t sL = 32u - (tab >> 16);
+    const uint16_t* T = &L.huf[0][0] + (tab & 0xFFFF);
+    uint32_t* ring = &L.u.inbuf[0][0] + lane;
+    if (!act) {
+        c0 = 1;
+        stop = 0;
+        nbytes = 0;
+    }
+    int32_t n = -(int32_t)c0;
+    uint32_t widx = ((c0 - 1u) >> 5) & ~(uint32_t)(BATCH - 1);
+    uint32_t nextbyte = nbytes - 4u * widx;
+    uint32_t pend[BATCH];
+#define RING_PUT()                                                              \
+    do {                                                                        \
+        const uint32_t wb__ = (uint32_t)RING - (widx & (uint32_t)(RING - 1));   \
+        _Pragma("unroll") for (int k = 0; k < BATCH; ++k) ring[(wb__ - (uint32_t)k) * WAVE] = pend[k]; \
+        if (wb__ == (uint32_t)RING) ring[0] = pend[0];                          \
+        widx += BATCH;                                                          \
+    } while (0)
+    for (int f = 0; f < 2; ++f) {
+        fetch_batch(p, nextbyte, pend);
+        RING_PUT();
+    }
+    fetch_batch(p, nextbyte, pend);
+    uint32_t m = 0;
+    bool done = c0 >= stop;
+    // a pair of symbols eats at least two bits: more trips than this means a code of length 0
+    uint32_t trips = wave_max_u32(done ? 0u : stop - c0) / 32u + 2u;
+    while (__any(!done)) {
+        if (trips-- == 0) return make_uint2(0xFFFFFFFFu, 0u);
+        if (widx - (((uint32_t)~n) >> 5) <= (uint32_t)(RING - BATCH)) {
+            RING_PUT();
+            fetch_batch(p, nextbyte, pend);
+        }
+#pragma unroll 4
+        for (int q = 0; q < PERIOD / 2; ++q) {
+            const int32_t t = n >> 5;
+            const uint32_t a = ring[((((uint32_t)t) & (uint32_t)(RING - 1)) + 1u) * WAVE];
+            const uint32_t b = ring[(((uint32_t)t) & (uint32_t)(RING - 1)) * WAVE];
+            uint32_t x = __builtin_amdgcn_alignbit(a, b, (uint32_t)n);
+            const uint32_t l1 = (uint32_t)T[x >> sL] >> 8;
+            x <<= l1;
+            const uint32_t l2 = (uint32_t)T[x >> sL] >> 8;
+            const uint32_t c1 = (uint32_t)-n + l1, c2 = c1 + l2;
+            const bool one = c1 >= stop;  // the first symbol already reaches the stop
+            if (!done) {
+                n = -(int32_t)(one ? c1 : c2);
+                m += one ? 1u : 2u;
+                done = one || c2 >= stop;
+            }
+        }
+    }
+#undef RING_PUT
+    return make_uint2((uint32_t)-n, m);
+}
+
+// all lanes.  Turns up to four queued long streams into 64 pieces (see above).  Returns false (tasks untouched) if the
+// queue does not qualify or the pieces do not fit together.
+__device__ __noinline__ bool huf_split_plan(const uint8_t* src, uint32_t& ntask, int lane)
+{
+    const uint32_t nt = ntask;
+    if (nt == 0 || nt > 4) return false;
+    const uint32_t t = (uint32_t)lane >> 4, j = (uint32_t)lane & 15u;
+    const bool act = t < nt;
+    uint32_t so = 0, nbytes = 0, out = 0, cnt = 0, tab = 0;
+    if (act) {
+        so = L.t_src[t];
+        nbytes = L.t_size[t];
+        out = L.t_out[t];
+        cnt = L.t_cnt[t];
+        tab = L.t_tab[t];
+    }
+    if (__any(act && nbytes < SPLIT_MIN_BYTES)) return false;
+    const uint8_t* p = src + so;
+    const uint32_t last = act ? p[nbytes - 1] : 1u;
+    if (__any(last == 0)) return false;
+    const uint32_t pad = 8u - (uint32_t)hbit(last), B = 8u * nbytes;
+    const uint32_t seg = (B - pad + 15u) / 16u;
+    const uint32_t c_lo = pad + j * seg, c_hi = j == 15 ? B : pad + (j + 1u) * seg;
+    // pass 0: where this piece presumably starts
+    uint32_t s_bit = pad;
+    {
+        const bool run = act && j != 0;
+        const uint32_t from = (c_lo - pad <= SPLIT_RUNUP) ? pad : c_lo - SPLIT_RUNUP;
+        const uint2 r = huf_dry_walk(p, nbytes, run, from, c_lo, tab, lane);
+        if (__any(run && r.x == 0xFFFFFFFFu)) return false;
+        if (run) s_bit = r.x;
+    }
+    // pass 1 and the repair rounds
+    uint32_t e_bit = 0, m = 0;
+    bool need = act;
+    for (int round = 0; round < 18; ++round) {
+        if (!__any(need)) break;
+        const uint2 r = huf_dry_walk(p, nbytes, need, s_bit, c_hi, tab, lane);
+        if (__any(need && r.x == 0xFFFFFFFFu)) return false;
+        if (need) {
+            e_bit = r.x;
+            m = r.y;
+        }
+        const uint32_t e_prev = (uint32_t)__shfl_up((int)e_bit, 1, 64);
+        need = act && j != 0 && e_prev != s_bit;
+        if (need) s_bit = e_prev;
+    }
+    if (__any(need)) return false;
+    // the pieces chain; do they cover the stream, symbol for symbol?
+    const uint32_t incl = wave_incl_scan_u32(act ? m : 0u);
+    const uint32_t before = (uint32_t)__shfl((int)incl, t ? (int)(t * 16u) - 1 : 0, 64) * (t ? 1u : 0u);
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(t * 16u + 15u), 64) - before;
+    if (__any(act && (total != cnt || (j == 15 && e_bit != B)))) return false;
+    wave_lds_sync();
+    L.t_src[lane] = so;
+    L.t_size[lane] = nbytes;
+    L.t_out[lane] = out + (incl - m - before);
+    L.t_cnt[lane] = act ? m : 0u;
+    L.t_tab[lane] = tab;
+    L.t_bit[lane] = act ? s_bit : 1u;
+    L.t_end[lane] = act ? e_bit : 1u;
+    wave_lds_sync();
+    ntask = WAVE;
+    return true;
+}
+
+// all lanes: decode the queued Huffman streams.  keep_fse: the sequence tables in LDS (which the rings overwrite) are
+// still needed -- a libzstd frame whose next block may say Repeat_Mode -- so they spend the flush in registers.
+// Returns true if any stream is corrupt.
+__device__ __noinline__ bool flush_tasks(const uint8_t* src, uint8_t* dst, uint32_t& ntask, bool keep_fse, int lane)
+{
+    constexpr int KEEP = 3 * FSE_SLOT / WAVE;
+    uint32_t keep[KEEP];
+    uint32_t* f = &L.u.p.fse[0][0];
+    if (keep_fse) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) keep[k] = f[k * WAVE + lane];
+        wave_lds_sync();
+    }
+    const bool split = huf_split_plan(src, ntask, lane);
+    const bool bad = flush_tasks_ring(src, dst, ntask, split, lane);
+    if (keep_fse) {
+#pragma unroll
+        for (int k = 0; k < KEEP; ++k) f[k * WAVE + lane] = keep[k];
+        __syncthreads();
+    }
+    return bad;
 }
 
 // all lanes.  Second half of the zero-run fast path: (literal length, match length) pairs are known, every
@@ -1085,6 +1228,114 @@ __device__ __noinline__ uint32_t zero_run_chain(const uint8_t* bs_, uint32_t bsn
     return 1u;
 }
 
+// all lanes.  The sequences of a block with arbitrary offsets (libzstd's frames), decoded -- not executed -- into 16-byte
+// records {literal length, match length, offset, 0} at `rec`, fully validated (bit stream, literal budget, offsets
+// inside the output, block and frame size).  The three state machines are one dependent chain: wave-uniform code on
+// the scalar unit, FSE tables in LDS (read at a uniform address), the backward bit stream in a 256-byte register
+// window (lane j = the j-th dword from the end, reloaded with one coalesced load per 2048 bits), 64 records collected
+// across the lanes before they leave with one store.  rep[] = the three repeat offsets (in and out).
+// Returns false if the section is corrupt.
+__device__ __noinline__ bool general_sequence_records(const uint8_t* bs_, uint32_t bsn_, uint4* rec, uint32_t nseq_, uint32_t log_ll_,
+                                                      uint32_t log_of_, uint32_t log_ml_, uint32_t regen_, uint32_t opos_, uint32_t fcs_,
+                                                      uint32_t (&rep)[3], int lane)
+{
+    const uint32_t bsn = uni(bsn_), nseq = uni(nseq_), log_ll = uni(log_ll_), log_of = uni(log_of_), log_ml = uni(log_ml_);
+    const uint32_t regen = uni(regen_), opos0 = uni(opos_), fcs = uni(fcs_);
+    uint32_t rep0 = uni(rep[0]), rep1 = uni(rep[1]), rep2 = uni(rep[2]);
+    const uint8_t* bs = reinterpret_cast<const uint8_t*>(((uint64_t)uni((uint32_t)((uint64_t)bs_ >> 32)) << 32) |
+                                                         uni((uint32_t)(uint64_t)bs_));
+    if (bsn == 0) return false;
+    uint32_t k0 = 0;
+    auto load_window = [&]() -> uint32_t {
+        const int64_t off = (int64_t)bsn - 4 * (int64_t)(k0 + (uint32_t)lane + 1);
+        uint32_t v = 0;
+        if (off >= 0) {
+            __builtin_memcpy(&v, bs + off, 4);
+        } else if (off > -4) {
+            for (int k = 0; k < 4 + (int)off; ++k) v |= (uint32_t)bs[k] << (8 * (k - (int)off));
+        }
+        return v;
+    };
+    uint32_t win = load_window();
+    const uint32_t top = lane_get(win, 0) >> 24;
+    if (top == 0) return false;
+    const uint32_t hb = (uint32_t)hbit(top);
+    uint64_t buf = 0;
+    uint32_t have = 0, q = 0;
+    auto refill = [&]() {
+        if (have <= 32) {
+            if (q - k0 == 64) {
+                k0 += 64;
+                win = load_window();
+            }
+            const uint32_t d = lane_get(win, q - k0);
+            ++q;
+            buf |= (uint64_t)d << (32 - have);
+            have += 32;
+        }
+    };
+    auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 32
+        refill();
+        const uint32_t v = (uint32_t)((buf >> 1) >> (63 - nb));
+        buf <<= nb;
+        have -= nb;
+        return v;
+    };
+    refill();
+    buf <<= 8 - hb;
+    have -= 8 - hb;
+    uint32_t sl = take(log_ll), so = take(log_of), sm = take(log_ml);
+    uint32_t sum_ll = 0, outp = opos0;
+    uint32_t r_ll = 0, r_ml = 0, r_of = 0;
+    for (uint32_t i = 0; i < nseq; ++i) {
+        const uint32_t el = uni(L.u.p.fse[0][sl]), eo = uni(L.u.p.fse[1][so]), em = uni(L.u.p.fse[2][sm]);
+        const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
+        if (lc > 35 || mc > 52 || oc > 31) return false;
+        const uint32_t ofv = (oc ? (1u << oc) : 1u) + (oc ? take(oc) : 0u);
+        const uint32_t mlen = ML_BASE[mc] + take(ML_BITS[mc]);
+        const uint32_t llen = LL_BASE[lc] + take(LL_BITS[lc]);
+        uint32_t offset;
+        if (ofv > 3) {
+            offset = ofv - 3;
+            rep2 = rep1; rep1 = rep0; rep0 = offset;
+        } else {
+            const uint32_t idx = ofv - 1 + (llen == 0 ? 1u : 0u);
+            if (idx == 0) {
+                offset = rep0;
+            } else {
+                offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                if (offset == 0) offset = 1;  // libzstd forces an invalid 0 to 1
+                if (idx > 1) rep2 = rep1;
+                rep1 = rep0;
+                rep0 = offset;
+            }
+        }
+        if (i + 1 < nseq) {
+            sl = (el >> 16) + take((el >> 8) & 0xFF);
+            sm = (em >> 16) + take((em >> 8) & 0xFF);
+            so = (eo >> 16) + take((eo >> 8) & 0xFF);
+        }
+        sum_ll += llen;
+        if (sum_ll > regen || (uint64_t)outp + llen + mlen > fcs) return false;
+        outp += llen;
+        if (offset > outp) return false;
+        outp += mlen;
+        if (outp - opos0 > BLOCK_MAX) return false;
+        const bool mine = (uint32_t)lane == (i & 63);
+        r_ll = mine ? llen : r_ll;
+        r_ml = mine ? mlen : r_ml;
+        r_of = mine ? offset : r_of;
+        if ((i & 63) == 63) rec[(i & ~63u) + (uint32_t)lane] = make_uint4(r_ll, r_ml, r_of, 0u);
+    }
+    if ((uint32_t)lane < (nseq & 63)) rec[(nseq & ~63u) + (uint32_t)lane] = make_uint4(r_ll, r_ml, r_of, 0u);
+    // every bit consumed, none beyond: bits taken = 32 q - have, of which 8 - hb were padding
+    if ((uint64_t)32 * q - have != (uint64_t)8 * bsn) return false;
+    rep[0] = rep0;
+    rep[1] = rep1;
+    rep[2] = rep2;
+    return true;
+}
+
 // all lanes.  The same walk as zero_run_chain, split at the encoder's checkpoints (zstd_encode.hip, CP_MAGIC): lane
 // j decodes sequences [j * spacing, (j + 1) * spacing) from (unread bits, LL state, ML state) = checkpoint j - 1
 // (lane 0: from the top of the stream).  The bit stream is staged in LDS (the ring's area, idle while headers are
@@ -1203,7 +1454,7 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
 template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs)
 {
-    unsigned long long tph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
@@ -1222,7 +1473,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const uint32_t cap = b.dst_cap[r];
 #define FLUSH()                                                                                                       \
     do {                                                                                                              \
-        if (fse_live ? flush_tasks_direct(src, dst, ntask, lane) : flush_tasks_ring(src, dst, ntask, lane)) FAIL(); \
+        if (flush_tasks(src, dst, ntask, fse_live, lane)) FAIL();                                                     \
         if (d_active) {                                                                                               \
             PHASE(1);                                                                                                 \
             if (place_zero_runs(dst, reinterpret_cast<const uint2*>(dst + d_pairs), d_nseq, d_lit, d_ltype, d_regen,    \
@@ -1314,7 +1565,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     opos = 0;
     ntask = 0;
     bool huf_valid = false;
-    bool fse_live = attempt != 0;  // FSE tables must survive: literal streams use the ring-less path
+    bool fse_live = attempt != 0;  // FSE tables must survive: flush_tasks parks them in registers
     bool tables_built = false, tables_lost = false;
     // one block whose zero-run sequences are already decoded into pairs but not yet placed: its literals are
     // still queued as stream tasks (staged behind the frame), it is finished right after the next flush
@@ -1494,7 +1745,18 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 ws_lit = (uint32_t)__shfl((int)ws_lit, 0, 64);
                 ws_pairs = (uint32_t)__shfl((int)ws_pairs, 0, 64);
             }
-            const uint32_t lit_dst = !has_seq ? opos : (defer ? ws_lit : fcs - regen);
+            // Other blocks with sequences (libzstd's frames): if the slot has room behind the frame for the literals and
+            // one 16-byte record per sequence, the sequences are decoded first and executed in parallel (see below);
+            // otherwise they run one by one with the literals staged right-aligned at the end of the output.
+            bool par = false;
+            uint32_t ws_plit = 0, ws_seq = 0;
+            if (has_seq && !defer) {
+                const uint32_t ns_hdr = nseq < 128 ? nseq : (nseq < 255 ? ((nseq - 128) << 8) + SQB(1) : SQB(1) + (SQB(2) << 8) + 0x7F00);
+                ws_plit = (fcs + 15u) & ~15u;
+                ws_seq = ws_plit + (ltype >= 2 ? ((regen + 15u) & ~15u) : 0u);
+                par = (uint64_t)ws_seq + 16ull * ns_hdr + 16 <= cap;
+            }
+            const uint32_t lit_dst = !has_seq ? opos : (defer ? ws_lit : (par ? ws_plit : fcs - regen));
             const uint8_t* lit_src = blk + lh;  // raw literals are read in place
             if (ltype >= 2) {
                 const uint8_t* q = blk + lh + tree_used;
@@ -1662,7 +1924,9 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 }
             } else {
                 // everything decoded so far must be in memory before matches can read it
+                PHASE(0);
                 FLUSH();
+                PHASE(8);
                 // (this block's own Huffman literals were queued above, so they were decoded with the ring too)
                 if (!fse_live && tables_built) tables_lost = true;  // the ring shares its LDS with the FSE tables
                 stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
@@ -1712,11 +1976,12 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 nseq = L.ctl[C_I];
                 sq_used = L.ctl[C_J];
                 tables_built = true;
+                PHASE(9);
                 const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
                 const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
                 const uint8_t* bs = sq + sq_used;
                 const uint32_t bsn = sqn - sq_used;
-                fse_live = true;  // libzstd-style frame: keep the FSE tables, later literal streams use the direct path
+                fse_live = true;  // libzstd-style frame: keep the FSE tables across the flushes of later blocks
                 BitReader br;
                 uint32_t sl = 0, so = 0, sm = 0;
                 uint32_t err = 0;
@@ -1732,6 +1997,90 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 if (__shfl((int)err, 0, 64)) FAIL();
                 uint32_t lpos = 0;
                 const uint32_t block_start = opos;
+                if (par) {
+                    // ---- (A) the three state machines are walked once, the sequences only recorded, fully checked
+                    uint4* seqbuf = reinterpret_cast<uint4*>(dst + ws_seq);
+                    {
+                        uint32_t reps[3] = { rep0, rep1, rep2 };
+                        const bool good = general_sequence_records(bs, bsn, seqbuf, nseq, (uint32_t)__shfl(log_ll, 0, 64), (uint32_t)__shfl(log_of, 0, 64),
+                                                                   (uint32_t)__shfl(log_ml, 0, 64), regen, opos, fcs, reps, lane);
+                        if (!good) FAIL();
+                        rep0 = reps[0];
+                        rep1 = reps[1];
+                        rep2 = reps[2];
+                    }
+                    __syncthreads();  // the records (and everything decoded so far) are in memory
+                    PHASE(10);
+                    // ---- (B) all literals at once: positions from prefix sums, 64 sequences per trip
+                    {
+                        uint32_t lposw = 0, oposw = opos;
+                        for (uint32_t base = 0; base < nseq; base += WAVE) {
+                            const uint32_t i = base + (uint32_t)lane;
+                            const uint4 sv = i < nseq ? seqbuf[i] : make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t ll = sv.x, tot = sv.x + sv.y;
+                            const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(tot);
+                            const uint32_t lp = lposw + il - ll;
+                            uint8_t* o = dst + oposw + it - tot;
+                            if (ltype == 1) {
+                                for (uint32_t k = 0; k < ll; ++k) o[k] = rle_byte;
+                            } else {
+                                const uint8_t* f = litp + lp;
+                                uint32_t k = 0;
+                                for (; k + 4 <= ll; k += 4) {
+                                    uint32_t v;
+                                    __builtin_memcpy(&v, f + k, 4);
+                                    __builtin_memcpy(o + k, &v, 4);
+                                }
+                                for (; k < ll; ++k) o[k] = f[k];
+                            }
+                            lposw += (uint32_t)__shfl((int)il, 63, 64);
+                            oposw += (uint32_t)__shfl((int)it, 63, 64);
+                        }
+                        // literals behind the last sequence
+                        const uint32_t rest = regen - lposw;
+                        if ((uint64_t)oposw + rest > fcs) FAIL();
+                        if (ltype == 1) {
+                            for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
+                        } else {
+                            for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = litp[lposw + k];
+                        }
+                        lpos = regen;
+                        __syncthreads();
+                        PHASE(11);
+                        // ---- (C) matches, 64 sequences per trip, in rounds: a match may be copied once everything
+                        // below the first not yet copied match of the trip is final and its source ends below that
+                        // point; the first one is always ready (a lane copies byte by byte, so it may overlap itself)
+                        uint32_t ow = opos;
+                        for (uint32_t base = 0; base < nseq; base += WAVE) {
+                            const uint32_t i = base + (uint32_t)lane;
+                            const uint4 sv = i < nseq ? seqbuf[i] : make_uint4(0u, 0u, 0u, 0u);
+                            const uint32_t tot = sv.x + sv.y;
+                            const uint32_t it = wave_incl_scan_u32(tot);
+                            const uint32_t mdst = ow + it - sv.y;  // where this lane's match goes
+                            const uint32_t msrc = mdst - sv.z;
+                            uint64_t todo = __ballot(i < nseq && sv.y != 0);
+                            while (todo) {
+                                const int f = __ffsll((long long)todo) - 1;
+                                const uint32_t frontier = (uint32_t)__shfl((int)mdst, f, 64);
+                                const bool mine = ((todo >> lane) & 1ull) && (lane == f || msrc + sv.y <= frontier || sv.z <= sv.x);  // ... or its source lies in its own literals
+                                if (mine) {  // a match longer than its offset repeats the bytes in front of it
+                                    if (sv.z >= sv.y) {
+                                        for (uint32_t k = 0; k < sv.y; ++k) dst[mdst + k] = dst[msrc + k];
+                                    } else {
+                                        for (uint32_t k = 0; k < sv.y; ++k) dst[mdst + k] = dst[msrc + (k % sv.z)];
+                                    }
+                                }
+                                todo &= ~__ballot(mine);
+                                __syncthreads();  // these bytes are sources of later matches
+                            }
+                            ow += (uint32_t)__shfl((int)it, 63, 64);
+                        }
+                        opos = ow + rest;
+                    }
+                    if (opos - block_start > BLOCK_MAX || opos - block_start > block_max) FAIL();
+                    __syncthreads();
+                    PHASE(4);
+                } else {
                 uint32_t safe = opos;  // output below this position is known to be in memory
                 for (uint32_t i = 0; i < nseq; ++i) {
                     uint32_t llen = 0, mlen = 0, offset = 0;
@@ -1819,6 +2168,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 opos += rest;
                 if (opos - block_start > BLOCK_MAX || opos - block_start > block_max) FAIL();
                 __syncthreads();
+                }
             }
             pos += bsize;
         }
@@ -1848,7 +2198,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     if (opos != fcs) FAIL();
     if (lane == 0) b.result[r] = fcs;
     if (TIMED && lane == 0)
-        for (int k = 0; k < 8; ++k) dbg[(size_t)r * 8 + k] = tph[k];
+        for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
 #undef SQB
 #undef PHASE
 #undef FLUSH

@@ -620,7 +620,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                                                            const uint32_t* src_cap, const SeqCTables* seqtab)
 {
     __shared__ __attribute__((aligned(16))) EncLds L;
-    unsigned long long tph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const uint32_t r = blockIdx.x;
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     }
     if (lane == 0) b.result[r] = opos;
     if (TIMED && lane == 0)
-        for (int k = 0; k < 8; ++k) dbg[(size_t)r * 8 + k] = tph[k];
+        for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
 #undef PHASE
 #undef NEED
 }
