@@ -829,6 +829,7 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
 // Nothing is trusted: the pieces must chain from the end mark to the first bit of the stream and their symbol
 // counts must add up to the stream's regenerated size, else the streams are decoded the ordinary way (which also
 // is what reports a corrupt stream).
+constexpr uint32_t LANE_COPY_MAX = 256;   // sequence execution: longer literal runs and matches are moved by the whole wave
 constexpr uint32_t SPLIT_MIN_BYTES = 1024;  // shorter streams are not worth the extra passes
 constexpr uint32_t SPLIT_RUNUP = 768;       // bits
 
@@ -1228,6 +1229,129 @@ __device__ __noinline__ uint32_t zero_run_chain(const uint8_t* bs_, uint32_t bsn
     return 1u;
 }
 
+// ---- byte movers for sequence execution ----------------------------------------------------------------
+// Literal runs and matches are a few to a few thousand bytes at arbitrary addresses.  A loop of load-then-store is a
+// chain of memory round trips (about a microsecond each); these helpers issue all the loads of a batch before its
+// stores, move 16 bytes per instruction whatever the alignment, and never touch a byte outside [0, n).
+typedef __attribute__((address_space(1), aligned(1))) const u32x4 gld16;
+typedef __attribute__((address_space(1), aligned(1))) u32x4 gst16;
+typedef __attribute__((address_space(1), aligned(1))) const uint32_t gld4;
+typedef __attribute__((address_space(1), aligned(1))) uint32_t gst4;
+typedef __attribute__((address_space(1), aligned(1))) const uint16_t gld2;
+typedef __attribute__((address_space(1), aligned(1))) uint16_t gst2;
+
+// one lane: n bytes from f to o.  The source of a batch (up to 79 bytes) must not be written by the same batch.
+__device__ __forceinline__ void lane_copy(gu8* o, gcu8* f, uint32_t n)
+{
+    uint32_t k = 0;
+    while (n - k >= 64) {
+        const u32x4 a = *(gld16*)(f + k), b = *(gld16*)(f + k + 16), c = *(gld16*)(f + k + 32), d = *(gld16*)(f + k + 48);
+        *(gst16*)(o + k) = a;
+        *(gst16*)(o + k + 16) = b;
+        *(gst16*)(o + k + 32) = c;
+        *(gst16*)(o + k + 48) = d;
+        k += 64;
+    }
+    const uint32_t r = n - k;
+    if (n >= 16) {
+        if (r) {  // whole vectors, then one that ends exactly at n (it may overlap the one before: same bytes)
+            u32x4 a = {}, b = {}, c = {};
+            if (r > 16) a = *(gld16*)(f + k);
+            if (r > 32) b = *(gld16*)(f + k + 16);
+            if (r > 48) c = *(gld16*)(f + k + 32);
+            const u32x4 z = *(gld16*)(f + n - 16);
+            if (r > 16) *(gst16*)(o + k) = a;
+            if (r > 32) *(gst16*)(o + k + 16) = b;
+            if (r > 48) *(gst16*)(o + k + 32) = c;
+            *(gst16*)(o + n - 16) = z;
+        }
+    } else if (n) {  // 8 + 4 + 2 + 1
+        const uint32_t p4 = n & 8u, p2 = n & 12u, p1 = n & 14u;
+        uint32_t a0 = 0, a1 = 0, b = 0, c = 0, d = 0;
+        if (n & 8u) {
+            a0 = *(gld4*)f;
+            a1 = *(gld4*)(f + 4);
+        }
+        if (n & 4u) b = *(gld4*)(f + p4);
+        if (n & 2u) c = *(gld2*)(f + p2);
+        if (n & 1u) d = f[p1];
+        if (n & 8u) {
+            *(gst4*)o = a0;
+            *(gst4*)(o + 4) = a1;
+        }
+        if (n & 4u) *(gst4*)(o + p4) = b;
+        if (n & 2u) *(gst2*)(o + p2) = (uint16_t)c;
+        if (n & 1u) o[p1] = (uint8_t)d;
+    }
+}
+
+// all lanes: n bytes from f to o, the regions do not overlap
+__device__ __forceinline__ void wave_copy(gu8* o, gcu8* f, uint32_t n, int lane)
+{
+    uint32_t k = 16u * (uint32_t)lane;
+    while (k + 3u * 1024u + 16u <= n) {
+        const u32x4 a = *(gld16*)(f + k), b = *(gld16*)(f + k + 1024), c = *(gld16*)(f + k + 2048), d = *(gld16*)(f + k + 3072);
+        *(gst16*)(o + k) = a;
+        *(gst16*)(o + k + 1024) = b;
+        *(gst16*)(o + k + 2048) = c;
+        *(gst16*)(o + k + 3072) = d;
+        k += 4096;
+    }
+    for (; k + 16u <= n; k += 1024u) *(gst16*)(o + k) = *(gld16*)(f + k);
+    const uint32_t r = n & 15u;
+    if ((uint32_t)lane < r) o[n - r + (uint32_t)lane] = f[n - r + (uint32_t)lane];
+}
+
+// 16 bytes of the period-`off` pattern that starts at f (off = 1, 2, 4, 8 or 16; f[0 .. 15] must be readable)
+__device__ __forceinline__ u32x4 period_pattern(gcu8* f, uint32_t off)
+{
+    u32x4 v = *(gld16*)f;
+    if (off == 1) v.x = (v.x & 0xFFu) * 0x01010101u;
+    if (off == 2) v.x = (v.x & 0xFFFFu) * 0x00010001u;
+    if (off <= 4) v.y = v.x;
+    if (off <= 8) {
+        v.z = v.x;
+        v.w = v.y;
+    }
+    return v;
+}
+
+// one lane: n bytes of the pattern v (phase 0 at o)
+__device__ __forceinline__ void lane_fill(gu8* o, u32x4 v, uint32_t n)
+{
+    uint32_t k = 0;
+    for (; k + 16u <= n; k += 16u) *(gst16*)(o + k) = v;
+    if (n & 8u) {
+        *(gst4*)(o + k) = v.x;
+        *(gst4*)(o + k + 4) = v.y;
+        v.x = v.z;
+        v.y = v.w;
+        k += 8;
+    }
+    if (n & 4u) {
+        *(gst4*)(o + k) = v.x;
+        v.x = v.y;
+        k += 4;
+    }
+    if (n & 2u) {
+        *(gst2*)(o + k) = (uint16_t)v.x;
+        v.x >>= 16;
+        k += 2;
+    }
+    if (n & 1u) o[k] = (uint8_t)v.x;
+}
+
+// all lanes: n bytes of the pattern v (phase 0 at o)
+__device__ __forceinline__ void wave_fill(gu8* o, u32x4 v, uint32_t n, int lane)
+{
+    for (uint32_t k = 16u * (uint32_t)lane; k + 16u <= n; k += 1024u) *(gst16*)(o + k) = v;
+    const uint32_t r = n & 15u;
+    if ((uint32_t)lane < r) {
+        const uint32_t w = (lane & 8) ? ((lane & 4) ? v.w : v.z) : ((lane & 4) ? v.y : v.x);
+        o[n - r + (uint32_t)lane] = (uint8_t)(w >> (8 * (lane & 3)));
+    }
+}
+
 // all lanes.  The sequences of a block with arbitrary offsets (libzstd's frames), decoded -- not executed -- into 16-byte
 // records {literal length, match length, offset, 0} at `rec`, fully validated (bit stream, literal budget, offsets
 // inside the output, block and frame size).  The three state machines are one dependent chain: wave-uniform code on
@@ -1245,55 +1369,62 @@ __device__ __noinline__ bool general_sequence_records(const uint8_t* bs_, uint32
     const uint8_t* bs = reinterpret_cast<const uint8_t*>(((uint64_t)uni((uint32_t)((uint64_t)bs_ >> 32)) << 32) |
                                                          uni((uint32_t)(uint64_t)bs_));
     if (bsn == 0) return false;
-    uint32_t k0 = 0;
-    auto load_window = [&]() -> uint32_t {
-        const int64_t off = (int64_t)bsn - 4 * (int64_t)(k0 + (uint32_t)lane + 1);
+    // code -> baseline | extra bits << 24, one code per lane (read with v_readlane: no memory on the chain)
+    const uint32_t llx = lane < 36 ? LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24) : 0u;
+    const uint32_t mlx = lane < 53 ? ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24) : 0u;
+    // the window: lane j holds dwords k0 + j and k0 + 64 + j, counted from the end of the stream.  It is moved only
+    // at the top of the loop (a sequence eats at most 89 bits), so the reads inside never miss.
+    uint32_t k0 = 0, win0, win1;
+    auto load_dword = [&](uint32_t k) -> uint32_t {
+        const int64_t off = (int64_t)bsn - 4 * (int64_t)(k + 1);
         uint32_t v = 0;
         if (off >= 0) {
             __builtin_memcpy(&v, bs + off, 4);
         } else if (off > -4) {
-            for (int k = 0; k < 4 + (int)off; ++k) v |= (uint32_t)bs[k] << (8 * (k - (int)off));
+            for (int b = 0; b < 4 + (int)off; ++b) v |= (uint32_t)bs[b] << (8 * (b - (int)off));
         }
         return v;
     };
-    uint32_t win = load_window();
-    const uint32_t top = lane_get(win, 0) >> 24;
+    win0 = load_dword((uint32_t)lane);
+    win1 = load_dword(64u + (uint32_t)lane);
+    const uint32_t top = lane_get(win0, 0) >> 24;
     if (top == 0) return false;
     const uint32_t hb = (uint32_t)hbit(top);
     uint64_t buf = 0;
     uint32_t have = 0, q = 0;
-    auto refill = [&]() {
+    auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 32
         if (have <= 32) {
-            if (q - k0 == 64) {
-                k0 += 64;
-                win = load_window();
-            }
-            const uint32_t d = lane_get(win, q - k0);
+            const uint32_t idx = q - k0;
+            const uint32_t d0 = lane_get(win0, idx & 63u), d1 = lane_get(win1, idx & 63u);
+            const uint32_t d = idx < 64 ? d0 : d1;
             ++q;
             buf |= (uint64_t)d << (32 - have);
             have += 32;
         }
-    };
-    auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 32
-        refill();
         const uint32_t v = (uint32_t)((buf >> 1) >> (63 - nb));
         buf <<= nb;
         have -= nb;
         return v;
     };
-    refill();
-    buf <<= 8 - hb;
-    have -= 8 - hb;
+    (void)take(8 - hb);
     uint32_t sl = take(log_ll), so = take(log_of), sm = take(log_ml);
     uint32_t sum_ll = 0, outp = opos0;
     uint32_t r_ll = 0, r_ml = 0, r_of = 0;
     for (uint32_t i = 0; i < nseq; ++i) {
+        if (q - k0 > 120) {
+            k0 = q;
+            win0 = load_dword(k0 + (uint32_t)lane);
+            win1 = load_dword(k0 + 64u + (uint32_t)lane);
+        }
         const uint32_t el = uni(L.u.p.fse[0][sl]), eo = uni(L.u.p.fse[1][so]), em = uni(L.u.p.fse[2][sm]);
         const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
         if (lc > 35 || mc > 52 || oc > 31) return false;
-        const uint32_t ofv = (oc ? (1u << oc) : 1u) + (oc ? take(oc) : 0u);
-        const uint32_t mlen = ML_BASE[mc] + take(ML_BITS[mc]);
-        const uint32_t llen = LL_BASE[lc] + take(LL_BITS[lc]);
+        const uint32_t lx = lane_get(llx, lc), mx = lane_get(mlx, mc);
+        const uint32_t lb = lx >> 24, mb = mx >> 24;
+        const uint32_t ofv = (1u << oc) + take(oc);             // RFC 8878 3.1.1.3.2.1.1: offset bits first,
+        const uint32_t ex = take(mb + lb);                      // then match length, then literal length
+        const uint32_t mlen = (mx & 0xFFFFFFu) + (ex >> lb);
+        const uint32_t llen = (lx & 0xFFFFFFu) + (ex & ((1u << lb) - 1u));
         uint32_t offset;
         if (ofv > 3) {
             offset = ofv - 3;
@@ -1310,10 +1441,12 @@ __device__ __noinline__ bool general_sequence_records(const uint8_t* bs_, uint32
                 rep0 = offset;
             }
         }
-        if (i + 1 < nseq) {
-            sl = (el >> 16) + take((el >> 8) & 0xFF);
-            sm = (em >> 16) + take((em >> 8) & 0xFF);
-            so = (eo >> 16) + take((eo >> 8) & 0xFF);
+        if (i + 1 < nseq) {  // the three states move on: LL, ML, OF (at most 9 + 9 + 8 bits)
+            const uint32_t nl = (el >> 8) & 0xFF, nm = (em >> 8) & 0xFF, no = (eo >> 8) & 0xFF;
+            const uint32_t v = take(nl + nm + no);
+            sl = (el >> 16) + (v >> (nm + no));
+            sm = (em >> 16) + ((v >> no) & ((1u << nm) - 1u));
+            so = (eo >> 16) + (v & ((1u << no) - 1u));
         }
         sum_ll += llen;
         if (sum_ll > regen || (uint64_t)outp + llen + mlen > fcs) return false;
@@ -2021,17 +2154,17 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                             const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(tot);
                             const uint32_t lp = lposw + il - ll;
                             uint8_t* o = dst + oposw + it - tot;
+                            const bool big = ll > LANE_COPY_MAX;  // long runs are moved by the whole wave
                             if (ltype == 1) {
                                 for (uint32_t k = 0; k < ll; ++k) o[k] = rle_byte;
-                            } else {
-                                const uint8_t* f = litp + lp;
-                                uint32_t k = 0;
-                                for (; k + 4 <= ll; k += 4) {
-                                    uint32_t v;
-                                    __builtin_memcpy(&v, f + k, 4);
-                                    __builtin_memcpy(o + k, &v, 4);
-                                }
-                                for (; k < ll; ++k) o[k] = f[k];
+                            } else if (!big) {
+                                lane_copy((gu8*)o, (gcu8*)(litp + lp), ll);
+                            }
+                            for (uint64_t bigs = ltype == 1 ? 0ull : __ballot(big); bigs; bigs &= bigs - 1) {
+                                const int bl = __ffsll((long long)bigs) - 1;
+                                const uint32_t bo = (uint32_t)__shfl((int)(oposw + it - tot), bl, 64);
+                                const uint32_t bf = (uint32_t)__shfl((int)lp, bl, 64);
+                                wave_copy((gu8*)dst + bo, (gcu8*)litp + bf, (uint32_t)__shfl((int)ll, bl, 64), lane);
                             }
                             lposw += (uint32_t)__shfl((int)il, 63, 64);
                             oposw += (uint32_t)__shfl((int)it, 63, 64);
@@ -2042,7 +2175,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if (ltype == 1) {
                             for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
                         } else {
-                            for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = litp[lposw + k];
+                            wave_copy((gu8*)dst + oposw, (gcu8*)litp + lposw, rest, lane);
                         }
                         lpos = regen;
                         __syncthreads();
@@ -2063,11 +2196,34 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                                 const int f = __ffsll((long long)todo) - 1;
                                 const uint32_t frontier = (uint32_t)__shfl((int)mdst, f, 64);
                                 const bool mine = ((todo >> lane) & 1ull) && (lane == f || msrc + sv.y <= frontier || sv.z <= sv.x);  // ... or its source lies in its own literals
-                                if (mine) {  // a match longer than its offset repeats the bytes in front of it
-                                    if (sv.z >= sv.y) {
-                                        for (uint32_t k = 0; k < sv.y; ++k) dst[mdst + k] = dst[msrc + k];
+                                // a match longer than its offset repeats the bytes in front of it: offsets 1, 2, 4, 8, 16
+                                // (runs of a byte, of a key pattern) become pattern stores, other short offsets go byte by byte
+                                const bool apart = sv.z >= sv.y;
+                                const bool pat = !apart && (sv.z == 1 || sv.z == 2 || sv.z == 4 || sv.z == 8 || sv.z == 16);
+                                const bool big = mine && sv.y > LANE_COPY_MAX && (apart || pat);
+                                u32x4 pv = {};
+                                if (mine && pat) pv = period_pattern((gcu8*)dst + msrc, sv.z);
+                                if (mine && !big) {
+                                    if (apart || sv.z >= 80) {
+                                        lane_copy((gu8*)dst + mdst, (gcu8*)dst + msrc, sv.y);
+                                    } else if (pat) {
+                                        lane_fill((gu8*)dst + mdst, pv, sv.y);
                                     } else {
                                         for (uint32_t k = 0; k < sv.y; ++k) dst[mdst + k] = dst[msrc + (k % sv.z)];
+                                    }
+                                }
+                                for (uint64_t bigs = __ballot(big); bigs; bigs &= bigs - 1) {
+                                    const int bl = __ffsll((long long)bigs) - 1;
+                                    const uint32_t bo = (uint32_t)__shfl((int)mdst, bl, 64), bn = (uint32_t)__shfl((int)sv.y, bl, 64);
+                                    if (__shfl((int)pat, bl, 64)) {
+                                        u32x4 bv;
+                                        bv.x = (uint32_t)__shfl((int)pv.x, bl, 64);
+                                        bv.y = (uint32_t)__shfl((int)pv.y, bl, 64);
+                                        bv.z = (uint32_t)__shfl((int)pv.z, bl, 64);
+                                        bv.w = (uint32_t)__shfl((int)pv.w, bl, 64);
+                                        wave_fill((gu8*)dst + bo, bv, bn, lane);
+                                    } else {
+                                        wave_copy((gu8*)dst + bo, (gcu8*)dst + (uint32_t)__shfl((int)msrc, bl, 64), bn, lane);
                                     }
                                 }
                                 todo &= ~__ballot(mine);
