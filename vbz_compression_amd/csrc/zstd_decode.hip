@@ -1372,11 +1372,11 @@ __device__ __noinline__ bool general_sequence_records(const uint8_t* bs_, uint32
     // code -> baseline | extra bits << 24, one code per lane (read with v_readlane: no memory on the chain)
     const uint32_t llx = lane < 36 ? LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24) : 0u;
     const uint32_t mlx = lane < 53 ? ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24) : 0u;
-    // the window: lane j holds dwords k0 + j and k0 + 64 + j, counted from the end of the stream.  It is moved only
-    // at the top of the loop (a sequence eats at most 89 bits), so the reads inside never miss.
-    uint32_t k0 = 0, win0, win1;
-    auto load_dword = [&](uint32_t k) -> uint32_t {
-        const int64_t off = (int64_t)bsn - 4 * (int64_t)(k + 1);
+    // the window: lane j holds dword k0 + j, counted from the end of the stream (beyond the start: zeros).  It is
+    // moved only at the top of the loop (a sequence eats at most 89 bits), so the reads inside never miss.  There is no
+    // bit buffer: `pos` bits are consumed, the next ones are {D[pos / 32], D[pos / 32 + 1]} << pos % 32.
+    auto load_window = [&](uint32_t k0) -> uint32_t {
+        const int64_t off = (int64_t)bsn - 4 * (int64_t)(k0 + (uint32_t)lane + 1);
         uint32_t v = 0;
         if (off >= 0) {
             __builtin_memcpy(&v, bs + off, 4);
@@ -1385,75 +1385,60 @@ __device__ __noinline__ bool general_sequence_records(const uint8_t* bs_, uint32
         }
         return v;
     };
-    win0 = load_dword((uint32_t)lane);
-    win1 = load_dword(64u + (uint32_t)lane);
-    const uint32_t top = lane_get(win0, 0) >> 24;
+    uint32_t k0 = 0;
+    uint32_t win = load_window(0);
+    const uint32_t top = lane_get(win, 0) >> 24;
     if (top == 0) return false;
-    const uint32_t hb = (uint32_t)hbit(top);
-    uint64_t buf = 0;
-    uint32_t have = 0, q = 0;
+    uint32_t pos = 8u - (uint32_t)hbit(top);
     auto take = [&](uint32_t nb) -> uint32_t {  // nb <= 32
-        if (have <= 32) {
-            const uint32_t idx = q - k0;
-            const uint32_t d0 = lane_get(win0, idx & 63u), d1 = lane_get(win1, idx & 63u);
-            const uint32_t d = idx < 64 ? d0 : d1;
-            ++q;
-            buf |= (uint64_t)d << (32 - have);
-            have += 32;
-        }
-        const uint32_t v = (uint32_t)((buf >> 1) >> (63 - nb));
-        buf <<= nb;
-        have -= nb;
+        const uint32_t k = (pos >> 5) - k0;
+        const uint64_t two = ((uint64_t)lane_get(win, k) << 32) | lane_get(win, k + 1);
+        const uint32_t v = (uint32_t)(((two << (pos & 31u)) >> 1) >> (63 - nb));
+        pos += nb;
         return v;
     };
-    (void)take(8 - hb);
     uint32_t sl = take(log_ll), so = take(log_of), sm = take(log_ml);
-    uint32_t sum_ll = 0, outp = opos0;
+    // checks that cannot lead a read or write astray are collected and looked at once, behind the loop
+    uint64_t sum_ll = 0, outp = opos0;
+    uint32_t worst_l = 0, worst_o = 0, worst_m = 0, astray = 0;
     uint32_t r_ll = 0, r_ml = 0, r_of = 0;
     for (uint32_t i = 0; i < nseq; ++i) {
-        if (q - k0 > 120) {
-            k0 = q;
-            win0 = load_dword(k0 + (uint32_t)lane);
-            win1 = load_dword(k0 + 64u + (uint32_t)lane);
+        if ((pos >> 5) - k0 > 58) {
+            k0 = pos >> 5;
+            win = load_window(k0);
         }
         const uint32_t el = uni(L.u.p.fse[0][sl]), eo = uni(L.u.p.fse[1][so]), em = uni(L.u.p.fse[2][sm]);
         const uint32_t lc = el & 0xFF, oc = eo & 0xFF, mc = em & 0xFF;
-        if (lc > 35 || mc > 52 || oc > 31) return false;
-        const uint32_t lx = lane_get(llx, lc), mx = lane_get(mlx, mc);
+        worst_l = lc > worst_l ? lc : worst_l;
+        worst_o = oc > worst_o ? oc : worst_o;
+        worst_m = mc > worst_m ? mc : worst_m;
+        const uint32_t lx = lane_get(llx, lc & 63u), mx = lane_get(mlx, mc & 63u);
         const uint32_t lb = lx >> 24, mb = mx >> 24;
-        const uint32_t ofv = (1u << oc) + take(oc);             // RFC 8878 3.1.1.3.2.1.1: offset bits first,
-        const uint32_t ex = take(mb + lb);                      // then match length, then literal length
+        const uint32_t ofv = (1u << (oc & 31u)) + take(oc & 31u);  // RFC 8878 3.1.1.3.2.1.1: offset bits first,
+        const uint32_t ex = take(mb + lb);                          // then match length, then literal length
         const uint32_t mlen = (mx & 0xFFFFFFu) + (ex >> lb);
         const uint32_t llen = (lx & 0xFFFFFFu) + (ex & ((1u << lb) - 1u));
-        uint32_t offset;
-        if (ofv > 3) {
-            offset = ofv - 3;
-            rep2 = rep1; rep1 = rep0; rep0 = offset;
-        } else {
-            const uint32_t idx = ofv - 1 + (llen == 0 ? 1u : 0u);
-            if (idx == 0) {
-                offset = rep0;
-            } else {
-                offset = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                if (offset == 0) offset = 1;  // libzstd forces an invalid 0 to 1
-                if (idx > 1) rep2 = rep1;
-                rep1 = rep0;
-                rep0 = offset;
-            }
-        }
-        if (i + 1 < nseq) {  // the three states move on: LL, ML, OF (at most 9 + 9 + 8 bits)
-            const uint32_t nl = (el >> 8) & 0xFF, nm = (em >> 8) & 0xFF, no = (eo >> 8) & 0xFF;
+        // repeat offsets (3.1.1.5), branch free: idx 0 = rep0 as it is, 1 = rep1, 2 = rep2, 3 = rep0 - 1
+        const bool isrep = ofv <= 3;
+        const uint32_t idx = ofv - 1 + (llen == 0 ? 1u : 0u);
+        uint32_t cand = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - (idx == 3 ? 1u : 0u));
+        cand = cand ? cand : 1u;  // libzstd forces an invalid 0 to 1
+        const uint32_t offset = isrep ? cand : ofv - 3;
+        rep2 = (isrep && idx <= 1) ? rep2 : rep1;
+        rep1 = (isrep && idx == 0) ? rep1 : rep0;
+        rep0 = offset;
+        {  // the three states move on: LL, ML, OF (at most 9 + 9 + 8 bits; the last sequence reads none)
+            const bool last = i + 1 == nseq;
+            const uint32_t nl = last ? 0u : (el >> 8) & 0xFF, nm = last ? 0u : (em >> 8) & 0xFF, no = last ? 0u : (eo >> 8) & 0xFF;
             const uint32_t v = take(nl + nm + no);
             sl = (el >> 16) + (v >> (nm + no));
             sm = (em >> 16) + ((v >> no) & ((1u << nm) - 1u));
             so = (eo >> 16) + (v & ((1u << no) - 1u));
         }
         sum_ll += llen;
-        if (sum_ll > regen || (uint64_t)outp + llen + mlen > fcs) return false;
         outp += llen;
-        if (offset > outp) return false;
+        astray += offset > outp ? 1u : 0u;
         outp += mlen;
-        if (outp - opos0 > BLOCK_MAX) return false;
         const bool mine = (uint32_t)lane == (i & 63);
         r_ll = mine ? llen : r_ll;
         r_ml = mine ? mlen : r_ml;
@@ -1461,8 +1446,9 @@ __device__ __noinline__ bool general_sequence_records(const uint8_t* bs_, uint32
         if ((i & 63) == 63) rec[(i & ~63u) + (uint32_t)lane] = make_uint4(r_ll, r_ml, r_of, 0u);
     }
     if ((uint32_t)lane < (nseq & 63)) rec[(nseq & ~63u) + (uint32_t)lane] = make_uint4(r_ll, r_ml, r_of, 0u);
-    // every bit consumed, none beyond: bits taken = 32 q - have, of which 8 - hb were padding
-    if ((uint64_t)32 * q - have != (uint64_t)8 * bsn) return false;
+    if (worst_l > 35 || worst_m > 52 || worst_o > 31 || astray) return false;
+    if (sum_ll > regen || outp > fcs || outp - opos0 > BLOCK_MAX) return false;  // both only grow
+    if (pos != 8u * bsn) return false;  // every bit consumed, none beyond
     rep[0] = rep0;
     rep[1] = rep1;
     rep[2] = rep2;
