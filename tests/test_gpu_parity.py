@@ -190,6 +190,11 @@ def test_zstd_decode_libzstd_frames():
     text = np.frombuffer((b"the quick brown fox jumps over the lazy dog " * 4000), np.uint8)
     contents.append(text.copy())                                                      # long matches, repeat offsets
     contents.append(np.minimum(rng.geometric(0.3, 150000), 255).astype(np.uint8))
+    # matches that overlap their own output, at every kind of distance the byte movers tell apart
+    for period in (1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 63, 64, 79, 80, 81, 100, 255, 256, 257, 1000, 5000):
+        unit = rng.integers(0, 256, period, dtype=np.uint8)
+        rep = np.tile(unit, 40000 // period + 2)[: 40000 + period % 7]
+        contents.append(np.concatenate([rng.integers(0, 256, 37 + period % 11, dtype=np.uint8), rep, unit[: period // 2], rep[: 300 + period]]))
     frames, want = [], []
     for c in contents:
         for level in (1, 3, 9):
@@ -349,6 +354,38 @@ def test_zstd_decode_rejects_corruption():
             assert isinstance(g, int) and g == 0xFFFFFFFF
         else:
             assert _same(g, mine)
+
+
+def test_zstd_decode_rejects_corruption_of_long_libzstd_frames():
+    """A read-sized frame of the reference: its four literal streams are long enough to be decoded in 64 pieces and its
+    sequences are executed out of order.  Damage must be handled exactly as the strict restatement handles it."""
+    import gpu_util as G
+
+    if O.lib().vbo_zstd_version() is None:
+        pytest.skip("no libzstd on this box")
+    rng = np.random.default_rng(35)
+    s = O.svb_compress(O.synth_signal(5, 7, 120000), 2, True, 0)
+    frames, sizes = [], []
+    for level in (1, 3):
+        frame = O.zstd_compress(s, level)
+        frames += [frame[:cut].copy() for cut in (len(frame) // 3, len(frame) - 2)]
+        for k in range(80):
+            bad = frame.copy()
+            for _ in range(int(rng.integers(1, 3))):
+                # every region gets its share: headers, trees, the streams, the sequence section
+                lo = 0 if k % 4 else int(len(bad) * 0.9)
+                bad[int(rng.integers(lo, len(bad)))] ^= 1 << int(rng.integers(0, 8))
+            frames.append(bad)
+    got = G.zstd_decompress(frames, [len(s)] * len(frames))
+    refused = 0
+    for f, g in zip(frames, got):
+        mine = O.zstd_restate_decompress(f, len(s))
+        if mine is None:
+            refused += 1
+            assert isinstance(g, int) and g == 0xFFFFFFFF
+        else:
+            assert _same(g, mine)
+    assert refused > 20
 
 
 def test_zstd_decode_rejects_corruption_of_own_frames():
