@@ -87,3 +87,29 @@ def test_no_silent_cpu_fallback():
     r = L.vbz_compress(src, 32, dst, 256, ctypes.byref(C(True, 2, 1, 0)))
     assert r == _lib.VBZ_DEVICE_ERROR
     assert not L.vbz_gpu_create(0, None)
+
+
+def test_fast5_repacker_builds_and_lists_without_a_gpu(tmp_path):
+    """bin/vbz_fast5_repack exists after build() and reads a gzip fast5 (no codec work, so no GPU): the samples of
+    the reference's test file match the sha256 the golden index holds for them."""
+    import hashlib
+    import json
+
+    import numpy as np
+
+    from vbz_compression_amd import fast5
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    assert os.path.exists(fast5.TOOL)
+    try:
+        reads = fast5.list_fast5(os.path.join(golden, "multi_fast5_zip.fast5"), export_signal=str(tmp_path / "sig"))
+    except fast5.Hdf5NotFound:
+        pytest.skip("no libhdf5 >= 1.10.3 here")
+    idx = {e["read"]: e for e in json.load(open(os.path.join(golden, "fast5_chunks.json")))}
+    sig = np.fromfile(str(tmp_path / "sig"), np.int16)
+    pos = 0
+    assert len(reads) == 10
+    for r in reads:
+        assert r["samples"] == idx[r["name"]]["samples"] and r["filters"] == [1]
+        assert hashlib.sha256(sig[pos : pos + r["samples"]].tobytes()).hexdigest() == idx[r["name"]]["raw_sha256"]
+        pos += r["samples"]

@@ -733,3 +733,54 @@ def test_hdf5_filter_32020_calling_convention():
         total_gpu += len(mine)
     print("real reads: gpu %d B, reference %d B" % (total_gpu, total_ref))
     assert abs(total_gpu / total_ref - 1.0) < 0.01, (total_gpu, total_ref)
+
+
+@pytest.mark.gpu
+def test_fast5_bulk_repacker(tmp_path):
+    """the reference's fast5 conversion (python/fast5compress/fast5vbz.py:17-55) done in bulk -- every
+    read_*/Raw/Signal of a multi-read file coded in one batched GPU call and stored with H5Dwrite_chunk.  The file is
+    the reference's own test file (python/test/test_vbz_filter.py:57-73 reads the same reads).  What must hold: the
+    samples survive (sha256 pinned by the golden index), every stored chunk is a sized VBZ buffer the reference path
+    decodes, sizes are within 1 % of the reference's, and -d brings the file back to gzip."""
+    import hashlib
+    import shutil
+
+    from vbz_compression_amd import fast5
+
+    src = str(tmp_path / "reads.fast5")
+    shutil.copy(os.path.join(GOLDEN, "multi_fast5_zip.fast5"), src)
+    idx = {e["read"]: e for e in json.load(open(os.path.join(GOLDEN, "fast5_chunks.json")))}
+    try:
+        before = fast5.list_fast5(src, export_signal=str(tmp_path / "sig0"))
+    except fast5.Hdf5NotFound:
+        pytest.skip("no libhdf5 >= 1.10.3 on this box")
+    assert len(before) == 10 and all(r["filters"] == [1] and r["integer_size"] == 2 for r in before)
+    sig = np.fromfile(str(tmp_path / "sig0"), np.int16)
+    pos, signals = 0, {}
+    for r in before:
+        signals[r["name"]] = sig[pos : pos + r["samples"]]
+        pos += r["samples"]
+        assert hashlib.sha256(signals[r["name"]].tobytes()).hexdigest() == idx[r["name"]]["raw_sha256"]
+    for version in (1, 0):
+        out = fast5.compress_fast5(src, ".v%d" % version, vbz_version=version)
+        assert out == src + ".v%d" % version
+        after = fast5.list_fast5(out, export_chunks=str(tmp_path / "chunks"))
+        assert [r["name"] for r in after] == [r["name"] for r in before]
+        chunks = np.fromfile(str(tmp_path / "chunks"), np.uint8)
+        pos = 0
+        oo = O.options(True, 2, 1, version)
+        for r, r0 in zip(after, before):
+            assert r["filters"] == [32020] and r["samples"] == r0["samples"] and r["fnv1a64"] == r0["fnv1a64"]
+            assert r["chunk_bytes"] == r["stored_bytes"] > 0
+            chunk = chunks[pos : pos + r["chunk_bytes"]]
+            pos += r["chunk_bytes"]
+            want = signals[r["name"]]
+            back = O.decompress(chunk, want.nbytes, oo, sized=True)        # the reference path reads what was written
+            assert not isinstance(back, int) and back.tobytes() == want.tobytes()
+            ref = O.compress(want, oo, sized=True)
+            assert abs(len(chunk) - len(ref)) <= 0.01 * len(ref) + 16, (r["name"], len(chunk), len(ref))
+            assert abs(len(chunk) - idx[r["name"]]["chunk_size"]) <= 0.01 * idx[r["name"]]["chunk_size"] + 16  # the shipped vbz file
+    # and back to gzip (fast5vbz.py -d), reading the vbz chunks directly
+    back = fast5.compress_fast5(src + ".v1", ".gz", decompress=True)
+    again = fast5.list_fast5(back)
+    assert [(r["name"], r["filters"], r["fnv1a64"]) for r in again] == [(r["name"], [1], r["fnv1a64"]) for r in before]

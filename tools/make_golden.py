@@ -12,6 +12,8 @@ Writes under tests/golden/:
                           v1 file's chunks, plus the sha256 of the int16 samples each must decode
                           to, taken from test_data/multi_fast5_zip.fast5
                           (reference python/test/test_vbz_filter.py:57-73 asserts exactly this).
+  multi_fast5_zip.fast5   the reference's own test file (test_data/, gzip-compressed signal of 10 reads), byte for byte:
+                          the input of the fast5 re-packer tests (python/test/test_vbz_filter.py:57-73 reads it too)
 Nothing here copies reference source text; these are inputs and expected outputs.
 """
 import hashlib
@@ -72,6 +74,9 @@ def main():
         )
         blob += c0
         print(key, len(raw), len(c0), c0 == c1)
+    import shutil
+
+    shutil.copyfile(os.path.join(REF, "test_data/multi_fast5_zip.fast5"), os.path.join(OUT, "multi_fast5_zip.fast5"))
     open(os.path.join(OUT, "fast5_chunks.bin"), "wb").write(bytes(blob))
     json.dump(index, open(os.path.join(OUT, "fast5_chunks.json"), "w"), indent=1)
     print("chunks bytes", len(blob))

@@ -1,6 +1,6 @@
 """Build the HIP shared libraries in-tree (so they travel with gpurun snapshots).
 
-    python -m vbz_compression_amd.build            # libvbz_hip.so + libvbz_hdf_plugin.so
+    python -m vbz_compression_amd.build            # libvbz_hip.so + libvbz_hdf_plugin.so + bin/vbz_fast5_repack
 
 hipcc cross-compiles gfx950 code objects without a GPU present.
 """
@@ -58,6 +58,19 @@ def build(force=False, verbose=True):
     if os.path.exists(plugin_src) and (force or _stale(plugin, [plugin_src, lib] + hdrs)):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-o", plugin, plugin_src,
                "-L" + LIBDIR, "-lvbz_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    # bulk fast5 re-packer (host program: libhdf5 is loaded at run time, the codec is libvbz_hip.so)
+    tool_src = os.path.join(CSRC, "fast5_repack.cpp")
+    bindir = os.path.join(HERE, "bin")
+    tool = os.path.join(bindir, "vbz_fast5_repack")
+    if os.path.exists(tool_src) and (force or _stale(tool, [tool_src, lib, plugin] + hdrs)):
+        os.makedirs(bindir, exist_ok=True)
+        rocm = os.path.dirname(os.path.dirname(os.path.realpath(HIPCC)))
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-o", tool, tool_src,
+               "-L" + LIBDIR, "-lvbz_hdf_plugin", "-lvbz_hip", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-ldl",
+               "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(rocm, "lib")]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
