@@ -466,6 +466,56 @@ def test_c_abi_cross_codec_round_trips():
                             assert g.tobytes() == r.tobytes()   # no entropy stage: byte-identical output
 
 
+def test_c_abi_calls_from_many_threads_overlap():
+    """The reference's calls are re-entrant and stateless; its callers parallelise by calling from many threads
+    (SURVEY 8b "Threading").  Here a call borrows one of a pool of contexts, so concurrent calls must (a) stay correct
+    and (b) overlap on the GPU instead of queueing behind one another."""
+    import threading
+    import time
+
+    from vbz_compression_amd import _lib, vbz
+
+    go = _lib.CompressionOptions(True, 2, 1, 1)
+    oo = O.options(True, 2, 1, 1)
+    reads = [O.synth_signal(5, 100 + i, 60000 + 997 * i) for i in range(32)]
+    want = [O.compress(a, oo, sized=True) for a in reads]
+    vbz.compress_raw(reads[0], go, sized=True)  # context creation is not what is timed
+    errors = []
+
+    def work(ids, rounds):
+        try:
+            for _ in range(rounds):
+                for i in ids:
+                    g = vbz.compress_raw(reads[i], go, sized=True)
+                    back = vbz.decompress_raw(want[i], reads[i].nbytes, go, sized=True)    # a frame of the reference
+                    mine = vbz.decompress_raw(g, reads[i].nbytes, go, sized=True)
+                    if isinstance(g, int) or isinstance(back, int) or isinstance(mine, int):
+                        errors.append((i, "error code"))
+                    elif back.tobytes() != reads[i].tobytes() or mine.tobytes() != reads[i].tobytes():
+                        errors.append((i, "bytes differ"))
+                    elif O.decompress(g, reads[i].nbytes, oo, sized=True).tobytes() != reads[i].tobytes():
+                        errors.append((i, "oracle cannot read it"))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", repr(e)))
+
+    def timed(nthreads, rounds):
+        ids = list(range(len(reads)))
+        ts = [threading.Thread(target=work, args=(ids[k::nthreads], rounds)) for k in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return time.perf_counter() - t0
+
+    timed(8, 1)          # warm the pool
+    one = timed(1, 2)
+    eight = timed(8, 2)
+    assert not errors, errors[:3]
+    # most of a call is latency (copies, a handful of one-workgroup kernels): eight callers must not take eight turns
+    assert eight < 0.7 * one, (one, eight)
+
+
 def test_config3_uint32_ten_million_elements():
     """BASELINE.json configs[3]: uint32, no zig-zag (UD=32020,5,0,0,4,0,3), one 10M-element buffer through the
     single-buffer C ABI: many passes of blocks in one frame, every code length; cross-decoded both ways."""

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -609,20 +610,69 @@ int vbz_gpu_profile_read(vbz_gpu_ctx* c, const char** names, uint32_t* launches,
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// The reference's calls are re-entrant and callers parallelise by calling from many threads (vbz.cpp has no
+// statics).  A call here needs a context (stream, device buffers), so there is a pool of them: a caller takes an idle
+// context or creates one -- up to VBZ_HIP_CONTEXTS (default 16) -- and calls from different threads overlap on the
+// GPU, each on its own stream.  Beyond the limit callers wait for a context to come back.
 std::mutex g_mutex;
-vbz_gpu_ctx* g_ctx = nullptr;
+std::condition_variable g_idle_cv;
+std::vector<vbz_gpu_ctx*> g_idle;
+unsigned g_created = 0;
 bool g_ctx_failed = false;
 
-vbz_gpu_ctx* default_ctx()
+unsigned pool_limit()
 {
-    if (!g_ctx && !g_ctx_failed) {
-        int dev = 0;
-        if (const char* e = getenv("VBZ_HIP_DEVICE")) dev = atoi(e);
-        g_ctx = vbz_gpu_create(dev, nullptr);
-        if (!g_ctx) g_ctx_failed = true;
-    }
-    return g_ctx;
+    unsigned n = 16;
+    if (const char* e = getenv("VBZ_HIP_CONTEXTS")) n = (unsigned)atoi(e);
+    return n < 1 ? 1 : (n > 256 ? 256 : n);
 }
+
+vbz_gpu_ctx* take_ctx()
+{
+    std::unique_lock<std::mutex> lock(g_mutex);
+    for (;;) {
+        if (!g_idle.empty()) {
+            vbz_gpu_ctx* c = g_idle.back();
+            g_idle.pop_back();
+            return c;
+        }
+        if (g_ctx_failed) return nullptr;
+        if (g_created < pool_limit()) {
+            ++g_created;
+            lock.unlock();
+            int dev = 0;
+            if (const char* e = getenv("VBZ_HIP_DEVICE")) dev = atoi(e);
+            vbz_gpu_ctx* c = vbz_gpu_create(dev, nullptr);
+            lock.lock();
+            if (c) return c;
+            --g_created;
+            if (g_created == 0) g_ctx_failed = true;  // no usable device: every call reports VBZ_DEVICE_ERROR
+            g_idle_cv.notify_all();
+            if (g_ctx_failed) return nullptr;
+            continue;
+        }
+        g_idle_cv.wait(lock);
+    }
+}
+
+void give_ctx(vbz_gpu_ctx* c)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        g_idle.push_back(c);
+    }
+    g_idle_cv.notify_one();
+}
+
+struct CtxLease
+{
+    vbz_gpu_ctx* c;
+    CtxLease() : c(take_ctx()) {}
+    ~CtxLease()
+    {
+        if (c) give_ctx(c);
+    }
+};
 
 struct OneMeta  // device-side descriptors of a one-read batch
 {
@@ -634,8 +684,8 @@ struct OneMeta  // device-side descriptors of a one-read batch
 vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* dst, vbz_size_t dst_cap, vbz_size_t dev_cap,
                    const CompressionOptions* o, int sized)
 {
-    std::lock_guard<std::mutex> lock(g_mutex);
-    vbz_gpu_ctx* c = default_ctx();
+    CtxLease lease;
+    vbz_gpu_ctx* c = lease.c;
     if (!c) return VBZ_DEVICE_ERROR;
     (void)hipSetDevice(c->device);
     if (!ensure(c, c->one_in, (size_t)src_size + 64) || !ensure(c, c->one_out, (size_t)dev_cap + 64) ||
@@ -684,7 +734,7 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     result = hm->result;
     if (result >= VBZ_FIRST_ERROR) return result;
     if (result > dst_cap) return VBZ_DESTINATION_SIZE_ERROR;
-    if (result && hipMemcpy(dst, c->one_out.p, result, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (result && (hipMemcpyAsync(dst, c->one_out.p, result, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
         set_error(c, "device to host copy failed");
         return VBZ_DEVICE_ERROR;
     }
