@@ -834,3 +834,53 @@ def test_fast5_bulk_repacker(tmp_path):
     back = fast5.compress_fast5(src + ".v1", ".gz", decompress=True)
     again = fast5.list_fast5(back)
     assert [(r["name"], r["filters"], r["fnv1a64"]) for r in again] == [(r["name"], [1], r["fnv1a64"]) for r in before]
+
+
+@pytest.mark.gpu
+def test_h5repack_through_filter_32020(tmp_path):
+    """BASELINE.json configs[2]: test_data/multi_fast5_zip.fast5 re-packed by libhdf5's own h5repack with this
+    library's plugin on HDF5_PLUGIN_PATH (UD=32020,0,4,0,2,1,1: the 1.10.6 syntax) -- libhdf5 loads
+    libvbz_hdf_plugin.so and calls vbz_filter once per chunk.  h5diff must find no difference, every chunk must be a sized
+    VBZ buffer the reference path decodes, of the reference's size within 1 %, and byte-identical to what the bulk
+    re-packer writes for the same read (one encoder behind both boundaries)."""
+    import shutil
+    import subprocess
+
+    from vbz_compression_amd import _lib, fast5
+
+    h5repack = shutil.which("h5repack") or "/opt/conda/bin/h5repack"
+    h5diff = shutil.which("h5diff") or "/opt/conda/bin/h5diff"
+    if not (os.path.exists(h5repack) and os.path.exists(h5diff)):
+        pytest.skip("no h5repack / h5diff on this box")
+    src = str(tmp_path / "reads.fast5")
+    out = str(tmp_path / "repacked.fast5")
+    shutil.copy(os.path.join(GOLDEN, "multi_fast5_zip.fast5"), src)
+    env = dict(os.environ, HDF5_PLUGIN_PATH=os.path.dirname(_lib.LIB_PATH))
+    r = subprocess.run([h5repack, "-f", "UD=32020,0,4,0,2,1,1", src, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       universal_newlines=True)
+    assert r.returncode == 0 and "error" not in r.stdout.lower(), r.stdout[-2000:]
+    d = subprocess.run([h5diff, src, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert d.returncode == 0, d.stdout[-2000:]
+    try:
+        before = fast5.list_fast5(src, export_signal=str(tmp_path / "sig"))
+        after = fast5.list_fast5(out, export_chunks=str(tmp_path / "chunks"))
+        bulk = fast5.list_fast5(fast5.compress_fast5(src, ".bulk", vbz_version=0), export_chunks=str(tmp_path / "bulk_chunks"))
+    except fast5.Hdf5NotFound:
+        pytest.skip("no libhdf5 >= 1.10.3 for the listing tool")
+    sig = np.fromfile(str(tmp_path / "sig"), np.int16)
+    chunks = np.fromfile(str(tmp_path / "chunks"), np.uint8)
+    assert chunks.tobytes() == np.fromfile(str(tmp_path / "bulk_chunks"), np.uint8).tobytes()
+    assert [(r["name"], r["fnv1a64"]) for r in after] == [(r["name"], r["fnv1a64"]) for r in before]
+    assert [r["chunk_bytes"] for r in after] == [r["chunk_bytes"] for r in bulk]
+    oo = O.options(True, 2, 1, 0)
+    spos = cpos = 0
+    for r in after:
+        assert r["filters"] == [32020] and r["chunk_bytes"] == r["stored_bytes"] > 0
+        want = sig[spos : spos + r["samples"]]
+        chunk = chunks[cpos : cpos + r["chunk_bytes"]]
+        spos += r["samples"]
+        cpos += r["chunk_bytes"]
+        back = O.decompress(chunk, want.nbytes, oo, sized=True)
+        assert not isinstance(back, int) and back.tobytes() == want.tobytes()
+        ref = O.compress(want, oo, sized=True)
+        assert abs(len(chunk) - len(ref)) <= 0.01 * len(ref) + 16, (r["name"], len(chunk), len(ref))
