@@ -4,15 +4,16 @@
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
 
 #include "vbz.h"
 
-int main()
+int main(int argc, char** argv)
 {
-    const int n = 100000, reads = 64, rounds = 4;
+    const int n = 100000, reads = 64, rounds = argc > 1 ? atoi(argv[1]) : 16;
     std::vector<std::vector<int16_t>> sig(reads, std::vector<int16_t>(n));
     uint64_t x = 88172645463325252ull;
     for (auto& s : sig) {
@@ -27,7 +28,7 @@ int main()
     const vbz_size_t cap = vbz_max_compressed_size(2 * n, &o);
     std::vector<uint8_t> warm(cap);
     if (vbz_is_error(vbz_compress_sized(sig[0].data(), 2 * n, warm.data(), cap, &o))) return 1;
-    for (int nt : { 1, 2, 4, 8, 16, 32, 64 }) {
+    for (int nt : { 64, 1, 2, 4, 8, 16, 32, 64 }) {  // the first line warms the library up (contexts, pinned arenas)
         std::vector<std::thread> ts;
         int bad = 0;
         const auto t0 = std::chrono::steady_clock::now();
