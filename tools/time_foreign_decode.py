@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the decode of frames the reference wrote (libzstd, through the oracle) on a GPU box.
 
-    python tools/time_foreign_decode.py [--reads 2048]
+    python tools/time_foreign_decode.py [--reads 2048] [--samples 400000]
 
 Prints the number of reads that did not decode to their input and the average duration of the decode kernels."""
 import argparse
@@ -19,10 +19,11 @@ import oracle_lib as O  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=2048)
+    ap.add_argument("--samples", type=int, default=0, help="samples per read (default: the generator's ~100 k; larger reads are several blocks)")
     args = ap.parse_args()
     opts = G.codec().options(True, 2, 1, 1)
     oo = O.options(True, 2, 1, 1)
-    reads = [O.synth_signal(5, i, O.synth_read_length(5, i)) for i in range(args.reads)]
+    reads = [O.synth_signal(5, i, args.samples or O.synth_read_length(5, i)) for i in range(args.reads)]
     frames = [O.compress(a, oo, sized=True) for a in reads]
     sizes = [a.nbytes for a in reads]
     got = G.decompress(frames, sizes, opts, sized=True)

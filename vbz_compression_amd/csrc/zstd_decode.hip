@@ -818,8 +818,8 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
 // ---- long Huffman streams, split ----------------------------------------------------------------------
 // libzstd writes the literals of a block as four streams of up to 32 KB: four busy lanes, sixty idle ones, and the
 // longest dependent chain of the whole frame.  Huffman codes resynchronise: a decoder started at an arbitrary bit
-// falls into step with the real code boundaries after a few dozen symbols.  So every stream is cut into 16 pieces of
-// equal bit length, one lane each:
+// falls into step with the real code boundaries after a few dozen symbols.  So every stream is cut into pieces of
+// equal bit length, one lane each (16 pieces for up to 4 queued streams, 8 / 4 / 2 for up to 8 / 16 / 32):
 //   pass 0  a lane starts SPLIT_RUNUP bits before its piece and walks to the first code boundary inside it: its
 //           presumed start;
 //   pass 1  from there it walks its piece to the first boundary inside the next one, counting symbols;
@@ -830,7 +830,7 @@ __device__ __noinline__ bool flush_tasks_ring(const uint8_t* src, uint8_t* dst, 
 // counts must add up to the stream's regenerated size, else the streams are decoded the ordinary way (which also
 // is what reports a corrupt stream).
 constexpr uint32_t LANE_COPY_MAX = 256;   // sequence execution: longer literal runs and matches are moved by the whole wave
-constexpr uint32_t SPLIT_MIN_BYTES = 1024;  // shorter streams are not worth the extra passes
+constexpr uint32_t SPLIT_MIN_PIECE = 64;    // bytes: shorter pieces are not worth the extra passes
 constexpr uint32_t SPLIT_RUNUP = 768;       // bits
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
@@ -909,8 +909,11 @@ __device__ __noinline__ uint2 huf_dry_walk(const uint8_t* stream, uint32_t nbyte
 __device__ __noinline__ bool huf_split_plan(const uint8_t* src, uint32_t& ntask, int lane)
 {
     const uint32_t nt = ntask;
-    if (nt == 0 || nt > 4) return false;
-    const uint32_t t = (uint32_t)lane >> 4, j = (uint32_t)lane & 15u;
+    if (nt == 0 || nt > 32) return false;
+    // 1-4 streams: 16 pieces each; up to 8: 8; up to 16: 4; up to 32: 2 (reads of several blocks queue 4 streams a block)
+    const uint32_t gs = nt <= 4 ? 4u : (nt <= 8 ? 3u : (nt <= 16 ? 2u : 1u));
+    const uint32_t G = 1u << gs;
+    const uint32_t t = (uint32_t)lane >> gs, j = (uint32_t)lane & (G - 1u);
     const bool act = t < nt;
     uint32_t so = 0, nbytes = 0, out = 0, cnt = 0, tab = 0;
     if (act) {
@@ -920,13 +923,13 @@ __device__ __noinline__ bool huf_split_plan(const uint8_t* src, uint32_t& ntask,
         cnt = L.t_cnt[t];
         tab = L.t_tab[t];
     }
-    if (__any(act && nbytes < SPLIT_MIN_BYTES)) return false;
+    if (__any(act && nbytes < SPLIT_MIN_PIECE * G)) return false;
     const uint8_t* p = src + so;
     const uint32_t last = act ? p[nbytes - 1] : 1u;
     if (__any(last == 0)) return false;
     const uint32_t pad = 8u - (uint32_t)hbit(last), B = 8u * nbytes;
-    const uint32_t seg = (B - pad + 15u) / 16u;
-    const uint32_t c_lo = pad + j * seg, c_hi = j == 15 ? B : pad + (j + 1u) * seg;
+    const uint32_t seg = (B - pad + G - 1u) >> gs;
+    const uint32_t c_lo = pad + j * seg, c_hi = j == G - 1u ? B : pad + (j + 1u) * seg;
     // pass 0: where this piece presumably starts
     uint32_t s_bit = pad;
     {
@@ -954,9 +957,9 @@ __device__ __noinline__ bool huf_split_plan(const uint8_t* src, uint32_t& ntask,
     if (__any(need)) return false;
     // the pieces chain; do they cover the stream, symbol for symbol?
     const uint32_t incl = wave_incl_scan_u32(act ? m : 0u);
-    const uint32_t before = (uint32_t)__shfl((int)incl, t ? (int)(t * 16u) - 1 : 0, 64) * (t ? 1u : 0u);
-    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(t * 16u + 15u), 64) - before;
-    if (__any(act && (total != cnt || (j == 15 && e_bit != B)))) return false;
+    const uint32_t before = (uint32_t)__shfl((int)incl, t ? (int)(t * G) - 1 : 0, 64) * (t ? 1u : 0u);
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)((t * G + G - 1u) & 63u), 64) - before;
+    if (__any(act && (total != cnt || (j == G - 1u && e_bit != B)))) return false;
     wave_lds_sync();
     L.t_src[lane] = so;
     L.t_size[lane] = nbytes;
