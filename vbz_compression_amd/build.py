@@ -69,7 +69,7 @@ def build(force=False, verbose=True):
         os.makedirs(bindir, exist_ok=True)
         rocm = os.path.dirname(os.path.dirname(os.path.realpath(HIPCC)))
         cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-o", tool, tool_src,
-               "-L" + LIBDIR, "-lvbz_hdf_plugin", "-lvbz_hip", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-ldl",
+               "-L" + LIBDIR, "-lvbz_hdf_plugin", "-lvbz_hip", "-L" + os.path.join(rocm, "lib"), "-lamdhip64", "-ldl", "-lz", "-pthread",
                "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(rocm, "lib")]
         if verbose:
             print(" ".join(cmd), flush=True)

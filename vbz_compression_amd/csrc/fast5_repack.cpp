@@ -7,7 +7,9 @@
 // the codec out of the per-chunk callback: all signals of a file are read first, coded in ONE batched call on the
 // GPU (include/vbz_gpu.h), and the finished chunks are handed to libhdf5 with H5Dwrite_chunk, which stores them
 // as they are.  The other direction (-d: back to gzip, as the reference's script does) reads the stored chunks
-// with H5Dread_chunk and decodes them in one batch.
+// with H5Dread_chunk and decodes them in one batch.  gzip, the other side of both conversions, is host work: chunks
+// stored with deflate alone are read and written raw as well and (de)flated by a pool of threads, not one by one
+// inside libhdf5.
 //
 //   vbz_fast5_repack [-d] [-s SUFFIX] [--vbz-version N] FILE...      (fast5vbz.py:58-75)
 //   vbz_fast5_repack --list FILE [--export-signal OUT] [--export-chunks OUT]
@@ -16,6 +18,7 @@
 // usual names.  Its few entry points used here are declared below with their public 1.10 signatures.
 #include <dlfcn.h>
 #include <hip/hip_runtime_api.h>
+#include <zlib.h>
 
 #include <chrono>
 #include <cstdint>
@@ -23,7 +26,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/vbz.h"
@@ -83,7 +88,7 @@ struct Hdf5
     hid_t dataset_create_class = 0;  // H5P_DATASET_CREATE
 };
 
-const int H5D_CHUNKED = 2, H5T_INTEGER = 0;
+const int H5D_CHUNKED = 2, H5T_INTEGER = 0, H5Z_FILTER_DEFLATE = 1;
 const unsigned H5F_ACC_RDONLY = 0, H5F_ACC_RDWR = 1, H5Z_FLAG_OPTIONAL = 1;
 
 bool load_hdf5(Hdf5& h, const char* wanted)
@@ -149,6 +154,8 @@ struct Read
     std::string filters;
     std::vector<uint8_t> signal;  // raw samples, file byte order
     std::vector<uint8_t> chunk;   // stored chunk (vbz, one chunk)
+    bool gz = false;              // stored with deflate alone, as a single chunk: read raw, inflated by the pool
+    uint64_t chunk_elems = 0;     // chunk dimension (the chunk holds this many samples, the dataset may be shorter)
 };
 
 uint64_t fnv1a64(const uint8_t* p, size_t n)
@@ -165,7 +172,7 @@ double now_ms()
 
 struct Timers
 {
-    double h5_read = 0, h5_write = 0, gpu = 0, copies = 0;
+    double h5_read = 0, h5_write = 0, gpu = 0, copies = 0, zlib = 0;
 };
 
 // the read groups of a multi-read file (fast5vbz.py:38-41)
@@ -208,16 +215,19 @@ bool load_read(const Hdf5& h, hid_t file, Read& r, Timers& t)
                 r.vbz = true;
                 for (size_t k = 0; k < 4 && k < ncd; ++k) r.cd[k] = cd[k];
             }
+            if (id == H5Z_FILTER_DEFLATE && nf == 1) r.gz = true;
         }
         if (r.filters.empty()) r.filters = "-";
         hsize_t cdim[8] = {};
-        if (r.vbz && h.H5Pget_layout(pl) == H5D_CHUNKED && h.H5Sget_simple_extent_ndims(sp) == 1 && h.H5Pget_chunk(pl, 8, cdim) == 1 &&
-            cdim[0] >= r.samples && r.samples > 0)
-            r.one_chunk = true;
+        const bool single = h.H5Pget_layout(pl) == H5D_CHUNKED && h.H5Sget_simple_extent_ndims(sp) == 1 && h.H5Pget_chunk(pl, 8, cdim) == 1 &&
+                            cdim[0] >= r.samples && r.samples > 0;
+        r.one_chunk = r.vbz && single;
+        r.gz = r.gz && single;
+        r.chunk_elems = cdim[0];
         if ((uint64_t)r.samples * r.elem >= 0xFFFFFFF0ull) ok = false;  // vbz sizes are 32 bits (vbz.h:11)
     }
     if (ok) {
-        if (r.one_chunk) {
+        if (r.one_chunk || r.gz) {
             const hsize_t off[1] = { 0 };
             hsize_t bytes = 0;
             uint32_t mask = 0;
@@ -228,11 +238,12 @@ bool load_read(const Hdf5& h, hid_t file, Read& r, Timers& t)
             }
             if (!ok) {  // not there, or stored unfiltered: let libhdf5 read it
                 r.one_chunk = false;
+                r.gz = false;
                 r.chunk.clear();
                 ok = true;
             }
         }
-        if (!r.one_chunk) {
+        if (!r.one_chunk && !r.gz) {
             r.signal.resize(r.samples * r.elem);
             // memory type = file type: no conversion, the bytes as stored (little endian in every fast5)
             if (r.samples) ok = h.H5Dread(d, ty, 0, 0, 0, r.signal.data()) >= 0;
@@ -244,6 +255,63 @@ bool load_read(const Hdf5& h, hid_t file, Read& r, Timers& t)
     h.H5Dclose(d);
     t.h5_read += now_ms() - t0;
     if (!ok) fprintf(stderr, "vbz_fast5_repack: cannot read %s\n", path.c_str());
+    return ok;
+}
+
+// ---- gzip on the host's cores -----------------------------------------------------------------------------
+template <typename F>
+void parallel_for(size_t n, F f)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt < 1 ? 1 : (nt > 64 ? 64 : nt);
+    if (nt > n) nt = (unsigned)n;
+    std::atomic<size_t> next{ 0 };
+    std::vector<std::thread> pool;
+    auto work = [&] {
+        for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1)) f(i);
+    };
+    for (unsigned t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+}
+
+// chunks that were read raw because deflate is their only filter: inflate them all at once.  A chunk that does not
+// inflate to its size is read again through libhdf5 (which also is what reports a damaged file).
+bool inflate_chunks(const Hdf5& h, hid_t file, std::vector<Read>& reads, Timers& t)
+{
+    const double t0 = now_ms();
+    std::vector<size_t> todo;
+    for (size_t i = 0; i < reads.size(); ++i)
+        if (reads[i].gz) todo.push_back(i);
+    std::vector<char> good(todo.size(), 0);
+    parallel_for(todo.size(), [&](size_t k) {
+        Read& r = reads[todo[k]];
+        std::vector<uint8_t> full(r.chunk_elems * r.elem);
+        uLongf len = (uLongf)full.size();
+        if (uncompress(full.data(), &len, r.chunk.data(), (uLong)r.chunk.size()) == Z_OK && len == full.size()) {
+            full.resize(r.samples * r.elem);
+            r.signal.swap(full);
+            good[k] = 1;
+        }
+    });
+    t.zlib += now_ms() - t0;
+    bool ok = true;
+    for (size_t k = 0; k < todo.size(); ++k) {
+        Read& r = reads[todo[k]];
+        r.chunk.clear();
+        r.gz = false;
+        if (good[k]) continue;
+        const std::string path = r.name + "/Raw/Signal";
+        const hid_t d = h.H5Dopen2(file, path.c_str(), 0);
+        const hid_t ty = d >= 0 ? h.H5Dget_type(d) : -1;
+        r.signal.resize(r.samples * r.elem);
+        if (d < 0 || ty < 0 || h.H5Dread(d, ty, 0, 0, 0, r.signal.data()) < 0) {
+            fprintf(stderr, "vbz_fast5_repack: cannot read %s\n", path.c_str());
+            ok = false;
+        }
+        if (ty >= 0) h.H5Tclose(ty);
+        if (d >= 0) h.H5Dclose(d);
+    }
     return ok;
 }
 
@@ -409,7 +477,7 @@ bool compress_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const st
         r.name = name;
         if (load_read(h, file, r, t)) reads.push_back(std::move(r));
     }
-    bool ok = decode_chunks(g, reads, t);
+    bool ok = inflate_chunks(h, file, reads, t) && decode_chunks(g, reads, t);
     // the new chunks: 2-byte (here: elem-byte) integers with zig-zag, level 1 zstd (fast5vbz.py:33-36)
     std::vector<std::vector<uint8_t>> packed(reads.size());
     if (ok && !decompress) {
@@ -431,6 +499,20 @@ bool compress_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const st
             }
             ok = g.init() && run_batch(g, in, out, cap, opt, true, t);
         }
+    }
+    if (ok && decompress) {  // gzip level 1 (fast5vbz.py:30), every read on its own core
+        const double t0 = now_ms();
+        std::vector<char> good(reads.size(), 1);
+        parallel_for(reads.size(), [&](size_t k) {
+            const Read& r = reads[k];
+            if (r.samples == 0) return;
+            uLongf len = compressBound((uLong)r.signal.size());
+            packed[k].resize(len);
+            if (compress2(packed[k].data(), &len, r.signal.data(), (uLong)r.signal.size(), 1) != Z_OK) good[k] = 0;
+            packed[k].resize(len);
+        });
+        for (char gk : good) ok = ok && gk;
+        t.zlib += now_ms() - t0;
     }
     uint64_t raw_bytes = 0, new_bytes = 0;
     for (size_t k = 0; ok && k < reads.size(); ++k) {
@@ -457,8 +539,8 @@ bool compress_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const st
             ok = d >= 0;
             if (ok && r.samples) {
                 const hsize_t off[1] = { 0 };
-                if (decompress) ok = h.H5Dwrite(d, ty, 0, 0, 0, r.signal.data()) >= 0;
-                else ok = h.H5Dwrite_chunk(d, 0, 0 /* every filter applied */, off, packed[k].size(), packed[k].data()) >= 0;
+                // the chunk is stored as it is: filter mask 0 = every filter of the pipeline has been applied
+                ok = h.H5Dwrite_chunk(d, 0, 0, off, packed[k].size(), packed[k].data()) >= 0;
             }
             if (d >= 0) {
                 new_bytes += h.H5Dget_storage_size(d);
@@ -476,9 +558,9 @@ bool compress_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const st
     if (ok) {
         printf("%s\n", out_name.c_str());  // fast5vbz.py:60-64
         fprintf(stderr,
-                "vbz_fast5_repack: %zu reads, %llu raw bytes -> %llu stored; hdf5 read %.1f ms, host<->device %.1f ms, codec %.1f ms, "
-                "hdf5 write %.1f ms, total %.1f ms\n",
-                reads.size(), (unsigned long long)raw_bytes, (unsigned long long)new_bytes, t.h5_read, t.copies, t.gpu, t.h5_write,
+                "vbz_fast5_repack: %zu reads, %llu raw bytes -> %llu stored; hdf5 read %.1f ms, gzip on the host %.1f ms, "
+                "host<->device %.1f ms, codec %.1f ms, hdf5 write %.1f ms, total %.1f ms\n",
+                reads.size(), (unsigned long long)raw_bytes, (unsigned long long)new_bytes, t.h5_read, t.zlib, t.copies, t.gpu, t.h5_write,
                 now_ms() - t_all);
     }
     return ok;
@@ -499,8 +581,9 @@ bool list_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const char* 
         r.name = name;
         if (load_read(h, file, r, t)) reads.push_back(std::move(r));
     }
+    const bool inflated = inflate_chunks(h, file, reads, t);
     h.H5Fclose(file);
-    if (!decode_chunks(g, reads, t)) return false;
+    if (!inflated || !decode_chunks(g, reads, t)) return false;
     FILE* fs = export_signal ? fopen(export_signal, "wb") : nullptr;
     FILE* fc = export_chunks ? fopen(export_chunks, "wb") : nullptr;
     if ((export_signal && !fs) || (export_chunks && !fc)) return false;
