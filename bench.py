@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+DEFAULT_READS = 32768  # reads per batch: 6.6 GB of raw signal; larger batches have shorter tails (8192: -9 %, 16384: -4 %)
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
 
 
@@ -72,7 +73,7 @@ def cpu_baseline(min_seconds=8.0, n_reads=2048):
 def committed_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest rocprofv3 PMC summary committed under profiles/
     (tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).
-    bench.py cannot run the profiler on itself; the summary is for the same 8192-read workload."""
+    bench.py cannot run the profiler on itself; the summary is for the same default workload (DEFAULT_READS per batch)."""
     import csv
     import glob
 
@@ -89,7 +90,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=8192, help="reads per batch (one batch per step)")
+    ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per batch (one batch per step)")
     ap.add_argument("--resident", type=int, default=2, help="distinct batches kept in HBM and cycled")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
@@ -240,8 +241,8 @@ def main():
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5),
-                "traffic": traffic if n == 8192 else None,
-                "traffic_source": traffic_src if n == 8192 else None,
+                "traffic": traffic if n == DEFAULT_READS else None,
+                "traffic_source": traffic_src if n == DEFAULT_READS else None,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_launch_ms": round(avg_ms, 4),
             },
