@@ -21,7 +21,10 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-DEFAULT_READS = 32768  # reads per batch: 6.6 GB of raw signal; larger batches have shorter tails (8192: -9 %, 16384: -4 %)
+# reads per batch.  A launch ends with a tail of partly idle CUs (about one frame's latency per kernel), so batches are
+# large: 65536 reads = 13 GB of raw signal, ~140 GB of HBM for two resident batches with their worst-case output
+# slots and the library's scratch.  Measured on one box: 8192 reads 365 GB/s, 16384: 385, 32768: 395, 65536: 411.
+DEFAULT_READS = 65536
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
 
 
@@ -73,7 +76,8 @@ def cpu_baseline(min_seconds=8.0, n_reads=2048):
 def committed_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest rocprofv3 PMC summary committed under profiles/
     (tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).
-    bench.py cannot run the profiler on itself; the summary is for the same default workload (DEFAULT_READS per batch)."""
+    bench.py cannot run the profiler on itself.  Returns (bytes, file, reads per launch of the profiled run): traffic is
+    proportional to the number of reads, so it is scaled to this run's batch when the two differ."""
     import csv
     import glob
 
@@ -81,8 +85,15 @@ def committed_traffic(kernel):
     for path in reversed(files):
         for r in csv.DictReader(open(path)):
             if r["kernel"].startswith(kernel):
-                return int(float(r["hbm_MB_per_launch"]) * 1e6), os.path.basename(path)
-    return None, None
+                # reads per launch of the profiled run: from the bench line committed with the same tag
+                reads = 8192
+                try:
+                    with open(path.replace("_hbm_traffic.csv", "_bench.json")) as f:
+                        reads = int(json.load(f)["config"]["reads_per_step"])
+                except (OSError, KeyError, ValueError):
+                    pass
+                return int(float(r["hbm_MB_per_launch"]) * 1e6), os.path.basename(path), reads
+    return None, None, None
 
 
 def main():
@@ -113,6 +124,10 @@ def main():
     opts = codec.options(True, 2, 1, 1)
     L = codec.L
     n = args.reads
+    if n == DEFAULT_READS:  # the default needs ~140 GB: step down on a GPU that does not have it free
+        free = torch.cuda.mem_get_info(dev)[0]
+        while n > 8192 and free < n * 2.4e6:
+            n //= 2
 
     # ---- resident batches: rank r owns batches r, r+W, ... of the global read table (weak scaling)
     batches = []
@@ -205,7 +220,10 @@ def main():
             "zstd_encode": 1.261 + 2.0 / ratio,                   # read svb stream, write frame
             "zstd_decode": 2.0 / ratio + 1.261,
         }.get(name, 2.0)
-        traffic, traffic_src = committed_traffic(name + "_kernel")
+        traffic, traffic_src, traffic_reads = committed_traffic(name + "_kernel")
+        if traffic is not None and traffic_reads != n:
+            traffic = int(traffic * (n / traffic_reads))
+            traffic_src = "%s, scaled from %d to %d reads per launch" % (traffic_src, traffic_reads, n)
         avg_ms = tot_ms / max(launches, 1)
         alg_bytes = per_sample * (samples / args.steps)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -241,8 +259,8 @@ def main():
                 "peak": PEAK_HBM_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 5),
-                "traffic": traffic if n == DEFAULT_READS else None,
-                "traffic_source": traffic_src if n == DEFAULT_READS else None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 "avg_launch_ms": round(avg_ms, 4),
             },
