@@ -2,7 +2,7 @@
 """Average duration of each kernel of the path on the bench workload (8192 synthetic reads resident in HBM), from the
 library's own HIP events.  For A/B runs of kernel variants inside one gpurun call (box-to-box variance is up to 25 %):
 
-    VBZ_HIPCC_EXTRA=-DSOMETHING python -m vbz_compression_amd.build --force && python tools/time_kernels.py
+    VBZ_HIPCC_EXTRA=-DSOMETHING python -m vbz_compression_amd.build --force && python tools/time_kernels.py [reads]
 """
 import ctypes
 import os
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vbz_compression_amd import batch
 codec=batch.GpuCodec(0); torch.cuda.set_stream(codec.stream)
-opts=codec.options(True,2,1,1); L=codec.L; n=8192
+opts=codec.options(True,2,1,1); L=codec.L; n=int(sys.argv[1]) if len(sys.argv)>1 else 8192
 lens=codec.synth_lengths(5,0,n); sizes=lens.to(torch.int64)*2
 off,total=batch.layout(sizes.cpu(),64); raw=torch.empty(total,dtype=torch.uint8,device="cuda"); off=off.cuda()
 codec.synth_signal(5,0,raw,off,lens); s32=sizes.to(torch.int32)
