@@ -905,3 +905,30 @@ def test_hdf5_write_read_through_registered_filter(tmp_path):
     if r.returncode == 3:
         pytest.skip("no libhdf5 on this box")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver and the judge read (metric, value, unit, n_gpus, steps,
+    warmup, ms_per_step, higher_is_better, scaling, vs_baseline, dtype, data, config.workload, roofline{bound, achieved,
+    peak, unit, frac, traffic}); a small batch keeps this a test, not a measurement."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--reads", "512", "--steps", "3", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "ratio"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "MB/s" and d["dtype"] == "int16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and d["config"]["reads_per_step"] == 512 and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    assert d["value"] > 0 and 2.3 < d["ratio"] < 2.5
