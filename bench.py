@@ -6,37 +6,79 @@
 A "step" is one pass of the hot path -- vbz_compress then vbz_decompress semantics for every read of
 one batch (delta zig-zag + streamvbyte + zstd-format entropy stage, and back) -- over one batch of
 synthetic int16 reads already resident in HBM.  Workload = BASELINE.json configs[1]: synthetic
-int16 reads of ~100k samples (SURVEY.md 8d generator, seed 5), `--reads` reads per batch.
+int16 reads of ~100k samples (SURVEY.md 8d generator, seed 5), `--reads` reads per batch; as many DISTINCT
+batches as HBM holds are kept resident (about one million reads on a 288 GB MI355X), every one of them is
+round-trip verified before the timed region, and the timed steps cycle over them.
 Prints ONE JSON line (metric: MB/s of raw int16 bytes through encode+decode).
+
+Multi-GPU: `--gpus N` with N > 1 and no WORLD_SIZE in the environment makes this process a launcher: it starts N
+rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set) BEFORE anything touches the GPU, waits
+for them and relays rank 0's JSON line.  Under torchrun (WORLD_SIZE set) it is one of the ranks.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 # reads per batch.  A launch ends with a tail of partly idle CUs (about one frame's latency per kernel), so batches are
-# large: 65536 reads = 13 GB of raw signal, ~140 GB of HBM for two resident batches with their worst-case output
-# slots and the library's scratch.  Measured on one box: 8192 reads 365 GB/s, 16384: 385, 32768: 395, 65536: 411.
+# large: 65536 reads = 13 GB of raw signal.  Measured on one box: 8192 reads 365 GB/s, 16384: 385, 32768: 395, 65536: 411.
 DEFAULT_READS = 65536
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy reaches
+METRIC = "MB/s encode+decode, int16 signal, 1/2/4/8 MI355X vs CPU; ratio preserved"
+SVB_BYTES_PER_SAMPLE = 1.261  # svb stream bytes per int16 sample of this workload (DESIGN.md section 4)
 
 
-def cpu_baseline(min_seconds=8.0, n_reads=2048):
-    """The oracle (port of the reference CPU path + the pinned libzstd, dlopen'd) timed on this box's
-    host cores on a bounded sample of the same workload: reads [0, n_reads) of the same generator,
-    encode+decode, one pthread per hardware thread (reads are independent; the reference has no
-    internal threading).  The oracle is checker code: here it is only the reported baseline."""
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher (no GPU call may happen before or inside it)
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args, argv):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    line = ""
+    for ln in out0.splitlines():
+        if ln.startswith("{"):
+            line = ln
+    if line:
+        print(line, flush=True)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad or not line:
+        sys.stderr.write("bench.py launcher: rank exit codes %s%s\n" % (rcs, "" if line else "; rank 0 printed no JSON line"))
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline leg
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(min_seconds=8.0, n_reads=16384):
+    """The oracle (port of the reference CPU path: scalar svb + the pinned libzstd, dlopen'd) timed on this box's
+    host cores on a bounded sample of the same workload: reads [0, n_reads) of the same generator, encode+decode,
+    persistent pthreads claiming reads from a queue (reads are independent; the reference has no internal
+    threading), verification in an untimed pass.  The oracle is checker code: here it is only the reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
     cores = os.cpu_count() or 1
+    if cores < 32:  # a small host: keep the leg at ~10-30 s of CPU work
+        n_reads = min(n_reads, 256 * cores)
     opts = O.options(True, 2, 1, 1)
     one = O.bench_roundtrip(min(n_reads, 64), 1, 1.0, opts)
     allc = O.bench_roundtrip(n_reads, cores, min_seconds, opts)
@@ -45,8 +87,9 @@ def cpu_baseline(min_seconds=8.0, n_reads=2048):
         "unit": "MB/s",
         "cores": cores,
         "kind": "port",
-        "sample": "reads 0..%d of the same generator (%.1f MB raw), encode+decode, %d threads (all hardware threads of the host), "
-                  "libzstd %s level 1, best of %d passes; one thread: %.1f MB/s"
+        "sample": "reads 0..%d of the same generator (%.1f MB raw), encode+decode, %d persistent threads (all hardware threads of the "
+                  "host) claiming reads from a queue, scalar svb (not the SSSE3 worker) + libzstd %s level 1, verification in an "
+                  "untimed pass, best of %d timed passes; one thread: %.1f MB/s"
         % (n_reads - 1, allc["raw_bytes"] / 1e6, cores, (O.lib().vbo_zstd_version() or b"?").decode(), allc["passes"],
            one["raw_bytes"] / one["best_s"] / 1e6),
         "ratio": round(allc["raw_bytes"] / allc["comp_bytes"], 4),
@@ -73,104 +116,181 @@ def cpu_baseline(min_seconds=8.0, n_reads=2048):
     return out
 
 
-def committed_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the newest rocprofv3 PMC summary committed under profiles/
+def committed_traffic(kernels):
+    """HBM bytes per launch of each of `kernels` from the newest rocprofv3 PMC summary committed under profiles/
     (tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).
-    bench.py cannot run the profiler on itself.  Returns (bytes, file, reads per launch of the profiled run): traffic is
-    proportional to the number of reads, so it is scaled to this run's batch when the two differ."""
+    bench.py cannot run the profiler on itself.  Returns ({kernel: bytes}, file, reads per launch of the profiled run):
+    traffic is proportional to the number of reads, so the caller scales it to this run's batch when the two differ."""
     import csv
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
     for path in reversed(files):
+        found = {}
         for r in csv.DictReader(open(path)):
-            if r["kernel"].startswith(kernel):
-                # reads per launch of the profiled run: from the bench line committed with the same tag
-                reads = 8192
-                try:
-                    with open(path.replace("_hbm_traffic.csv", "_bench.json")) as f:
-                        reads = int(json.load(f)["config"]["reads_per_step"])
-                except (OSError, KeyError, ValueError):
-                    pass
-                return int(float(r["hbm_MB_per_launch"]) * 1e6), os.path.basename(path), reads
-    return None, None, None
+            for k in kernels:
+                if r["kernel"].startswith(k + "_kernel"):
+                    found[k] = int(float(r["hbm_MB_per_launch"]) * 1e6)
+        if found:
+            reads = 8192
+            try:
+                with open(path.replace("_hbm_traffic.csv", "_bench.json")) as f:
+                    reads = int(json.load(f)["config"]["reads_per_step"])
+            except (OSError, KeyError, ValueError):
+                pass
+            return found, os.path.basename(path), reads
+    return {}, None, None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per batch (one batch per step)")
-    ap.add_argument("--resident", type=int, default=2, help="distinct batches kept in HBM and cycled")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    args = ap.parse_args()
+def max_compressed_sizes(sizes, level):
+    """vbz_max_compressed_size (include/vbz.h; reference vbz/vbz.cpp:79-114) for int16 reads, vectorised over a tensor
+    of byte sizes: svb bound (n+3)/4 + 4n, ZSTD_COMPRESSBOUND when a level is set, +4."""
+    n = sizes // 2
+    svb = (n + 3) // 4 + 4 * n
+    if level:
+        svb = svb + (svb >> 8) + ((svb < (128 << 10)) * (((128 << 10) - svb) >> 11))
+    return svb + 4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one rank
+# ---------------------------------------------------------------------------------------------------------------------
+def run_rank(args):
+    import torch
+    import torch.distributed as dist
+
+    from vbz_compression_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the codec has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with `python bench.py --gpus N` or torchrun --nproc-per-node N)"
+                         % (args.gpus, world))
+    if args.dry_run:  # launcher / work-queue plumbing only (CPU test of the N > 1 path): no codec, no GPU
+        dev = None
+        backend = "gloo"
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the codec has no CPU path")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        backend = args.backend
     if world > 1:
-        import torch.distributed as dist
-
-        dist.init_process_group(backend="nccl", device_id=dev)
-    from vbz_compression_amd import batch, shard
-
-    codec = batch.GpuCodec(local_rank)
-    torch.cuda.set_stream(codec.stream)  # everything below (generation, events, kernels) runs on the codec's stream
-    opts = codec.options(True, 2, 1, 1)
-    L = codec.L
-    n = args.reads
-    if n == DEFAULT_READS:  # the default needs ~140 GB: step down on a GPU that does not have it free
-        free = torch.cuda.mem_get_info(dev)[0]
-        while n > 8192 and free < n * 2.4e6:
-            n //= 2
-
-    # ---- resident batches: rank r owns batches r, r+W, ... of the global read table (weak scaling)
-    batches = []
-    for b in range(args.resident):
-        gb = rank + b * world  # global batch index
-        first = gb * n
-        lens = codec.synth_lengths(5, first, n)
-        sizes = lens.to(torch.int64) * 2
-        off, total = batch.layout(sizes.cpu(), 64)
-        raw = torch.empty(total, dtype=torch.uint8, device=dev)
-        off = off.to(dev)
-        codec.synth_signal(5, first, raw, off, lens)
-        size32 = sizes.to(torch.int32)
-        caps = torch.tensor([L.vbz_max_compressed_size(int(s), ctypes.byref(opts)) for s in sizes.cpu().tolist()], dtype=torch.int64)
-        coff, ctotal = batch.layout(caps, 64)
-        comp = torch.empty(ctotal, dtype=torch.uint8, device=dev)
-        batches.append(
-            dict(raw=raw, off=off, size=size32, comp=comp, coff=coff.to(dev), cap=caps.to(torch.int32).to(dev),
-                 csize=torch.zeros(n, dtype=torch.int32, device=dev), back=torch.empty_like(raw),
-                 res=torch.zeros(n, dtype=torch.int32, device=dev), raw_bytes=int(sizes.sum()), samples=int(lens.sum()))
-        )
-    torch.cuda.synchronize()
-
-    def step(i, timed_parts=None):
-        B = batches[i % len(batches)]
-        codec.compress(B["raw"], B["off"], B["size"], B["comp"], B["coff"], B["cap"], B["csize"], opts)
-        if timed_parts is not None:
-            timed_parts[0].record()
-        codec.decompress(B["comp"], B["coff"], B["csize"], B["back"], B["off"], B["size"], B["res"], opts)
-        return B
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    # correctness of what is being timed: every read round-trips, on the device
-    B = batches[0]
-    if not os.environ.get("VBZ_BENCH_KERNEL_EXPERIMENT"):  # set only to time deliberately broken kernel variants
-        assert bool((B["res"] == B["size"]).all()), "decode failed for some read"
-        assert torch.equal(B["raw"], B["back"]), "round trip mismatch"
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+        assert dist.get_world_size() == args.gpus
+        # every rank sits on its own device
+        mine = torch.tensor([local_rank if dev is not None else rank], dtype=torch.int64, device=dev if backend == "nccl" else None)
+        seen = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(seen, mine)
+        assert len({int(t) for t in seen}) == world, "two ranks share a device"
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            dist.barrier()
+
+    coll_dev = dev if backend == "nccl" else None
+    n = args.reads
+    opts_tuple = (True, 2, 1, 1)
+
+    if args.dry_run:
+        # the same work queue as the real run, on the generator's length formula restated in torch
+        R = args.resident or 2
+        total_reads = world * R * n
+        g = torch.Generator().manual_seed(5)
+        lengths = 90000 + torch.randint(0, 20001, (total_reads,), generator=g)
+        lengths = shard.share_read_table(lengths if rank == 0 else torch.zeros(total_reads, dtype=torch.int64))
+        a, b = shard.partition_reads(lengths, world)[rank]
+        batches = shard.cut_batches(a, b, lengths, R)
+        barrier()
+        t0 = time.perf_counter()
+        raw = sum(int(lengths[x:y].sum()) * 2 for x, y in batches) * args.steps // R
+        elapsed = shard.max_over_ranks(time.perf_counter() - t0 + 1e-6)
+        table, off = shard.exchange_tallies(sum(y - x for x, y in batches), raw, raw // 2)
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "int16", "data": "dry-run (no codec: launcher and work-queue plumbing only)",
+                              "config": {"workload": "dry-run", "reads_per_step": n},
+                              "tallies": table.tolist(), "ranges": [list(p) for p in shard.partition_reads(lengths, world)]}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return 0
+
+    from vbz_compression_amd import batch
+
+    codec = batch.GpuCodec(local_rank)
+    torch.cuda.set_stream(codec.stream)  # everything below (generation, events, kernels) runs on the codec's stream
+    opts = codec.options(*opts_tuple)
+    L = codec.L
+
+    # ---- how many distinct batches fit: raw signal per batch, plus ONE shared set of worst-case output slots, decoded
+    # copy and library scratch (encode 9/8, decode 17/8 of the raw bytes, grown by 1/8 when (re)allocated)
+    free = torch.cuda.mem_get_info(dev)[0]
+    per_read = 200e3
+    fixed = lambda k: k * per_read * (2.14 + 1.0 + 2.125 * 1.125) + 20e9  # noqa: E731
+    if n == DEFAULT_READS:  # the default needs ~85 GB for one batch: step down on a GPU that does not have it free
+        while n > 8192 and free < fixed(n) + n * per_read:
+            n //= 2
+    R = args.resident or max(1, min(args.steps, 16, int((free - fixed(n)) // (n * per_read * 1.02))))
+
+    # ---- the work queue: rank 0 owns the read table (lengths of world x R x n reads), every rank takes the contiguous,
+    # sample-balanced range the partition gives it and cuts it into R batches (weak scaling: per-GPU work is fixed)
+    total_reads = world * R * n
+    if rank == 0:
+        lengths = torch.cat([codec.synth_lengths(5, f, min(1 << 20, total_reads - f)).to(torch.int64) for f in range(0, total_reads, 1 << 20)])
+    else:
+        lengths = torch.zeros(total_reads, dtype=torch.int64, device=dev)
+    lengths = shard.share_read_table(lengths, coll_dev)
+    my_first, my_last = shard.partition_reads(lengths, world)[rank]
+    ranges = shard.cut_batches(my_first, my_last, lengths, R)
+
+    max_total = max_ctotal = 0
+    batches = []
+    for (a, b) in ranges:
+        lens = codec.synth_lengths(5, a, b - a)
+        assert torch.equal(lens.cpu().to(torch.int64), lengths[a:b]), "read table mismatch between ranks"
+        sizes = lens.to(torch.int64) * 2
+        off, total = batch.layout(sizes.cpu(), 64)
+        caps = max_compressed_sizes(sizes.cpu(), 1)
+        coff, ctotal = batch.layout(caps, 64)
+        raw = torch.empty(total, dtype=torch.uint8, device=dev)
+        off = off.to(dev)
+        codec.synth_signal(5, a, raw, off, lens)
+        max_total, max_ctotal = max(max_total, total), max(max_ctotal, ctotal)
+        batches.append(dict(first=a, n=b - a, raw=raw, off=off, size=sizes.to(torch.int32), coff=coff.to(dev), cap=caps.to(torch.int32).to(dev),
+                            csize=torch.zeros(b - a, dtype=torch.int32, device=dev), raw_bytes=int(sizes.sum()), samples=int(lens.sum()),
+                            total=total))
+    for i in (0, len(batches[0]["cap"]) - 1):  # the vectorised bound is the library's
+        assert int(batches[0]["cap"][i]) == L.vbz_max_compressed_size(int(batches[0]["size"][i]), ctypes.byref(opts))
+    comp = torch.empty(max_ctotal, dtype=torch.uint8, device=dev)   # shared by all batches (outputs)
+    back = torch.empty(max_total, dtype=torch.uint8, device=dev)
+    res = torch.zeros(max(b["n"] for b in batches), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step(B, o=opts, mid=None):
+        codec.compress(B["raw"], B["off"], B["size"], comp, B["coff"], B["cap"], B["csize"], o)
+        if mid is not None:
+            mid.record()
+        codec.decompress(comp, B["coff"], B["csize"], back, B["off"], B["size"], res[: B["n"]], o)
+
+    # ---- every resident batch round-trips, on the device (untimed; also the first warm-up)
+    comp_bytes_all = 0
+    for B in batches:
+        step(B)
+        if not os.environ.get("VBZ_BENCH_KERNEL_EXPERIMENT"):  # set only to time deliberately broken kernel variants
+            assert bool((res[: B["n"]] == B["size"]).all()), "decode failed for some read"
+            assert torch.equal(B["raw"], back[: B["total"]]), "round trip mismatch"
+        B["comp_bytes"] = int(B["csize"].to(torch.int64).sum())
+        comp_bytes_all += B["comp_bytes"]
+    for i in range(args.warmup):
+        step(batches[i % R])
+    torch.cuda.synchronize()
 
     codec.profile_reset()
     codec.profile(True)
@@ -180,24 +300,24 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    raw_bytes = 0
-    samples = 0
+    raw_bytes = samples = comp_bytes = reads_done = 0
+    ev0.record()
     for i in range(args.steps):
-        if i == 0:
-            ev0.record()
-        Bi = step(i, (evm[i],))
+        B = batches[i % R]
+        step(B, mid=evm[i])
         eve[i].record()
-        raw_bytes += Bi["raw_bytes"]
-        samples += Bi["samples"]
+        raw_bytes += B["raw_bytes"]
+        samples += B["samples"]
+        comp_bytes += B["comp_bytes"]
+        reads_done += B["n"]
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     codec.profile(False)
-    elapsed = shard.max_over_ranks(elapsed, dev)
+    elapsed = shard.max_over_ranks(elapsed, coll_dev)
     prof = codec.profile_read()
-    comp_bytes = int(batches[0]["csize"].to(torch.int64).sum())
-    ratio = batches[0]["raw_bytes"] / comp_bytes
-    table, _ = shard.exchange_tallies(args.steps * n, raw_bytes, comp_bytes * args.steps, dev)
+    ratio = raw_bytes / comp_bytes
+    table, _ = shard.exchange_tallies(reads_done, raw_bytes, comp_bytes, coll_dev)
     total_raw = int(table[:, 1].sum())
 
     # encode / decode split from the events on torch's stream (the codec launches on it)
@@ -209,26 +329,86 @@ def main():
         prev = eve[i]
 
     if rank == 0:
-        # ---- roofline of the dominant kernel (largest total time over the timed region)
-        dom = max(prof.items(), key=lambda kv: kv[1][1])
-        name, (launches, tot_ms) = dom
-        svb_bytes = None
-        per_sample = {
-            # algorithmic bytes per int16 sample handled by ONE launch of that kernel (DESIGN.md "Kernels")
-            "svb_encode": 2.0 + 1.261,                             # read raw, write svb stream
-            "svb_decode": 1.261 + 2.0,
-            "zstd_encode": 1.261 + 2.0 / ratio,                   # read svb stream, write frame
-            "zstd_decode": 2.0 / ratio + 1.261,
-        }.get(name, 2.0)
-        traffic, traffic_src, traffic_reads = committed_traffic(name + "_kernel")
-        if traffic is not None and traffic_reads != n:
-            traffic = int(traffic * (n / traffic_reads))
-            traffic_src = "%s, scaled from %d to %d reads per launch" % (traffic_src, traffic_reads, n)
-        avg_ms = tot_ms / max(launches, 1)
-        alg_bytes = per_sample * (samples / args.steps)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # ---- stage level: svb only (zstd level 0), same batch, a few steps
+        stage = None
+        if not args.no_stages:
+            o0 = codec.options(True, 2, 0, 1)
+            B = batches[0]
+            step(B, o0)
+            assert torch.equal(B["raw"], back[: B["total"]]), "svb-only round trip mismatch"
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            k = 5
+            e[0].record()
+            for _ in range(k):
+                codec.compress(B["raw"], B["off"], B["size"], comp, B["coff"], B["cap"], B["csize"], o0)
+            e[1].record()
+            for _ in range(k):
+                codec.decompress(comp, B["coff"], B["csize"], back, B["off"], B["size"], res[: B["n"]], o0)
+            e[2].record()
+            torch.cuda.synchronize()
+            t_e, t_d = e[0].elapsed_time(e[1]) / k, e[1].elapsed_time(e[2]) / k
+            s_bytes = int(B["csize"].to(torch.int64).sum())
+            alg = B["raw_bytes"] + s_bytes  # per direction: 2 + s bytes per sample (SURVEY 8d "stage-level reporting")
+            stage = {"svb_only": {
+                "encode_MBps": round(B["raw_bytes"] / t_e / 1e3, 1), "decode_MBps": round(B["raw_bytes"] / t_d / 1e3, 1),
+                "svb_bytes_per_sample": round(s_bytes / B["samples"], 4),
+                "encode_hbm_frac": round(alg / (t_e * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "decode_hbm_frac": round(alg / (t_d * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "note": "zstd level 0 through the same batched entry points (byte-identical to the reference's level-0 output); "
+                        "algorithmic bytes per direction = raw + svb stream"}}
+
+        # ---- roofline: algorithmic bytes = (2 + c) per sample per direction, c = 2 / ratio.  `achieved` is
+        # quoted for the direction that holds the dominant kernel (largest total time): that direction's algorithmic bytes
+        # over the summed average launch durations of its kernels (HIP events the library records around every launch
+        # on its stream).  Dividing by the dominant kernel alone would credit it with the other kernels' work.
+        per_launch = {k: v[1] / max(v[0], 1) for k, v in prof.items()}
+        enc_k = [k for k in per_launch if k in ("plan_scratch", "svb_encode", "zstd_encode", "vbz_encode")]
+        dec_k = [k for k in per_launch if k in ("svb_decode", "zstd_decode", "vbz_decode", "parse_sized")]
+        # plan_scratch runs in both directions: charge its per-launch time to each
+        spl = samples / args.steps  # samples per launch
+        c = 2.0 / ratio
+        alg_dir = (2.0 + c) * spl
+        t_enc = sum(per_launch[k] for k in enc_k) * 1e-3
+        t_dec = (sum(per_launch[k] for k in dec_k) + per_launch.get("plan_scratch", 0.0)) * 1e-3
+        dom = max((k for k in per_launch if k != "plan_scratch"), key=lambda k: prof[k][1])
+        dom_dir = "encode" if dom in enc_k else "decode"
+        t_dom_dir = t_enc if dom_dir == "encode" else t_dec
+        achieved = alg_dir / t_dom_dir / 1e9
+        traffic_map, traffic_src, traffic_reads = committed_traffic([k for k in per_launch if k != "plan_scratch"])
+        scale = (batches[0]["n"] / traffic_reads) if traffic_reads else 1.0
+        dir_traffic = None
+        names = [k for k in (enc_k if dom_dir == "encode" else dec_k) if k != "plan_scratch"]
+        if names and all(k in traffic_map for k in names):
+            dir_traffic = int(sum(traffic_map[k] for k in names) * scale)
+            if traffic_reads != batches[0]["n"]:
+                traffic_src = "%s, scaled from %d to %d reads per launch" % (traffic_src, traffic_reads, batches[0]["n"])
+        roof = {
+            "bound": "hbm",
+            "kernel": dom,
+            "direction": dom_dir,
+            "achieved": round(achieved, 2),
+            "peak": PEAK_HBM_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / PEAK_HBM_GBS, 5),
+            "traffic": dir_traffic,
+            "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": int(alg_dir),
+            "algorithmic_bytes_per_sample": round(2.0 + c, 4),
+            "avg_launch_ms": round(t_dom_dir * 1e3, 4),
+            "definition": "SURVEY 8d: (2 + c) bytes per int16 sample per direction; achieved = that x samples per launch / sum of the "
+                          "average launch durations of the direction's kernels (%s)" % "+".join(names),
+            "per_direction": {
+                "encode": {"achieved": round(alg_dir / t_enc / 1e9, 2), "frac": round(alg_dir / t_enc / 1e9 / PEAK_HBM_GBS, 5), "ms": round(t_enc * 1e3, 4)},
+                "decode": {"achieved": round(alg_dir / t_dec / 1e9, 2), "frac": round(alg_dir / t_dec / 1e9 / PEAK_HBM_GBS, 5), "ms": round(t_dec * 1e3, 4)},
+            },
+            "end_to_end": {"achieved": round(2 * alg_dir / (elapsed / args.steps) / 1e9, 2),
+                           "frac": round(2 * alg_dir / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS, 5),
+                           "note": "encode + decode algorithmic bytes over the wall time of a step"},
+            "dominant_kernel_alone": {"achieved": round(alg_dir / (per_launch[dom] * 1e-3) / 1e9, 2),
+                                      "note": "the literal per-kernel formula; flatters the kernel when its direction has other launches"},
+        }
         out = {
-            "metric": "MB/s encode+decode, int16 signal, 1/2/4/8 MI355X vs CPU; ratio preserved",
+            "metric": METRIC,
             "value": round(total_raw / elapsed / 1e6, 1),
             "unit": "MB/s",
             "n_gpus": world,
@@ -242,37 +422,70 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: synthetic int16 reads of ~100k samples (SURVEY 8d generator, seed 5), "
-                            "%d reads (%.2f GB raw) per step per GPU, zig-zag + svb + zstd-format stage, encode then decode, inputs resident in HBM"
-                            % (n, batches[0]["raw_bytes"] / 1e9),
-                "reads_per_step": n,
+                            "%d reads (%.2f GB raw) per step per GPU, %d distinct batches resident per GPU (%d distinct reads over %d GPU(s), each "
+                            "round-trip verified before the timed region), zig-zag + svb + zstd-format stage, encode then decode, inputs resident in HBM"
+                            % (batches[0]["n"], batches[0]["raw_bytes"] / 1e9, R, total_reads, world),
+                "reads_per_step": batches[0]["n"],
+                "distinct_reads": total_reads,
                 "options": "zigzag=1,integer_size=2,zstd_level=1,vbz_version=1",
-                "parallelism": "reads sharded across %d GPU(s), no data-path collective" % world,
+                "parallelism": "read table partitioned by cumulative samples across %d GPU(s) (rank 0 broadcasts the table, "
+                               "all-gather of tallies); no data-path collective" % world,
             },
             "ratio": round(ratio, 4),
             "encode_MBps": round(raw_bytes / (enc_ms * 1e-3) / 1e6, 1),
             "decode_MBps": round(raw_bytes / (dec_ms * 1e-3) / 1e6, 1),
-            "kernels_ms_per_launch": {k: round(v[1] / max(v[0], 1), 4) for k, v in prof.items()},
-            "roofline": {
-                "bound": "hbm",
-                "kernel": name,
-                "achieved": round(achieved, 2),
-                "peak": PEAK_HBM_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / PEAK_HBM_GBS, 5),
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": int(alg_bytes),
-                "avg_launch_ms": round(avg_ms, 4),
-            },
+            "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
+            "roofline": roof,
         }
+        if stage:
+            out["stages"] = stage
+        if world == 1 and not args.no_pcie:
+            # host-resident data (never `value`): pinned host -> H2D -> codec -> D2H, three-stage pipeline
+            del comp, back
+            for B in batches[1:]:
+                B.clear()
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import pcie_pipeline
+
+            h = pcie_pipeline.measure(codec, 2048, 8)
+            out["host_resident"] = {"encode_decode_MBps": h["encode_decode_MBps"], "encode_MBps": h["encode_MBps"], "decode_MBps": h["decode_MBps"],
+                                    "h2d_GBps": h["h2d_GBps"], "d2h_GBps": h["d2h_GBps"], "round_trip_ok": h["round_trip_ok"],
+                                    "note": "PCIe-inclusive rate with pinned host buffers both ends (tools/pcie_pipeline.py); never `value`"}
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
             if "single_socket" in out["cpu_baseline"]:
                 out["vs_single_socket_cpu"] = round(out["value"] / out["cpu_baseline"]["single_socket"]["value"], 2)
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.destroy_process_group()
+        barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per batch (one batch per step)")
+    ap.add_argument("--resident", type=int, default=0, help="distinct batches kept in HBM and cycled (0: as many as fit, at most 16)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the work queue (nccl = RCCL)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher and work-queue plumbing only: no codec, no GPU (CPU test of the N > 1 path)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
+    ap.add_argument("--no-stages", action="store_true", help="skip the svb-only stage line")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not args.dry_run:
+            import torch  # device_count() does not initialise the GPU on this image
+
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, have))
+        return launch_ranks(args, sys.argv[1:])
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -14,8 +14,10 @@
  * the result back.  For throughput use the batched, device-resident extension in vbz_gpu.h.
  *
  * Deliberate divergences from the reference (all documented in DESIGN.md):
- *   - one extra error code, VBZ_DEVICE_ERROR, returned (with a message on stderr) when no gfx950
- *     device / kernel image is usable.  There is NO CPU fallback.
+ *   - there is NO CPU fallback: when no gfx950 device / kernel image is usable (or a device operation fails) the
+ *     entry points print the cause on stderr and return the reference's own VBZ_OUT_OF_MEMORY_ERROR, so that a
+ *     binary compiled against the reference header and only re-linked (`ret >= VBZ_FIRST_ERROR`, -7) sees an error.
+ *     VBZ_DEVICE_ERROR (-8) exists for the per-read results of the batched API (vbz_gpu.h); vbz_is_error() knows it.
  *   - vbz_compress_sized returns the error code of vbz_compress unchanged instead of adding 4 to it
  *     (reference vbz/vbz.cpp:321-329 turns VBZ_INPUT_SIZE_ERROR into 2).
  *   - the zstd stage is this library's own encoder: frames are standard zstd (RFC 8878) and decode
@@ -49,9 +51,9 @@ typedef uint32_t vbz_size_t;
 #define VBZ_STREAMVBYTE_STREAM_ERROR ((vbz_size_t)-5)
 #define VBZ_VERSION_ERROR ((vbz_size_t)-6)
 #define VBZ_OUT_OF_MEMORY_ERROR ((vbz_size_t)-7)
-/* extension: the HIP device, its memory or the kernel image is unusable (never a silent CPU path) */
+#define VBZ_FIRST_ERROR VBZ_OUT_OF_MEMORY_ERROR
+/* extension, vbz_gpu.h results only (never returned by the functions below): the HIP device is unusable */
 #define VBZ_DEVICE_ERROR ((vbz_size_t)-8)
-#define VBZ_FIRST_ERROR VBZ_DEVICE_ERROR
 
 /* Deprecated aliases, reference vbz/vbz.h:24-27 */
 #define VBZ_STREAMVBYTE_INPUT_SIZE_ERROR VBZ_INPUT_SIZE_ERROR

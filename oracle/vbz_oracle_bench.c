@@ -1,11 +1,17 @@
 /*
  * vbz_oracle_bench.c -- CPU ORACLE (test infrastructure): threaded timing harness for the CPU
  * baseline leg of bench.py.  It drives the oracle's vbo_compress / vbo_decompress (the restated
- * reference path + the pinned libzstd) from N pthreads over independent reads, the way the
- * reference is parallelised in practice (one process/thread per file: reference README.md:36-40).
+ * reference path -- scalar svb, not the SSSE3 worker -- plus the pinned libzstd) from N persistent
+ * pthreads over independent reads, the way the reference is parallelised in practice (one
+ * process/thread per file: reference README.md:36-40).
+ *
+ * Workers live for the whole call and meet at a barrier around every pass; reads are claimed from an
+ * atomic counter (no static imbalance); the first pass is an untimed verification pass (decoded
+ * samples memcmp'ed against the input), the timed passes contain vbo_compress + vbo_decompress only.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -13,15 +19,23 @@
 #include "vbz_oracle.h"
 
 typedef struct {
-    int tid, threads;
     uint32_t n_reads;
+    int threads;
     int16_t** reads;
     uint32_t* nsamples;
+    uint32_t max_samples;
     const VboOptions* opts;
-    int passes;
-    uint64_t comp_bytes; /* of one pass */
-    double enc_s, dec_s;
-    int ok;
+    pthread_barrier_t bar;
+    atomic_uint next;          /* work queue: next unclaimed read */
+    atomic_int stop, failed;
+    int verify;                /* this pass compares the decoded samples (untimed pass) */
+} shared_t;
+
+typedef struct {
+    shared_t* sh;
+    int tid;
+    uint64_t comp_bytes;       /* of the last pass */
+    double enc_s, dec_s;       /* of the last pass */
 } worker_t;
 
 static double now_s(void)
@@ -34,84 +48,92 @@ static double now_s(void)
 static void* worker(void* arg)
 {
     worker_t* w = (worker_t*)arg;
-    uint32_t maxn = 0;
-    for (uint32_t i = (uint32_t)w->tid; i < w->n_reads; i += (uint32_t)w->threads)
-        if (w->nsamples[i] > maxn) maxn = w->nsamples[i];
-    vbo_size_t cap = vbo_max_compressed_size(maxn * 2, w->opts);
-    uint8_t* cbuf = (uint8_t*)malloc(cap + 64);
-    int16_t* dbuf = (int16_t*)malloc((size_t)maxn * 2 + 64);
-    w->ok = cbuf && dbuf;
-    w->enc_s = w->dec_s = 0;
-    for (int p = 0; p < w->passes && w->ok; ++p) {
+    shared_t* sh = w->sh;
+    vbo_size_t cap = vbo_max_compressed_size(sh->max_samples * 2, sh->opts);
+    uint8_t* cbuf = (uint8_t*)malloc((size_t)cap + 64);
+    int16_t* dbuf = (int16_t*)malloc((size_t)sh->max_samples * 2 + 64);
+    if (!cbuf || !dbuf) atomic_store(&sh->failed, 1);
+    for (uint32_t i = (uint32_t)w->tid; i < sh->n_reads; i += (uint32_t)sh->threads)  /* generation, untimed */
+        vbo_synth_signal(5, i, sh->reads[i], sh->nsamples[i]);
+    for (;;) {
+        pthread_barrier_wait(&sh->bar);  /* pass start (the main thread resets the queue before it) */
+        if (atomic_load(&sh->stop)) break;
         uint64_t comp = 0;
-        for (uint32_t i = (uint32_t)w->tid; i < w->n_reads; i += (uint32_t)w->threads) {
-            const uint32_t bytes = w->nsamples[i] * 2;
-            double t0 = now_s();
-            vbo_size_t c = vbo_compress(w->reads[i], bytes, cbuf, cap, w->opts);
-            double t1 = now_s();
-            if (vbo_is_error(c)) { w->ok = 0; break; }
-            vbo_size_t d = vbo_decompress(cbuf, c, dbuf, bytes, w->opts);
-            double t2 = now_s();
-            if (d != bytes || memcmp(dbuf, w->reads[i], bytes) != 0) { w->ok = 0; break; }
+        double enc = 0, dec = 0;
+        for (;;) {
+            const uint32_t i = atomic_fetch_add(&sh->next, 1u);
+            if (i >= sh->n_reads || atomic_load(&sh->failed)) break;
+            const uint32_t bytes = sh->nsamples[i] * 2;
+            const double t0 = now_s();
+            const vbo_size_t c = vbo_compress(sh->reads[i], bytes, cbuf, cap, sh->opts);
+            const double t1 = now_s();
+            if (vbo_is_error(c)) { atomic_store(&sh->failed, 1); break; }
+            const vbo_size_t d = vbo_decompress(cbuf, c, dbuf, bytes, sh->opts);
+            const double t2 = now_s();
+            if (d != bytes || (sh->verify && memcmp(dbuf, sh->reads[i], bytes) != 0)) { atomic_store(&sh->failed, 1); break; }
             comp += c;
-            w->enc_s += t1 - t0;
-            w->dec_s += t2 - t1;
+            enc += t1 - t0;
+            dec += t2 - t1;
         }
         w->comp_bytes = comp;
+        w->enc_s = enc;
+        w->dec_s = dec;
+        pthread_barrier_wait(&sh->bar);  /* pass end */
     }
     free(cbuf);
     free(dbuf);
     return NULL;
 }
 
-typedef struct {
-    uint32_t n_reads, first, threads_used;
-    uint64_t seed;
-    int16_t** reads;
-    uint32_t* nsamples;
-} gen_t;
-
-static void* gen_worker(void* arg)
-{
-    worker_t* w = (worker_t*)arg;
-    for (uint32_t i = (uint32_t)w->tid; i < w->n_reads; i += (uint32_t)w->threads)
-        vbo_synth_signal(5, i, w->reads[i], w->nsamples[i]);
-    return NULL;
-}
-
-/* Generates reads [0, n_reads) of the SURVEY 8(d) workload (seed 5), then runs encode+decode passes
- * on `threads` threads until at least `min_seconds` have elapsed.  out[0]=raw bytes per pass,
- * out[1]=compressed bytes per pass, out[2]=best pass wall seconds, out[3]=sum of per-thread encode
- * seconds per pass, out[4]=same for decode, out[5]=passes run.  Returns 0 on success. */
+/* Generates reads [0, n_reads) of the SURVEY 8(d) workload (seed 5), runs one untimed verification pass, then
+ * timed encode+decode passes on `threads` persistent threads until at least `min_seconds` have elapsed (at least
+ * one).  out[0]=raw bytes per pass, out[1]=compressed bytes per pass, out[2]=best pass wall seconds, out[3]=sum of
+ * per-thread encode seconds of that pass, out[4]=same for decode, out[5]=timed passes run.  Returns 0 on success. */
 int vbo_bench_roundtrip(uint32_t n_reads, int threads, double min_seconds, const VboOptions* opts, double* out)
 {
     if (threads < 1) threads = 1;
-    int16_t** reads = (int16_t**)calloc(n_reads, sizeof(*reads));
-    uint32_t* ns = (uint32_t*)calloc(n_reads, sizeof(*ns));
+    shared_t sh;
+    memset(&sh, 0, sizeof sh);
+    sh.n_reads = n_reads;
+    sh.threads = threads;
+    sh.opts = opts;
+    sh.reads = (int16_t**)calloc(n_reads ? n_reads : 1, sizeof(*sh.reads));
+    sh.nsamples = (uint32_t*)calloc(n_reads ? n_reads : 1, sizeof(*sh.nsamples));
     worker_t* ws = (worker_t*)calloc((size_t)threads, sizeof(*ws));
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(*th));
-    if (!reads || !ns || !ws || !th) return -1;
+    if (!sh.reads || !sh.nsamples || !ws || !th) return -1;
     uint64_t raw = 0;
     for (uint32_t i = 0; i < n_reads; ++i) {
-        ns[i] = vbo_synth_read_length(5, i);
-        reads[i] = (int16_t*)malloc((size_t)ns[i] * 2);
-        if (!reads[i]) return -1;
-        raw += (uint64_t)ns[i] * 2;
+        sh.nsamples[i] = vbo_synth_read_length(5, i);
+        if (sh.nsamples[i] > sh.max_samples) sh.max_samples = sh.nsamples[i];
+        sh.reads[i] = (int16_t*)malloc((size_t)sh.nsamples[i] * 2);
+        if (!sh.reads[i]) return -1;
+        raw += (uint64_t)sh.nsamples[i] * 2;
     }
+    pthread_barrier_init(&sh.bar, NULL, (unsigned)threads + 1u);
+    atomic_init(&sh.next, 0u);
+    atomic_init(&sh.stop, 0);
+    atomic_init(&sh.failed, 0);
     for (int t = 0; t < threads; ++t) {
-        ws[t].tid = t; ws[t].threads = threads; ws[t].n_reads = n_reads; ws[t].reads = reads; ws[t].nsamples = ns;
-        ws[t].opts = opts; ws[t].passes = 1;
-        pthread_create(&th[t], NULL, gen_worker, &ws[t]);
+        ws[t].sh = &sh;
+        ws[t].tid = t;
+        pthread_create(&th[t], NULL, worker, &ws[t]);
     }
-    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     double best = 1e30, enc = 0, dec = 0, total = 0;
     uint64_t comp = 0;
-    int passes = 0, ok = 1;
-    while ((total < min_seconds || passes < 2) && ok) {
-        double t0 = now_s();
-        for (int t = 0; t < threads; ++t) pthread_create(&th[t], NULL, worker, &ws[t]);
-        for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
-        double dt = now_s() - t0;
+    int passes = 0;
+    /* pass 0: verification, untimed */
+    sh.verify = 1;
+    atomic_store(&sh.next, 0u);
+    pthread_barrier_wait(&sh.bar);
+    pthread_barrier_wait(&sh.bar);
+    sh.verify = 0;
+    while ((total < min_seconds || passes < 1) && !atomic_load(&sh.failed)) {
+        atomic_store(&sh.next, 0u);
+        const double t0 = now_s();
+        pthread_barrier_wait(&sh.bar);
+        pthread_barrier_wait(&sh.bar);
+        const double dt = now_s() - t0;
         total += dt;
         ++passes;
         if (dt < best) {
@@ -120,10 +142,14 @@ int vbo_bench_roundtrip(uint32_t n_reads, int threads, double min_seconds, const
             comp = 0;
             for (int t = 0; t < threads; ++t) { enc += ws[t].enc_s; dec += ws[t].dec_s; comp += ws[t].comp_bytes; }
         }
-        for (int t = 0; t < threads; ++t) ok &= ws[t].ok;
     }
+    atomic_store(&sh.stop, 1);
+    pthread_barrier_wait(&sh.bar);
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    pthread_barrier_destroy(&sh.bar);
+    const int ok = !atomic_load(&sh.failed);
     out[0] = (double)raw; out[1] = (double)comp; out[2] = best; out[3] = enc; out[4] = dec; out[5] = passes;
-    for (uint32_t i = 0; i < n_reads; ++i) free(reads[i]);
-    free(reads); free(ns); free(ws); free(th);
+    for (uint32_t i = 0; i < n_reads; ++i) free(sh.reads[i]);
+    free(sh.reads); free(sh.nsamples); free(ws); free(th);
     return ok ? 0 : -2;
 }

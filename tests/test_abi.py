@@ -85,7 +85,8 @@ def test_no_silent_cpu_fallback():
     src = (ctypes.c_int16 * 16)(*range(16))
     dst = (ctypes.c_uint8 * 256)()
     r = L.vbz_compress(src, 32, dst, 256, ctypes.byref(C(True, 2, 1, 0)))
-    assert r == _lib.VBZ_DEVICE_ERROR
+    # the reference's own code (a binary compiled against the reference header tests ret >= -7), cause on stderr
+    assert r == _lib.VBZ_OUT_OF_MEMORY_ERROR and r >= _lib.VBZ_FIRST_ERROR
     assert not L.vbz_gpu_create(0, None)
 
 

@@ -932,3 +932,11 @@ def test_bench_line_contract():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
     assert rf["traffic"] is None or rf["traffic"] > 0
     assert d["value"] > 0 and 2.3 < d["ratio"] < 2.5
+    # (2 + c) bytes per sample per direction, an end-to-end entry, the svb-only stage line, the PCIe-inclusive rate
+    assert abs(rf["algorithmic_bytes_per_sample"] - (2 + 2 / d["ratio"])) < 1e-3
+    for k in ("encode", "decode"):
+        assert 0 < rf["per_direction"][k]["frac"] < 1
+    assert 0 < rf["end_to_end"]["frac"] < 1
+    assert d["stages"]["svb_only"]["encode_MBps"] > d["encode_MBps"] and 1.2 < d["stages"]["svb_only"]["svb_bytes_per_sample"] < 1.3
+    assert d["host_resident"]["round_trip_ok"] and 0 < d["host_resident"]["encode_decode_MBps"] < d["value"]
+    assert d["config"]["distinct_reads"] >= 512

@@ -20,7 +20,22 @@ def test_partition_reads_is_contiguous_and_balanced():
         loads = [int(lengths[a:b].sum()) for a, b in parts]
         assert max(loads) - min(loads) <= 2 * 110000
     assert shard.partition_reads([], 4) == [(0, 0)] * 4
-    assert shard.batch_plan(10, 1, 4) == [1, 5, 9]
+
+
+def test_skewed_read_table_balances_within_two_percent():
+    """Real files hold reads of 9 885 ... 505 057 samples: a table with that spread, sorted the
+    worst way (long reads first), still ends within 2 % load balance, and a rank's batches are balanced the same way."""
+    g = torch.Generator().manual_seed(7)
+    lengths = torch.cat([torch.randint(300000, 505058, (3000,), generator=g), torch.randint(9885, 40000, (29000,), generator=g)])
+    for world in (2, 4, 8):
+        parts = shard.partition_reads(lengths, world)
+        loads = [int(lengths[a:b].sum()) for a, b in parts]
+        assert (max(loads) - min(loads)) / (sum(loads) / world) < 0.02, loads
+        a, b = parts[-1]
+        cuts = shard.cut_batches(a, b, lengths, 4)
+        assert cuts[0][0] == a and cuts[-1][1] == b and all(x[1] == y[0] for x, y in zip(cuts, cuts[1:]))
+        bl = [int(lengths[x:y].sum()) for x, y in cuts]
+        assert (max(bl) - min(bl)) / (sum(bl) / 4) < 0.02
 
 
 def _worker(rank, world, port, out):
@@ -29,8 +44,11 @@ def _worker(rank, world, port, out):
     try:
         table, offset = shard.exchange_tallies(reads=10 + rank, raw_bytes=1000 * (rank + 1), compressed_bytes=400 + 50 * rank)
         mx = shard.max_over_ranks(1.5 + rank)
-        plan = shard.batch_plan(7, rank, world)
-        out.put((rank, table.tolist(), offset, mx, plan))
+        # rank 0 owns the read table; everybody derives the same partition from the broadcast copy
+        lengths = torch.arange(1000, 1100, dtype=torch.int64) if rank == 0 else torch.zeros(100, dtype=torch.int64)
+        lengths = shard.share_read_table(lengths)
+        plan = shard.partition_reads(lengths, world)
+        out.put((rank, table.tolist(), offset, mx, plan, int(lengths.sum())))
     finally:
         dist.destroy_process_group()
 
@@ -49,11 +67,40 @@ def test_work_queue_metadata_exchange_world_size_2():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (r0, t0, off0, mx0, plan0), (r1, t1, off1, mx1, plan1) = res
+    (r0, t0, off0, mx0, plan0, sum0), (r1, t1, off1, mx1, plan1, sum1) = res
     assert t0 == t1 == [[10, 1000, 400], [11, 2000, 450]]
     assert (off0, off1) == (0, 400)          # exclusive scan of compressed bytes = global output offsets
     assert mx0 == mx1 == 2.5                  # MAX over ranks (the timed region of bench.py)
-    assert plan0 == [0, 2, 4, 6] and plan1 == [1, 3, 5]
+    assert sum0 == sum1 == sum(range(1000, 1100))
+    assert plan0 == plan1 and plan0[0][0] == 0 and plan0[0][1] == plan0[1][0] and plan0[1][1] == 100
+
+
+def test_bench_launcher_starts_one_process_per_rank():
+    """`python bench.py --gpus 2` with no WORLD_SIZE is a launcher: it starts two rank processes which form a process
+    group (gloo here, RCCL on GPUs) and run the same work-queue code as the real benchmark; --dry-run leaves the codec
+    out (there is no GPU in this test).  n_gpus, the sample-balanced ranges and the all-gathered tallies are checked."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--reads", "300", "--steps", "4"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    (a0, b0), (a1, b1) = out["ranges"]
+    assert a0 == 0 and b0 == a1 and b1 == 2 * 2 * 300
+    t = out["tallies"]
+    assert t[0][0] == b0 - a0 and t[1][0] == b1 - a1
+    assert abs(t[0][1] - t[1][1]) / t[0][1] < 0.01      # balanced by samples
+    # a world size that does not match --gpus is refused, and a failing rank makes the launcher fail
+    env2 = dict(env, WORLD_SIZE="2", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True, timeout=120, env=env2)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
 def test_single_rank_identity():

@@ -20,16 +20,15 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--reads", type=int, default=2048)
-    ap.add_argument("--batches", type=int, default=12)
-    args = ap.parse_args()
+def measure(codec, reads=2048, batches=12):
+    """Runs both pipelines on `codec`'s device; returns the result dict (see the module docstring)."""
     from vbz_compression_amd import batch
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    codec = batch.GpuCodec(0)
+    class args:  # noqa: N801
+        pass
+
+    args.reads, args.batches = reads, batches
+    dev = codec.device
     L = codec.L
     opts = codec.options(True, 2, 1, 1)
     copy_opts = codec.options(False, 0, 0, 0)  # integer_size 0, level 0: the batch call is a per-read byte copy
@@ -141,7 +140,7 @@ def main():
     torch.cuda.synchronize()
     d2h = 4 * total / (time.perf_counter() - t0) / 1e9
     k = args.batches
-    print(json.dumps({
+    return {
         "workload": "%d reads per batch, %d batches, pinned host memory both ends" % (n, k),
         "round_trip_ok": ok,
         "encode_MBps": round(k * raw_bytes / t_enc / 1e6, 1),
@@ -149,8 +148,20 @@ def main():
         "encode_decode_MBps": round(k * raw_bytes / (t_enc + t_dec) / 1e6, 1),
         "ratio": round(raw_bytes / comp_bytes, 4),
         "h2d_GBps": round(h2d, 1), "d2h_GBps": round(d2h, 1),
-    }))
-    return 0 if ok else 1
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=2048)
+    ap.add_argument("--batches", type=int, default=12)
+    args = ap.parse_args()
+    from vbz_compression_amd import batch
+
+    torch.cuda.set_device(0)
+    out = measure(batch.GpuCodec(0), args.reads, args.batches)
+    print(json.dumps(out))
+    return 0 if out["round_trip_ok"] else 1
 
 
 if __name__ == "__main__":

@@ -17,8 +17,8 @@ VBZ_DESTINATION_SIZE_ERROR = 0xFFFFFFFC
 VBZ_STREAMVBYTE_STREAM_ERROR = 0xFFFFFFFB
 VBZ_VERSION_ERROR = 0xFFFFFFFA
 VBZ_OUT_OF_MEMORY_ERROR = 0xFFFFFFF9
-VBZ_DEVICE_ERROR = 0xFFFFFFF8
-VBZ_FIRST_ERROR = VBZ_DEVICE_ERROR
+VBZ_DEVICE_ERROR = 0xFFFFFFF8  # vbz_gpu.h results only
+VBZ_FIRST_ERROR = VBZ_OUT_OF_MEMORY_ERROR  # the reference's value (vbz/vbz.h:22)
 
 
 class CompressionOptions(ctypes.Structure):
@@ -151,7 +151,7 @@ def load():
 
 
 def is_error(v):
-    return int(v) >= VBZ_FIRST_ERROR
+    return int(v) >= VBZ_DEVICE_ERROR
 
 
 def error_string(v):

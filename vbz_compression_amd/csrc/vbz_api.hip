@@ -199,6 +199,23 @@ size_t zstd_bound(size_t n)  // published ZSTD_COMPRESSBOUND (zstd.h), what vbz/
     return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0);
 }
 
+// The entry points run on the context's device and leave the caller's current device as they found it (a process
+// that drives several GPUs from one thread must not have its later allocations land on another device).
+struct DeviceGuard
+{
+    int saved = -1;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+        if (saved != device) (void)hipSetDevice(device);
+        else saved = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
 #define HIPCHK(c, expr, what)                                                      \
     do {                                                                           \
         hipError_t e__ = (expr);                                                   \
@@ -400,9 +417,13 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
         set_error(nullptr, "device %d out of range (%d devices)", device, count);
         return nullptr;
     }
-    if (hipSetDevice(device) != hipSuccess) {
-        set_error(nullptr, "hipSetDevice(%d) failed", device);
-        return nullptr;
+    DeviceGuard dg(device);
+    {
+        int now = -1;
+        if (hipGetDevice(&now) != hipSuccess || now != device) {
+            set_error(nullptr, "hipSetDevice(%d) failed", device);
+            return nullptr;
+        }
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
@@ -438,7 +459,8 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     } else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
             set_error(nullptr, "hipStreamCreate failed");
-            delete c;
+            c->stream = nullptr;
+            vbz_gpu_destroy(c);  // frees the uploaded tables as well
             return nullptr;
         }
         c->own_stream = true;
@@ -449,8 +471,8 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
 void vbz_gpu_destroy(vbz_gpu_ctx* c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    DeviceGuard dg(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->pending) {
         (void)hipEventDestroy(p.start);
         (void)hipEventDestroy(p.stop);
@@ -459,7 +481,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
     for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab })
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -476,7 +498,7 @@ int vbz_gpu_synchronize(vbz_gpu_ctx* c)
 int vbz_gpu_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
 {
     if (!c || !bt || !o) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1)) {
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
@@ -487,7 +509,7 @@ int vbz_gpu_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compre
 int vbz_gpu_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
 {
     if (!c || !bt || !o) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     if (!valid_int_size(o) || (o->integer_size != 0 && o->vbz_version > 1)) {
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
@@ -513,7 +535,7 @@ static ReadBatch to_rb(const vbz_gpu_batch* bt)
 int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int integer_size, int zigzag, int version)
 {
     if (!c || !bt) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || version > 1 || version < 0) return -2;
     Timed t(c, "svb_encode");
     HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, version == 1 && integer_size == 1, c->stream), "svb_encode launch");
@@ -523,7 +545,7 @@ int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int inte
 int vbz_gpu_svb_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int integer_size, int zigzag, int version)
 {
     if (!c || !bt) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || version > 1 || version < 0) return -2;
     Timed t(c, "svb_decode");
     HIPCHK(c, launch_svb_decode(to_rb(bt), integer_size, zigzag != 0, version == 1 && integer_size == 1, c->stream), "svb_decode launch");
@@ -533,7 +555,7 @@ int vbz_gpu_svb_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int in
 int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const uint32_t* key_bytes)
 {
     if (!c || !bt) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     Timed t(c, "zstd_encode");
     HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->stream), "zstd_encode launch");
     return 0;
@@ -542,7 +564,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
 int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
 {
     if (!c || !bt) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     Timed t(c, "zstd_decode");
     HIPCHK(c, launch_zstd_decode(to_rb(bt), E_ZSTD, nullptr, c->seqdtab.p, c->stream), "zstd_decode launch");
     return 0;
@@ -551,7 +573,7 @@ int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
 int vbz_gpu_synth_lengths(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len)
 {
     if (!c) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     HIPCHK(c, launch_synth_lengths(seed, first, n, out_len, c->stream), "synth_lengths launch");
     return 0;
 }
@@ -560,7 +582,7 @@ int vbz_gpu_synth_signal(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t
                          const uint32_t* len)
 {
     if (!c) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     HIPCHK(c, launch_synth_signal(seed, first, n, (uint8_t*)dst, off, len, c->stream), "synth_signal launch");
     return 0;
 }
@@ -568,7 +590,7 @@ int vbz_gpu_synth_signal(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t
 int vbz_gpu_synth_u32(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, void* dst, const uint64_t* off, const uint32_t* len)
 {
     if (!c) return -1;
-    (void)hipSetDevice(c->device);
+    DeviceGuard dg(c->device);
     HIPCHK(c, launch_synth_u32(seed, first, n, (uint8_t*)dst, off, len, c->stream), "synth_u32 launch");
     return 0;
 }
@@ -618,6 +640,7 @@ std::mutex g_mutex;
 std::condition_variable g_idle_cv;
 std::vector<vbz_gpu_ctx*> g_idle;
 unsigned g_created = 0;
+unsigned g_limit = 0;        // 0: pool_limit(); lowered to the number of live contexts once a creation fails
 bool g_ctx_failed = false;
 
 unsigned pool_limit()
@@ -637,7 +660,7 @@ vbz_gpu_ctx* take_ctx()
             return c;
         }
         if (g_ctx_failed) return nullptr;
-        if (g_created < pool_limit()) {
+        if (g_created < (g_limit ? g_limit : pool_limit())) {
             ++g_created;
             lock.unlock();
             int dev = 0;
@@ -646,10 +669,14 @@ vbz_gpu_ctx* take_ctx()
             lock.lock();
             if (c) return c;
             --g_created;
-            if (g_created == 0) g_ctx_failed = true;  // no usable device: every call reports VBZ_DEVICE_ERROR
-            g_idle_cv.notify_all();
-            if (g_ctx_failed) return nullptr;
-            continue;
+            if (g_created == 0) {
+                g_ctx_failed = true;  // no usable device: every call reports a device failure
+                g_idle_cv.notify_all();
+                return nullptr;
+            }
+            // creation failed while other contexts live (e.g. hipMalloc under memory pressure): stop growing the pool
+            // and wait for one of them to come back instead of retrying at once
+            g_limit = g_created;
         }
         g_idle_cv.wait(lock);
     }
@@ -674,6 +701,16 @@ struct CtxLease
     }
 };
 
+// vbz.h callers may be binaries compiled against the REFERENCE header and only re-linked: they test
+// `ret >= VBZ_FIRST_ERROR` with the reference's value (-7).  A device failure is therefore reported with the
+// reference's own VBZ_OUT_OF_MEMORY_ERROR ("the device or its memory is not available") plus a line on stderr;
+// the detailed cause is in vbz_gpu_last_error / on stderr.  VBZ_DEVICE_ERROR (-8) only appears in vbz_gpu.h results.
+vbz_size_t device_failure()
+{
+    fprintf(stderr, "vbz_hip: no usable gfx950 device (or a device operation failed); this library has no CPU path\n");
+    return VBZ_OUT_OF_MEMORY_ERROR;
+}
+
 struct OneMeta  // device-side descriptors of a one-read batch
 {
     uint64_t src_off, dst_off;
@@ -686,8 +723,8 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
 {
     CtxLease lease;
     vbz_gpu_ctx* c = lease.c;
-    if (!c) return VBZ_DEVICE_ERROR;
-    (void)hipSetDevice(c->device);
+    if (!c) return device_failure();
+    DeviceGuard dg(c->device);
     if (!ensure(c, c->one_in, (size_t)src_size + 64) || !ensure(c, c->one_out, (size_t)dev_cap + 64) ||
         !ensure(c, c->one_meta, sizeof(OneMeta)))
         return VBZ_OUT_OF_MEMORY_ERROR;
@@ -708,7 +745,7 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     ok &= hipMemcpyAsync(c->one_meta.p, hm, sizeof(OneMeta), hipMemcpyHostToDevice, s) == hipSuccess;
     if (!ok) {
         set_error(c, "host to device copy failed");
-        return VBZ_DEVICE_ERROR;
+        return device_failure();
     }
     OneMeta* dm = (OneMeta*)c->one_meta.p;
     vbz_gpu_batch bt;
@@ -724,19 +761,20 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     bt.dst_bytes = dev_cap;
     bt.result = &dm->result;
     int rc = compress ? compress_batch_impl(c, &bt, o, sized) : decompress_batch_impl(c, &bt, o, sized);
-    if (rc != 0) return VBZ_DEVICE_ERROR;
+    if (rc != 0) return device_failure();
     uint32_t result = VBZ_DEVICE_ERROR;
     if (hipMemcpyAsync(&hm->result, &dm->result, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         set_error(c, "kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
-        return VBZ_DEVICE_ERROR;
+        return device_failure();
     }
     result = hm->result;
+    if (result == VBZ_DEVICE_ERROR) return device_failure();
     if (result >= VBZ_FIRST_ERROR) return result;
     if (result > dst_cap) return VBZ_DESTINATION_SIZE_ERROR;
     if (result && (hipMemcpyAsync(dst, c->one_out.p, result, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
         set_error(c, "device to host copy failed");
-        return VBZ_DEVICE_ERROR;
+        return device_failure();
     }
     return result;
 }
@@ -753,7 +791,7 @@ vbz_size_t max_svb_size(unsigned integer_size, vbz_size_t source_size)
 
 extern "C" {
 
-bool vbz_is_error(vbz_size_t v) { return v >= VBZ_FIRST_ERROR; }
+bool vbz_is_error(vbz_size_t v) { return v >= VBZ_DEVICE_ERROR; }  // the reference's seven codes and the vbz_gpu.h extension
 
 char const* vbz_error_string(vbz_size_t v)
 {

@@ -1,18 +1,25 @@
-"""Read sharding across the GPUs of one node.
+"""Read sharding across the GPUs of one node: the work queue of the VBZ path.
 
 Reads are independent (one frame per read, no cross-read state: SURVEY.md section 8e), so the data
 path has NO collective: every rank encodes/decodes its own contiguous range of the read table.
 torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" on CPU) carries only work-queue
-metadata: the per-rank tallies that give every rank its global output offset.
+metadata: the read-length table (broadcast from rank 0, which owns it), from which every rank derives the
+same sample-balanced partition, and the per-rank tallies that give every rank its global output offset.
+Real files hold reads of 9 885 ... 505 057 samples, so the partition balances
+cumulative samples, not read counts.
 """
 import torch
 import torch.distributed as dist
 
 
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def partition_reads(lengths, world_size):
     """Split the read table into `world_size` contiguous ranges balanced by cumulative sample count.
     Returns a list of (first, last_exclusive) per rank.  Deterministic, identical on every rank."""
-    lengths = torch.as_tensor(lengths, dtype=torch.int64)
+    lengths = torch.as_tensor(lengths, dtype=torch.int64).cpu()
     n = int(lengths.numel())
     if n == 0:
         return [(0, 0)] * world_size
@@ -28,9 +35,23 @@ def partition_reads(lengths, world_size):
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
 
 
-def batch_plan(n_batches, rank, world_size):
-    """Static round-robin work queue over batches of reads: rank r owns batches r, r+W, r+2W, ..."""
-    return list(range(rank, n_batches, world_size))
+def cut_batches(first, last, lengths, n_batches):
+    """Cut one rank's range [first, last) of the read table into `n_batches` contiguous batches of near-equal
+    sample count (the unit one vbz_gpu_*_batch call handles).  Returns [(first, last_exclusive), ...]."""
+    lengths = torch.as_tensor(lengths, dtype=torch.int64).cpu()
+    parts = partition_reads(lengths[first:last], n_batches)
+    return [(first + a, first + b) for a, b in parts]
+
+
+def share_read_table(lengths, device=None):
+    """Rank 0 owns the read-length table; every other rank receives it (one broadcast, <= 4 MB for 1 M reads).
+    `lengths` must have the same shape on every rank (contents matter on rank 0 only).  Returns an int64 CPU tensor."""
+    t = torch.as_tensor(lengths, dtype=torch.int64)
+    if not _active():
+        return t.cpu()
+    t = t.to(device) if device is not None else t.clone()
+    dist.broadcast(t, src=0)
+    return t.cpu()
 
 
 def exchange_tallies(reads, raw_bytes, compressed_bytes, device=None):
@@ -38,7 +59,7 @@ def exchange_tallies(reads, raw_bytes, compressed_bytes, device=None):
     (table[world, 3], my exclusive output offset in compressed bytes).  Without an initialised
     process group this is the single-rank identity."""
     mine = torch.tensor([int(reads), int(raw_bytes), int(compressed_bytes)], dtype=torch.int64, device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return mine.unsqueeze(0).cpu(), 0
     world = dist.get_world_size()
     table = [torch.zeros_like(mine) for _ in range(world)]
@@ -50,7 +71,7 @@ def exchange_tallies(reads, raw_bytes, compressed_bytes, device=None):
 
 def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float (used for the timed region of the benchmark)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
