@@ -76,8 +76,9 @@ def cpu_baseline(min_seconds=8.0, n_reads=16384):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
-    cores = os.cpu_count() or 1
-    if cores < 32:  # a small host: keep the leg at ~10-30 s of CPU work
+    hw = os.cpu_count() or 1
+    cores, quota_note = usable_cpus()
+    if cores < 32:  # a small host (or a small CPU quota): keep the leg at ~10-30 s of CPU work
         n_reads = min(n_reads, 256 * cores)
     opts = O.options(True, 2, 1, 1)
     one = O.bench_roundtrip(min(n_reads, 64), 1, 1.0, opts)
@@ -87,11 +88,13 @@ def cpu_baseline(min_seconds=8.0, n_reads=16384):
         "unit": "MB/s",
         "cores": cores,
         "kind": "port",
-        "sample": "reads 0..%d of the same generator (%.1f MB raw), encode+decode, %d persistent threads (all hardware threads of the "
-                  "host) claiming reads from a queue, scalar svb (not the SSSE3 worker) + libzstd %s level 1, verification in an "
-                  "untimed pass, best of %d timed passes; one thread: %.1f MB/s"
-        % (n_reads - 1, allc["raw_bytes"] / 1e6, cores, (O.lib().vbo_zstd_version() or b"?").decode(), allc["passes"],
+        "sample": "reads 0..%d of the same generator (%.1f MB raw), encode+decode, %d persistent threads (%s) claiming reads from a "
+                  "queue, scalar svb (not the SSSE3 worker) + libzstd %s level 1, verification in an untimed pass, best of %d timed "
+                  "passes; one thread: %.1f MB/s"
+        % (n_reads - 1, allc["raw_bytes"] / 1e6, cores, quota_note, (O.lib().vbo_zstd_version() or b"?").decode(), allc["passes"],
            one["raw_bytes"] / one["best_s"] / 1e6),
+        "one_thread": round(one["raw_bytes"] / one["best_s"] / 1e6, 1),
+        "host_hw_threads": hw,
         "ratio": round(allc["raw_bytes"] / allc["comp_bytes"], 4),
         "encode_share": round(allc["enc_thread_s"] / (allc["enc_thread_s"] + allc["dec_thread_s"]), 3),
     }
@@ -103,7 +106,7 @@ def cpu_baseline(min_seconds=8.0, n_reads=16384):
             with open("/sys/devices/system/cpu/cpu%d/topology/physical_package_id" % cpu) as f:
                 if int(f.read()) == 0:
                     socket0.append(cpu)
-        if socket0 and len(socket0) < cores:
+        if socket0 and len(socket0) < cores and cores == hw:  # only meaningful when the process may use the whole host
             saved = os.sched_getaffinity(0)
             os.sched_setaffinity(0, socket0)
             try:
@@ -114,6 +117,34 @@ def cpu_baseline(min_seconds=8.0, n_reads=16384):
     except OSError:
         pass
     return out
+
+
+def usable_cpus():
+    """Hardware threads this process can really keep busy: the affinity mask, capped by the cgroup CPU quota (a container
+    may see 256 CPUs and be allowed 8 CPUs' worth of time -- short bursts then look 10x faster than sustained work)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = "all %d hardware threads in the affinity mask" % n
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()
+            if q != "max":
+                quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = float(f.read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        k = max(1, int(quota + 0.5))
+        note = "cgroup CPU quota %.1f of %d hardware threads" % (quota, n)
+        n = k
+    return n, note
 
 
 def committed_traffic(kernels):
@@ -259,7 +290,7 @@ def run_rank(args):
         off, total = batch.layout(sizes.cpu(), 64)
         caps = max_compressed_sizes(sizes.cpu(), 1)
         coff, ctotal = batch.layout(caps, 64)
-        raw = torch.empty(total, dtype=torch.uint8, device=dev)
+        raw = torch.zeros(total, dtype=torch.uint8, device=dev)  # zeros: the alignment gaps between reads compare equal below
         off = off.to(dev)
         codec.synth_signal(5, a, raw, off, lens)
         max_total, max_ctotal = max(max_total, total), max(max_ctotal, ctotal)
@@ -282,6 +313,7 @@ def run_rank(args):
     # ---- every resident batch round-trips, on the device (untimed; also the first warm-up)
     comp_bytes_all = 0
     for B in batches:
+        back.zero_()  # the arena is shared by batches with different layouts: clear the previous batch's bytes in the gaps
         step(B)
         if not os.environ.get("VBZ_BENCH_KERNEL_EXPERIMENT"):  # set only to time deliberately broken kernel variants
             assert bool((res[: B["n"]] == B["size"]).all()), "decode failed for some read"
@@ -334,6 +366,7 @@ def run_rank(args):
         if not args.no_stages:
             o0 = codec.options(True, 2, 0, 1)
             B = batches[0]
+            back.zero_()
             step(B, o0)
             assert torch.equal(B["raw"], back[: B["total"]]), "svb-only round trip mismatch"
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
@@ -375,13 +408,13 @@ def run_rank(args):
         t_dom_dir = t_enc if dom_dir == "encode" else t_dec
         achieved = alg_dir / t_dom_dir / 1e9
         traffic_map, traffic_src, traffic_reads = committed_traffic([k for k in per_launch if k != "plan_scratch"])
-        scale = (batches[0]["n"] / traffic_reads) if traffic_reads else 1.0
+        scale = (n / traffic_reads) if traffic_reads else 1.0
         dir_traffic = None
         names = [k for k in (enc_k if dom_dir == "encode" else dec_k) if k != "plan_scratch"]
         if names and all(k in traffic_map for k in names):
             dir_traffic = int(sum(traffic_map[k] for k in names) * scale)
-            if traffic_reads != batches[0]["n"]:
-                traffic_src = "%s, scaled from %d to %d reads per launch" % (traffic_src, traffic_reads, batches[0]["n"])
+            if traffic_reads != n:
+                traffic_src = "%s, scaled from %d to %d reads per launch" % (traffic_src, traffic_reads, n)
         roof = {
             "bound": "hbm",
             "kernel": dom,
@@ -422,10 +455,11 @@ def run_rank(args):
             "data": "synthetic",
             "config": {
                 "workload": "configs[1]: synthetic int16 reads of ~100k samples (SURVEY 8d generator, seed 5), "
-                            "%d reads (%.2f GB raw) per step per GPU, %d distinct batches resident per GPU (%d distinct reads over %d GPU(s), each "
+                            "~%d reads (%.2f GB raw) per step per GPU (batches are cut by cumulative samples), %d distinct batches resident per GPU (%d distinct reads over %d GPU(s), each "
                             "round-trip verified before the timed region), zig-zag + svb + zstd-format stage, encode then decode, inputs resident in HBM"
                             % (batches[0]["n"], batches[0]["raw_bytes"] / 1e9, R, total_reads, world),
-                "reads_per_step": batches[0]["n"],
+                "reads_per_step": n,
+                "reads_in_first_batch": batches[0]["n"],
                 "distinct_reads": total_reads,
                 "options": "zigzag=1,integer_size=2,zstd_level=1,vbz_version=1",
                 "parallelism": "read table partitioned by cumulative samples across %d GPU(s) (rank 0 broadcasts the table, "

@@ -89,6 +89,10 @@ void vbo_synth_u32(uint64_t seed, uint64_t read_index, uint32_t* out, size_t n);
  * Returns decoded size, or (size_t)-1 on any format error. Writes at most cap bytes. */
 size_t vbo_zstd_restate_decompress(void* dst, size_t cap, const void* src, size_t n);
 
+/* ---- replay of the reference's fuzz target (oracle/vbz_oracle_fuzz.c; reference vbz/fuzzing/vbz_fuzz.cpp:138-161) */
+uint32_t vbo_fuzz_max_destination(uint32_t size, const VboOptions* o);
+int vbo_fuzz_decompress_sweep(const void* data, uint32_t size, const VboOptions* o, uint32_t max_destination, uint32_t* results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,7 +123,7 @@ int main(int argc, char** argv)
     const std::string path = argc > 1 ? argv[1] : "./test_file.h5";
     sym<herr_t (*)()>("H5open")();
     if (sym<herr_t (*)(const void*)>("H5Zregister")(vbz_plugin_info()) < 0) return 1;  // vbz_plugin_user_utils.h:54-62
-    const size_t n = 2000000;  // the reference draws 10 M; 8 chunks of 250 k values each keep the GPU test short
+    const size_t n = 10000000;  // vbz_hdf_plugin_test.cpp:119-136: 10 M random values, 8 chunks of 1.25 M values each
     const bool ok = both<int8_t>(path.c_str(), n) && both<uint8_t>(path.c_str(), n) && both<int16_t>(path.c_str(), n) &&
                     both<uint16_t>(path.c_str(), n) && both<int32_t>(path.c_str(), n) && both<uint32_t>(path.c_str(), n);
     std::printf(ok ? "ok\n" : "FAILED\n");

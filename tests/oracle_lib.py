@@ -31,7 +31,7 @@ class Options(ctypes.Structure):
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vbz_oracle.c", "zstd_restate.c", "vbz_oracle_bench.c", "vbz_oracle.h", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vbz_oracle.c", "zstd_restate.c", "vbz_oracle_bench.c", "vbz_oracle_fuzz.c", "vbz_oracle.h", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
@@ -87,8 +87,23 @@ def lib():
         L.vbo_synth_u32.argtypes = [ctypes.c_uint64, ctypes.c_uint64, vp, sz]
         L.vbo_bench_roundtrip.restype = ctypes.c_int
         L.vbo_bench_roundtrip.argtypes = [u32, ctypes.c_int, ctypes.c_double, op, ctypes.POINTER(ctypes.c_double)]
+        L.vbo_fuzz_max_destination.restype = u32
+        L.vbo_fuzz_max_destination.argtypes = [u32, op]
+        L.vbo_fuzz_decompress_sweep.restype = ctypes.c_int
+        L.vbo_fuzz_decompress_sweep.argtypes = [vp, u32, op, u32, vp]
         _lib = L
     return _lib
+
+
+def fuzz_sweep(data, opts):
+    """Replay of the reference fuzz target's decompress half for one input and option set (oracle/vbz_oracle_fuzz.c):
+    returns (max_destination, results[max_destination + 1, 2]) -- column 0 vbz_decompress, column 1 vbz_decompress_sized."""
+    a, p, n = _buf(np.frombuffer(bytes(data), np.uint8))
+    G = lib().vbo_fuzz_max_destination(n, ctypes.byref(opts))
+    res = np.zeros((G + 1, 2), np.uint32)
+    rc = lib().vbo_fuzz_decompress_sweep(p, n, ctypes.byref(opts), G, res.ctypes.data)
+    assert rc == 0
+    return G, res
 
 
 def options(zigzag=True, size=2, level=1, version=0):

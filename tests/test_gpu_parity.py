@@ -589,6 +589,11 @@ def test_pyvbz_interface():
                 c = vbz.compress(a, version=ver)
                 assert vbz.decompressed_size(c, dt, version=ver) == a.nbytes
                 assert (vbz.decompress(c, dt, version=ver) == a).all()
+                # the reference's positional form: compress(data, options), decompress(data, dtype, options)
+                o = vbz.compression_options(np.issubdtype(dt, np.signedinteger), np.dtype(dt).itemsize, 1, ver)
+                assert vbz.compress(a, o).tobytes() == c.tobytes() and (vbz.decompress(c, dt, o) == a).all()
+    with pytest.raises(TypeError):
+        vbz.compress(np.arange(4, dtype=np.int16), True)   # a bare zig-zag flag in the options slot is refused, not ignored
     sig = np.arange(0, 1000, dtype=np.int16)    # python/pyvbz/README.md:18-23
     c = vbz.compress(sig)
     assert c[:4].view("<u4")[0] == 2000 and len(c) < 400
@@ -664,7 +669,7 @@ def test_full_size_device_round_trip_properties():
 
     c = G.codec()
     dev = c.device
-    n = 2048
+    n = 16384
     lens = c.synth_lengths(5, 0, n)
     sizes = (lens.to(torch.int64) * 2)
     off, total = batch.layout(sizes.cpu(), 64)
@@ -689,13 +694,19 @@ def test_full_size_device_round_trip_properties():
     assert torch.equal(raw, back)
     ratio = float(sizes.sum()) / float(csize.to(torch.int64).sum())
     assert 2.2 < ratio < 2.6, ratio
-    hraw, hcomp = raw.cpu().numpy(), comp.cpu().numpy()
-    for i in (0, 1, 777, n - 1):
-        o, s = int(off[i]), int(sizes[i])
-        a = hraw[o : o + s].view(np.int16)
+    offh, coffh, csz = off.cpu().tolist(), coff.cpu().tolist(), csize.cpu().tolist()
+    oo = O.options(True, 2, 1, 1)
+    osum = gsum = 0
+    for i in [0, 1, 777, n - 1] + list(range(5, n, n // 28)):   # 32+ reads spread over the batch, each against the oracle
+        o, s = offh[i], int(sizes[i])
+        a = raw[o : o + s].cpu().numpy().view(np.int16)
         assert (a == O.synth_signal(5, i, s // 2)).all()                 # device generator == oracle generator
-        f = hcomp[int(coff[i]) : int(coff[i]) + int(csize[i])]
-        assert O.decompress(f, s, O.options(True, 2, 1, 1)).tobytes() == a.tobytes()
+        f = comp[coffh[i] : coffh[i] + csz[i]].cpu().numpy()
+        assert O.decompress(f, s, oo).tobytes() == a.tobytes()           # the reference's decoder reads the device's frame
+        ref = O.compress(a, oo)
+        osum += len(ref)
+        gsum += len(f)
+    assert abs(gsum / osum - 1.0) < 0.01, (gsum, osum)                   # T2: size within 1 % of the oracle's on the sample
 
 
 def test_zstd_encoder_tables_match_libzstd_construction():

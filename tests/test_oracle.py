@@ -218,3 +218,34 @@ def test_hdf5_filter_convention():
     s2 = ctypes.c_size_t(16)
     assert O.lib().vbo_filter(0, 2, cd, 16, ctypes.byref(s2), ctypes.byref(p2)) == 0
     libc.free(p2)
+
+
+def test_fuzz_corpus_replay_on_the_oracle():
+    """The reference's corpus runner (vbz/fuzzing/vbz_fuzz_runner.cpp, a ctest) replays LLVMFuzzerTestOneInput over the 238
+    corpus files and only requires "no crash".  The same replay on the oracle (oracle/vbz_oracle_fuzz.c): every file is
+    the committed data (sha256 in the index), every option set x every guessed size runs, and the tally of verdicts is
+    pinned so that a change of the oracle's error behaviour shows up here before it shows up in the GPU comparison."""
+    import collections
+    import hashlib
+
+    index = json.load(open(os.path.join(GOLDEN, "fuzz_corpus.json")))
+    blob = open(os.path.join(GOLDEN, "fuzz_corpus.bin"), "rb").read()
+    assert len(index) == 238 and sum(e["size"] for e in index) == len(blob)
+    tally = collections.Counter()
+    calls = 0
+    for e in index:
+        data = blob[e["offset"] : e["offset"] + e["size"]]
+        assert hashlib.sha256(data).hexdigest() == e["sha256"]
+        for zz in (True, False):
+            for isz in (0, 1, 2, 4):
+                for lvl in (0, 1):
+                    for ver in (0, 1):
+                        G, res = O.fuzz_sweep(data, O.options(zz, isz, lvl, ver))
+                        calls += res.size
+                        ok = res < O.FIRST_ERROR
+                        tally["ok"] += int(ok.sum())
+                        for v, c in zip(*np.unique(res[~ok], return_counts=True)):
+                            tally[O.ERRORS[int(v)]] += int(c)
+    assert calls == 949216
+    assert dict(tally) == {"ok": 87750, "VBZ_DESTINATION_SIZE_ERROR": 539540, "VBZ_INPUT_SIZE_ERROR": 512, "VBZ_ZSTD_ERROR": 252044,
+                           "VBZ_STREAMVBYTE_STREAM_ERROR": 69322, "VBZ_OUT_OF_MEMORY_ERROR": 48}, dict(tally)

@@ -14,6 +14,8 @@ Writes under tests/golden/:
                           (reference python/test/test_vbz_filter.py:57-73 asserts exactly this).
   multi_fast5_zip.fast5   the reference's own test file (test_data/, gzip-compressed signal of 10 reads), byte for byte:
                           the input of the fast5 re-packer tests (python/test/test_vbz_filter.py:57-73 reads it too)
+  fuzz_corpus.bin/.json   the 238 inputs of the reference's fuzz corpus (vbz/fuzzing/fuzz_corpus/, arbitrary bytes <= 2.3 KB
+                          each) packed into one blob + index; `--fuzz-only` (any python) writes just these
 Nothing here copies reference source text; these are inputs and expected outputs.
 """
 import hashlib
@@ -28,7 +30,24 @@ REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
+def pack_fuzz_corpus():
+    d = os.path.join(REF, "vbz/fuzzing/fuzz_corpus")
+    blob = bytearray()
+    index = []
+    for name in sorted(os.listdir(d)):
+        data = open(os.path.join(d, name), "rb").read()
+        index.append(dict(name=name, offset=len(blob), size=len(data), sha256=hashlib.sha256(data).hexdigest()))
+        blob += data
+    os.makedirs(OUT, exist_ok=True)
+    open(os.path.join(OUT, "fuzz_corpus.bin"), "wb").write(bytes(blob))
+    json.dump(index, open(os.path.join(OUT, "fuzz_corpus.json"), "w"), indent=0)
+    print("fuzz corpus", len(index), "files", len(blob), "bytes")
+
+
 def main():
+    pack_fuzz_corpus()
+    if "--fuzz-only" in sys.argv:
+        return 0
     import h5py
 
     os.makedirs(OUT, exist_ok=True)

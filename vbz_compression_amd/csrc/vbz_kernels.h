@@ -36,7 +36,7 @@ struct ReadBatch
 };
 
 // ---- streamvbyte stage (svb_kernels.hip) -------------------------------------------------------
-// integer_size in {1,2,4}; zigzag; half = v1 nibble codec (not implemented on the device yet).
+// integer_size in {1,2,4}; zigzag.
 // hdr: 0, or 4 to prepend / skip the sized header (u32 LE original size) in front of the svb stream.
 // strict_cap: apply the reference's worst-case capacity rule (keys + 4 bytes per value) to dst_cap.
 // half: the v1 nibble codec for 1-byte integers (vbz/v1/vbz_streamvbyte_impl.h)
