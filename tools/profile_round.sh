@@ -5,15 +5,19 @@
 # command, and two separate --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with other traces).
 # Afterwards, in the development container:
 #   python tools/summarize_profile.py <tag> gpurun_out/<tag>/kt/*/*kernel_stats.csv \
-#          gpurun_out/<tag>/fetch/*/*counter_collection.csv gpurun_out/<tag>/write/*/*counter_collection.csv
+#          gpurun_out/<tag>/fetch/*/*counter_collection.csv gpurun_out/<tag>/write/*/*counter_collection.csv \
+#          [gpurun_out/<tag>/sq1/*/*counter_collection.csv gpurun_out/<tag>/sq2/*/*counter_collection.csv]
 set -u
 tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -- python3 bench.py --no-cpu > "$out/kt.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/fetch" -- python3 bench.py --no-cpu --steps 3 --warmup 1 > "$out/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/write" -- python3 bench.py --no-cpu --steps 3 --warmup 1 > "$out/write.log" 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -- python3 bench.py --no-cpu --no-pcie --no-stages > "$out/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/fetch" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/write" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/write.log" 2>&1
+# SQ counters (instruction mix, stalls, LDS conflicts), two more separate passes
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -f csv -d "$out/sq1" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/sq1.log" 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC -f csv -d "$out/sq2" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/sq2.log" 2>&1
 ls -R "$out" | head -40
 cat "$out/bench.json"

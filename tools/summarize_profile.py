@@ -50,6 +50,25 @@ def main():
                 wa = ws / max(wn, 1)
                 w.writerow([k, max(fn, wn), "%.1f" % fa, "%.1f" % wa, "%.1f" % (2 * fa * 1024 / 1e6), "%.1f" % (wa * 1024 / 1e6),
                             "%.1f" % ((2 * fa + wa) * 1024 / 1e6)])
+    if len(sys.argv) >= 6:
+        # SQ counters of further --pmc passes: per-kernel averages per launch, one column per counter
+        agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+        names = []
+        for path in sys.argv[5:]:
+            for r in csv.DictReader(open(path)):
+                k = short(r["Kernel_Name"])
+                if "svb_" not in k and "zstd_" not in k and "vbz_" not in k:
+                    continue
+                a = agg[k][r["Counter_Name"]]
+                a[0] += 1
+                a[1] += float(r["Counter_Value"])
+                if r["Counter_Name"] not in names:
+                    names.append(r["Counter_Name"])
+        with open(os.path.join(out, tag + "_sq_counters.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "launches"] + names)
+            for k, v in sorted(agg.items()):
+                w.writerow([k, max(x[0] for x in v.values())] + ["%.4g" % (v[c][1] / max(v[c][0], 1)) if c in v else "" for c in names])
 
 
 if __name__ == "__main__":

@@ -50,6 +50,34 @@ __global__ __launch_bounds__(1024) void plan_scratch_kernel(uint32_t n, const ui
     }
 }
 
+// segment counts of a batch of few, large reads: exclusive scan by one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32_t* size, uint32_t unit, const uint32_t* gate, uint32_t* seg_first)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        uint32_t c = 0;
+        if (i < n) {
+            const uint32_t sz = (gate && gate[i] >= E_FIRST) || size[i] >= E_FIRST ? 0u : size[i];
+            c = sz ? (uint32_t)(((uint64_t)sz + unit - 1) / unit) : 1u;
+        }
+        const uint32_t inc = wave_incl_scan_u32(c);
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t pre = carry_s;
+        for (int k = 0; k < w; ++k) pre += wsum[k];
+        if (i < n) seg_first[i] = pre + inc - c;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + inc;
+        __syncthreads();
+    }
+    if (tid == 0) seg_first[n] = carry_s;
+}
+
 __global__ void parse_sized_kernel(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
                                    const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
                                    uint32_t* gate)
@@ -153,6 +181,12 @@ hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mu
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(plan_scratch_kernel, dim3(1), dim3(1024), 0, s, n, raw_size, mul_num, mul_den, limit, off, cap, gate,
                        gate_is_input ? 1u : 0u);
+    return hipGetLastError();
+}
+
+hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t* seg_first, hipStream_t s)
+{
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, s, n, size, unit_bytes, gate, seg_first);
     return hipGetLastError();
 }
 

@@ -54,47 +54,32 @@ __device__ __forceinline__ void store_elem(uint8_t* p, int elem, uint32_t v)
 // ------------------------------------------------------------------------------------------------
 // encode
 // ------------------------------------------------------------------------------------------------
-template <int ELEM, bool ZZ, bool I16ZZ>
-__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap)
+// Per-read validation shared by the one-workgroup-per-read kernel and the segmented kernels: 0 = go on, or the error.
+template <int ELEM, bool I16ZZ>
+__device__ __forceinline__ uint32_t svb_encode_check(uint32_t size, uint32_t cap, uint32_t hdr, uint32_t strict_cap)
+{
+    if (size % ELEM != 0) return E_INPUT_SIZE;  // vbz/v0/vbz_streamvbyte.cpp:28-31
+    const uint32_t n = size / ELEM;
+    const uint32_t keyLen = (n + 3u) >> 2;
+    // the reference requires the destination to hold the worst case (vbz/vbz.cpp:171-174); the
+    // library's own scratch slots (strict_cap == 0) are sized for what this kernel can really emit
+    const uint64_t worst = (uint64_t)keyLen + ((I16ZZ && !strict_cap) ? 2ull : 4ull) * n + hdr;
+    if (worst > cap) return worst > 0xFFFFFFF0ull ? E_INPUT_SIZE : E_DESTINATION_SIZE;
+    return 0;
+}
+
+// Values [first, end) of a read of n values (first a multiple of the tile size): control bytes to keys[first/4 ...),
+// data bytes to data[0 ...) -- `data` is where this range's data bytes start, any alignment; only bytes of the range
+// are touched.  COUNT_ONLY: nothing is written, the data byte count is all that is wanted.  Returns the data bytes
+// (workgroup-uniform).  All 256 threads.
+template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY>
+__device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t first, uint32_t end, uint8_t* keys, uint8_t* data,
+                                                     uint8_t* stage, uint32_t* wsum)
 {
     constexpr int VPL = Vpl<ELEM>::value;
     constexpr int TILE = WG * VPL;
-    constexpr int MAXLEN = I16ZZ ? 2 : 4;
-    constexpr int STAGE = TILE * MAXLEN + 32;
-    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
-    __shared__ uint32_t wsum[4];
-
-    const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (tid == 0) b.result[r] = b.gate[r];
-        return;
-    }
-    const uint32_t size = b.src_size[r];
-    const uint32_t cap = b.dst_cap[r];
-    if (size % ELEM != 0) {  // vbz/v0/vbz_streamvbyte.cpp:28-31
-        if (tid == 0) b.result[r] = E_INPUT_SIZE;
-        return;
-    }
-    const uint32_t n = size / ELEM;
-    const uint32_t keyLen = (n + 3u) >> 2;
-    {   // the reference requires the destination to hold the worst case (vbz/vbz.cpp:171-174); the
-        // library's own scratch slots (strict_cap == 0) are sized for what this kernel can really emit
-        const uint64_t worst = (uint64_t)keyLen + ((I16ZZ && !strict_cap) ? 2ull : 4ull) * n + hdr;
-        if (worst > cap) {
-            if (tid == 0) b.result[r] = worst > 0xFFFFFFF0ull ? E_INPUT_SIZE : E_DESTINATION_SIZE;
-            return;
-        }
-    }
-    const uint8_t* in = b.src + b.src_off[r];
-    uint8_t* out = b.dst + b.dst_off[r];
-    if (hdr) {
-        if (tid < 4) out[tid] = (uint8_t)(size >> (8 * tid));
-        out += 4;
-    }
-    uint8_t* keys = out;
-    uint8_t* data = out + keyLen;
     const uint32_t A = (uint32_t)((uintptr_t)data & 15u);
     uint8_t* gal = data - A;  // 16-byte aligned address space of the data section
     const bool in_aligned = (((uintptr_t)in) & 15u) == 0;
@@ -105,19 +90,20 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
     // the next tile's 16 bytes per lane are requested before this tile is processed (one load always in flight)
     uint4 qnext = make_uint4(0u, 0u, 0u, 0u);
     {
-        const uint32_t i0 = (uint32_t)tid * VPL;
-        if (in_aligned && i0 < n && n - i0 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i0 * ELEM);
+        const uint32_t i0 = first + (uint32_t)tid * VPL;
+        if (in_aligned && i0 < end && end - i0 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i0 * ELEM);
     }
-    for (uint32_t t0 = 0; t0 < n; t0 += TILE) {
+    for (uint32_t t0 = first; t0 < end; t0 += TILE) {
         const uint32_t i0 = t0 + (uint32_t)tid * VPL;
-        const int valid = i0 >= n ? 0 : (n - i0 >= (uint32_t)VPL ? VPL : (int)(n - i0));
+        const int valid = i0 >= end ? 0 : (end - i0 >= (uint32_t)VPL ? VPL : (int)(end - i0));
+        const bool full = in_aligned && end - t0 >= (uint32_t)TILE;
         const uint4 q = qnext;
         {
             const uint32_t i1 = i0 + TILE;
-            if (in_aligned && i1 < n && n - i1 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i1 * ELEM);
+            if (in_aligned && i1 < end && end - i1 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i1 * ELEM);
         }
         uint32_t u[VPL];
-        if (I16ZZ && in_aligned && t0 + TILE <= n) {
+        if (I16ZZ && full) {
             // full int16 tile: wrap-around delta and 16-bit zig-zag (sse3.h:432-440) on two samples per instruction
             typedef short s16x2 __attribute__((ext_vector_type(2)));
             const uint32_t w[4] = { q.x, q.y, q.z, q.w };
@@ -171,7 +157,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         }
         }
         uint32_t keybits = 0, L = 0;
-        if (I16ZZ && in_aligned && t0 + TILE <= n) {  // full tile of one- or two-byte values
+        if (I16ZZ && full) {  // full tile of one- or two-byte values
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
                 const uint32_t code = u[k] >> 8 ? 1u : 0u;
@@ -179,8 +165,10 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
                 L += code;
             }
             L += VPL;
-            const uint16_t kk = (uint16_t)keybits;
-            __builtin_memcpy(keys + (i0 >> 2), &kk, 2);
+            if (!COUNT_ONLY) {
+                const uint16_t kk = (uint16_t)keybits;
+                __builtin_memcpy(keys + (i0 >> 2), &kk, 2);
+            }
         } else {
 #pragma unroll
         for (int k = 0; k < VPL; ++k) {
@@ -192,7 +180,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         }
         }
         // control bytes: VPL/4 per lane, contiguous across the wave
-        if (!(I16ZZ && in_aligned && t0 + TILE <= n) && valid > 0) {
+        if (!COUNT_ONLY && !(I16ZZ && full) && valid > 0) {
             uint8_t* kp = keys + (i0 >> 2);
             if (VPL == 8 && valid > 4) {
                 uint16_t kk = (uint16_t)keybits;
@@ -203,8 +191,12 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         }
         uint32_t tot;
         const uint32_t ex = block_excl_scan_u32(L, wsum, tot);
+        if (COUNT_ONLY) {
+            P += tot;
+            continue;
+        }
         uint32_t o = (uint32_t)(P - F) + ex;
-        if (I16ZZ && in_aligned && t0 + TILE <= n) {
+        if (I16ZZ && full) {
             // full tile, one or two bytes per value: both bytes are always written and a one-byte value's second
             // byte is overwritten by the lane's next value (a later instruction) -- no branches; only the lane's
             // last value must not touch the next lane's first byte
@@ -250,25 +242,26 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         P += tot;
         // the scan at the top of the next tile contains the barrier that orders these LDS writes
     }
+    if (COUNT_ONLY) return P - A;
     wg_lds_barrier();
     {   // tail: bytes [F, P) still in LDS
         const uint32_t rem = (uint32_t)(P - F);
         const uint32_t lo = (F == 0) ? A : 0u;
         if ((uint32_t)tid >= lo && (uint32_t)tid < rem) gal[F + tid] = stage[tid];
     }
-    if (tid == 0) b.result[r] = hdr + keyLen + (uint32_t)(P - A);
+    return P - A;
 }
 
-// ------------------------------------------------------------------------------------------------
-// decode
-// ------------------------------------------------------------------------------------------------
-template <int ELEM, bool ZZ, bool I16ZZ>
-__global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
+template <int ELEM, bool I16ZZ>
+struct EncStage
 {
-    constexpr int VPL = Vpl<ELEM>::value;
-    constexpr int TILE = WG * VPL;
-    constexpr int STAGE = TILE * 4 + 48;
-    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
+    static constexpr int value = WG * Vpl<ELEM>::value * (I16ZZ ? 2 : 4) + 32;
+};
+
+template <int ELEM, bool ZZ, bool I16ZZ>
+__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage[EncStage<ELEM, I16ZZ>::value];
     __shared__ uint32_t wsum[4];
 
     const uint32_t r = blockIdx.x;
@@ -277,51 +270,164 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
         if (tid == 0) b.result[r] = b.gate[r];
         return;
     }
-    const uint32_t in_size = b.src_size[r];
-    if (in_size >= E_FIRST) {  // the previous stage failed for this read
-        if (tid == 0) b.result[r] = in_size;
+    const uint32_t size = b.src_size[r];
+    const uint32_t err = svb_encode_check<ELEM, I16ZZ>(size, b.dst_cap[r], hdr, strict_cap);
+    if (err) {
+        if (tid == 0) b.result[r] = err;
         return;
     }
-    const uint32_t out_size = b.dst_cap[r];  // exact decoded byte count
-    if (out_size % ELEM != 0) {              // vbz/v0/vbz_streamvbyte.cpp:75-78
-        if (tid == 0) b.result[r] = E_DESTINATION_SIZE;
-        return;
+    const uint32_t n = size / ELEM;
+    const uint32_t keyLen = (n + 3u) >> 2;
+    const uint8_t* in = b.src + b.src_off[r];
+    uint8_t* out = b.dst + b.dst_off[r];
+    if (hdr) {
+        if (tid < 4) out[tid] = (uint8_t)(size >> (8 * tid));
+        out += 4;
+    }
+    const uint64_t bytes = svb_encode_range<ELEM, ZZ, I16ZZ, false>(in, 0, n, out, out + keyLen, stage, wsum);
+    if (tid == 0) b.result[r] = hdr + keyLen + (uint32_t)bytes;
+}
+
+// ---- one read on many workgroups ("segments"): for batches of few, large reads --------------------------------------
+// A segment is SEG_TILES tiles of values.  seg_first[r] (exclusive scan of the reads' segment counts, seg_first[n_reads] =
+// total) maps a workgroup to its (read, segment).  Pass 1 counts the data bytes of every segment, a scan turns the
+// counts into data offsets (and gives the read's result), pass 2 encodes every segment at its offset.
+constexpr int SEG_TILES = 16;
+
+__device__ __forceinline__ bool seg_locate(const uint32_t* seg_first, uint32_t n_reads, uint32_t g, uint32_t& r, uint32_t& k)
+{
+    if (g >= seg_first[n_reads]) return false;
+    uint32_t lo = 0, hi = n_reads;  // the last read with seg_first[r] <= g
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (seg_first[mid] <= g) lo = mid; else hi = mid;
+    }
+    r = lo;
+    k = g - seg_first[lo];
+    return true;
+}
+
+template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY>
+__global__ __launch_bounds__(WG) void svb_seg_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, const uint32_t* seg_first,
+                                                            uint32_t* seg_bytes, const uint64_t* seg_off)
+{
+    constexpr int SEG = WG * Vpl<ELEM>::value * SEG_TILES;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[COUNT_ONLY ? 16 : EncStage<ELEM, I16ZZ>::value];
+    __shared__ uint32_t wsum[4];
+    uint32_t r, k;
+    if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
+    const int tid = threadIdx.x;
+    if (COUNT_ONLY && tid == 0) seg_bytes[blockIdx.x] = 0;
+    if (b.gate && b.gate[r] >= E_FIRST) return;
+    const uint32_t size = b.src_size[r];
+    if (svb_encode_check<ELEM, I16ZZ>(size, b.dst_cap[r], hdr, strict_cap)) return;
+    const uint32_t n = size / ELEM;
+    const uint32_t keyLen = (n + 3u) >> 2;
+    const uint32_t first = k * (uint32_t)SEG;
+    const uint32_t end = n - first > (uint32_t)SEG ? first + SEG : n;
+    if (first >= n) return;  // the single (empty) segment of an empty read
+    const uint8_t* in = b.src + b.src_off[r];
+    uint8_t* out = b.dst + b.dst_off[r] + hdr;
+    if (COUNT_ONLY) {
+        const uint64_t bytes = svb_encode_range<ELEM, ZZ, I16ZZ, true>(in, first, end, nullptr, nullptr, stage, wsum);
+        if (tid == 0) seg_bytes[blockIdx.x] = (uint32_t)bytes;
+    } else {
+        (void)svb_encode_range<ELEM, ZZ, I16ZZ, false>(in, first, end, out, out + keyLen + seg_off[blockIdx.x], stage, wsum);
+    }
+}
+
+// one workgroup per read: data offsets of its segments (exclusive scan of their byte counts) and the read's result
+template <int ELEM, bool I16ZZ>
+__global__ __launch_bounds__(WG) void svb_seg_encode_scan_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, const uint32_t* seg_first,
+                                                                 const uint32_t* seg_bytes, uint64_t* seg_off)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t s0 = seg_first[r], s1 = seg_first[r + 1];
+    uint64_t carry = 0;
+    for (uint32_t base = s0; base < s1; base += WG) {
+        const uint32_t i = base + (uint32_t)tid;
+        const uint32_t v = i < s1 ? seg_bytes[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(v, wsum, tot);
+        if (i < s1) seg_off[i] = carry + ex;
+        carry += tot;
+    }
+    if (tid == 0) {
+        uint32_t res;
+        if (b.gate && b.gate[r] >= E_FIRST) res = b.gate[r];
+        else {
+            const uint32_t size = b.src_size[r];
+            res = svb_encode_check<ELEM, I16ZZ>(size, b.dst_cap[r], hdr, strict_cap);
+            if (!res) {
+                const uint32_t n = size / ELEM;
+                res = hdr + ((n + 3u) >> 2) + (uint32_t)carry;
+                if (hdr) {
+                    uint8_t* out = b.dst + b.dst_off[r];
+                    for (int j = 0; j < 4; ++j) out[j] = (uint8_t)(size >> (8 * j));
+                }
+            }
+        }
+        b.result[r] = res;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+// Per-read validation of the decoder (both kernels): returns true when the read is finished with `res`.
+template <int ELEM, bool I16ZZ>
+__device__ __forceinline__ bool svb_decode_check(uint32_t in_size, uint32_t out_size, uint32_t& res)
+{
+    if (out_size % ELEM != 0) {  // vbz/v0/vbz_streamvbyte.cpp:75-78
+        res = E_DESTINATION_SIZE;
+        return true;
     }
     const uint32_t count = out_size / ELEM;
     const uint32_t keyLen = (count + 3u) >> 2;
     if (I16ZZ) {
         if (count == 0) {  // sse3.h:472-476
-            if (tid == 0) b.result[r] = 0;
-            return;
+            res = 0;
+            return true;
         }
         if (in_size < keyLen) {  // sse3.h:478-482
-            if (tid == 0) b.result[r] = E_INPUT_SIZE;
-            return;
+            res = E_INPUT_SIZE;
+            return true;
         }
     } else {
         // streamvbyte_validate_stream (vbz/v0/vbz_streamvbyte_impl.h:49-51)
         if (in_size == 0 || count == 0) {
-            if (tid == 0) b.result[r] = (in_size == count) ? 0u : E_STREAM;
-            return;
+            res = (in_size == count) ? 0u : E_STREAM;
+            return true;
         }
         if (keyLen > in_size) {
-            if (tid == 0) b.result[r] = E_STREAM;
-            return;
+            res = E_STREAM;
+            return true;
         }
     }
-    const uint8_t* in = b.src + b.src_off[r];
-    const uint8_t* data = in + keyLen;
-    uint8_t* out = b.dst + b.dst_off[r];
-    const uint32_t dataBytes = in_size - keyLen;
+    return false;
+}
+
+// MODE 0: decode values [first, end) of a stream of `count` values whose data bytes start at data[pos] and whose delta
+//         chain stands at `run`; store them.  MODE 1: only add up the data bytes the control bytes announce.
+//         MODE 2: decode without storing (the total of the deltas is wanted).  pos / run are updated; returns false when
+//         the stream is shorter than its control bytes claim.  All 256 threads.
+template <int ELEM, bool ZZ, bool I16ZZ, int MODE>
+__device__ __forceinline__ bool svb_decode_range(const uint8_t* in, const uint8_t* data, uint32_t dataBytes, uint32_t count, uint32_t first,
+                                                 uint32_t end, uint64_t& pos_io, uint32_t& run_io, uint8_t* out, uint8_t* stage, uint32_t* wsum)
+{
+    constexpr int VPL = Vpl<ELEM>::value;
+    constexpr int TILE = WG * VPL;
+    const int tid = threadIdx.x;
     const bool out_aligned = (((uintptr_t)out) & 15u) == 0;
     const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
-
-    uint32_t pos = 0;   // data bytes consumed so far
-    uint32_t run = 0;   // running value of the delta chain
-    bool bad = false;
-    for (uint32_t t0 = 0; t0 < count; t0 += TILE) {
+    uint64_t pos = pos_io;   // data bytes consumed so far
+    uint32_t run = run_io;   // running value of the delta chain
+    bool good = true;
+    for (uint32_t t0 = first; t0 < end; t0 += TILE) {
         const uint32_t i0 = t0 + (uint32_t)tid * VPL;
-        const int valid = i0 >= count ? 0 : (count - i0 >= (uint32_t)VPL ? VPL : (int)(count - i0));
+        const int valid = i0 >= end ? 0 : (end - i0 >= (uint32_t)VPL ? VPL : (int)(end - i0));
         uint32_t keybits = 0;
         if (valid > 0) {
             const uint8_t* kp = in + (i0 >> 2);
@@ -334,8 +440,12 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
             if (k < valid) L += ((keybits >> (2 * k)) & 3u) + 1u;
         uint32_t tot;
         const uint32_t ex = block_excl_scan_u32(L, wsum, tot);
-        if ((uint64_t)pos + tot > dataBytes) {  // stream shorter than its control bytes claim
-            bad = true;
+        if (MODE == 1) {
+            pos += tot;
+            continue;
+        }
+        if (pos + tot > dataBytes) {  // stream shorter than its control bytes claim
+            good = false;
             break;
         }
         // stage the tile's data bytes: aligned 16-byte chunks, coalesced
@@ -353,7 +463,7 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
         uint32_t acc = 0;
         // full tile of one- and two-byte codes (what the encoder writes for int16): values stay below 2^16, where the
         // body and the tail of the reference agree, so the lane just picks up its bytes
-        if (I16ZZ && t0 + TILE <= count && !__any((keybits & 0xAAAAu) != 0)) {
+        if (I16ZZ && end - t0 >= (uint32_t)TILE && !__any((keybits & 0xAAAAu) != 0)) {
 #pragma unroll
             for (int k = 0; k < VPL; ++k) {
                 const uint32_t two = (keybits >> (2 * k)) & 1u;
@@ -394,6 +504,10 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
         } else {
             wg_lds_barrier();  // stage is overwritten by the next tile
         }
+        if (MODE == 2) {
+            pos += tot;
+            continue;
+        }
         if (valid == VPL && out_aligned) {
             uint32_t w[4];
             if (ELEM == 4) {
@@ -422,7 +536,116 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
         }
         pos += tot;
     }
-    if (tid == 0) b.result[r] = (bad || pos != dataBytes) ? E_STREAM : count * ELEM;
+    pos_io = pos;
+    run_io = run;
+    return good;
+}
+
+template <int ELEM, bool ZZ, bool I16ZZ>
+__global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
+{
+    constexpr int STAGE = WG * Vpl<ELEM>::value * 4 + 48;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
+    __shared__ uint32_t wsum[4];
+
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (b.gate && b.gate[r] >= E_FIRST) {
+        if (tid == 0) b.result[r] = b.gate[r];
+        return;
+    }
+    const uint32_t in_size = b.src_size[r];
+    if (in_size >= E_FIRST) {  // the previous stage failed for this read
+        if (tid == 0) b.result[r] = in_size;
+        return;
+    }
+    const uint32_t out_size = b.dst_cap[r];  // exact decoded byte count
+    uint32_t res;
+    if (svb_decode_check<ELEM, I16ZZ>(in_size, out_size, res)) {
+        if (tid == 0) b.result[r] = res;
+        return;
+    }
+    const uint32_t count = out_size / ELEM;
+    const uint32_t keyLen = (count + 3u) >> 2;
+    const uint8_t* in = b.src + b.src_off[r];
+    const uint32_t dataBytes = in_size - keyLen;
+    uint64_t pos = 0;
+    uint32_t run = 0;
+    const bool good = svb_decode_range<ELEM, ZZ, I16ZZ, 0>(in, in + keyLen, dataBytes, count, 0, count, pos, run, b.dst + b.dst_off[r], stage, wsum);
+    if (tid == 0) b.result[r] = (!good || pos != dataBytes) ? E_STREAM : count * ELEM;
+}
+
+// ---- segmented decode: pass 1 adds up the data bytes each segment's control bytes announce; a scan gives every
+// segment its data offset and decides the read's verdict (the stream is good iff the announced total equals the data
+// bytes present -- the same predicate streamvbyte_validate_stream computes); zig-zag streams then need the delta total
+// of every segment (pass 2, decode without storing) and a second scan before the storing pass.
+template <int ELEM, bool ZZ, bool I16ZZ, int MODE>
+__global__ __launch_bounds__(WG) void svb_seg_decode_kernel(ReadBatch b, const uint32_t* seg_first, uint32_t* seg_val, const uint64_t* seg_pos,
+                                                            const uint32_t* seg_run)
+{
+    constexpr int SEG = WG * Vpl<ELEM>::value * SEG_TILES;
+    constexpr int STAGE = MODE == 1 ? 16 : WG * Vpl<ELEM>::value * 4 + 48;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
+    __shared__ uint32_t wsum[4];
+    uint32_t r, k;
+    if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
+    const int tid = threadIdx.x;
+    if (MODE != 0 && tid == 0) seg_val[blockIdx.x] = 0;
+    if (b.gate && b.gate[r] >= E_FIRST) return;
+    const uint32_t in_size = b.src_size[r];
+    if (in_size >= E_FIRST) return;
+    const uint32_t out_size = b.dst_cap[r];
+    uint32_t res;
+    if (svb_decode_check<ELEM, I16ZZ>(in_size, out_size, res)) return;
+    if (MODE != 1 && b.result[r] >= E_FIRST) return;  // the scan found the stream malformed
+    const uint32_t count = out_size / ELEM;
+    const uint32_t keyLen = (count + 3u) >> 2;
+    const uint32_t first = k * (uint32_t)SEG;
+    if (first >= count) return;
+    const uint32_t end = count - first > (uint32_t)SEG ? first + SEG : count;
+    const uint8_t* in = b.src + b.src_off[r];
+    const uint32_t dataBytes = in_size - keyLen;
+    uint64_t pos = MODE == 1 ? 0 : seg_pos[blockIdx.x];
+    uint32_t run = (MODE == 0 && ZZ) ? seg_run[blockIdx.x] : 0u;
+    const uint64_t pos0 = pos;
+    (void)svb_decode_range<ELEM, ZZ, I16ZZ, MODE>(in, in + keyLen, dataBytes, count, first, end, pos, run, b.dst + b.dst_off[r], stage, wsum);
+    if (MODE == 1 && tid == 0) seg_val[blockIdx.x] = (uint32_t)(pos - pos0);
+    if (MODE == 2 && tid == 0) seg_val[blockIdx.x] = run;
+}
+
+// one workgroup per read.  VERDICT: exclusive scan of the announced data bytes -> seg_pos, and the read's result;
+// otherwise: exclusive scan (mod 2^32) of the delta totals -> seg_run.
+template <int ELEM, bool I16ZZ, bool VERDICT>
+__global__ __launch_bounds__(WG) void svb_seg_decode_scan_kernel(ReadBatch b, const uint32_t* seg_first, const uint32_t* seg_val, uint64_t* seg_pos,
+                                                                 uint32_t* seg_run)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t s0 = seg_first[r], s1 = seg_first[r + 1];
+    uint64_t carry = 0;
+    for (uint32_t base = s0; base < s1; base += WG) {
+        const uint32_t i = base + (uint32_t)tid;
+        const uint32_t v = i < s1 ? seg_val[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(v, wsum, tot);
+        if (i < s1) {
+            if (VERDICT) seg_pos[i] = carry + ex;
+            else seg_run[i] = (uint32_t)carry + ex;
+        }
+        carry += tot;
+    }
+    if (VERDICT && tid == 0) {
+        uint32_t res;
+        if (b.gate && b.gate[r] >= E_FIRST) res = b.gate[r];
+        else if (b.src_size[r] >= E_FIRST) res = b.src_size[r];
+        else if (!svb_decode_check<ELEM, I16ZZ>(b.src_size[r], b.dst_cap[r], res)) {
+            const uint32_t count = b.dst_cap[r] / ELEM;
+            const uint32_t dataBytes = b.src_size[r] - ((count + 3u) >> 2);
+            res = carry == dataBytes ? count * ELEM : E_STREAM;
+        }
+        b.result[r] = res;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -686,6 +909,54 @@ hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, 
     if (integer_size == 1 && zigzag) return launch1(svb_decode_kernel<1, true, false>, b, s);
     if (integer_size == 1) return launch1(svb_decode_kernel<1, false, false>, b, s);
     return hipErrorInvalidValue;
+}
+
+// ---- segmented launches (few, large reads) --------------------------------------------------------------------------
+uint32_t svb_seg_unit_bytes(int integer_size)
+{
+    return (uint32_t)(WG * (integer_size == 4 ? 4 : 8) * SEG_TILES * integer_size);  // raw bytes of one segment
+}
+
+#define VBZ_SVB_DISPATCH(X)                                      \
+    do {                                                         \
+        if (integer_size == 2 && zigzag) { X(2, true, true); }   \
+        else if (integer_size == 2) { X(2, false, false); }      \
+        else if (integer_size == 4 && zigzag) { X(4, true, false); } \
+        else if (integer_size == 4) { X(4, false, false); }      \
+        else if (integer_size == 1 && zigzag) { X(1, true, false); } \
+        else if (integer_size == 1) { X(1, false, false); }      \
+        else return hipErrorInvalidValue;                        \
+    } while (0)
+
+hipError_t launch_svb_encode_seg(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, const uint32_t* seg_first,
+                                 uint32_t max_segs, uint32_t* seg_bytes, uint64_t* seg_off, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    const uint32_t sc = strict_cap ? 1u : 0u;
+#define X(E, Z, I)                                                                                                                   \
+    hipLaunchKernelGGL((svb_seg_encode_kernel<E, Z, I, true>), dim3(max_segs), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off);  \
+    hipLaunchKernelGGL((svb_seg_encode_scan_kernel<E, I>), dim3(b.n_reads), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off);    \
+    hipLaunchKernelGGL((svb_seg_encode_kernel<E, Z, I, false>), dim3(max_segs), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off)
+    VBZ_SVB_DISPATCH(X);
+#undef X
+    return hipGetLastError();
+}
+
+hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigzag, const uint32_t* seg_first, uint32_t max_segs,
+                                 uint32_t* seg_val, uint64_t* seg_pos, uint32_t* seg_run, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+#define X(E, Z, I)                                                                                                                          \
+    hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 1>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);             \
+    hipLaunchKernelGGL((svb_seg_decode_scan_kernel<E, I, true>), dim3(b.n_reads), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);       \
+    if (Z) {                                                                                                                                \
+        hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 2>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);         \
+        hipLaunchKernelGGL((svb_seg_decode_scan_kernel<E, I, false>), dim3(b.n_reads), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);  \
+    }                                                                                                                                       \
+    hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 0>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run)
+    VBZ_SVB_DISPATCH(X);
+#undef X
+    return hipGetLastError();
 }
 
 }  // namespace vbzhip

@@ -55,6 +55,8 @@ struct vbz_gpu_ctx
     DevBuf dbg;       // per-read phase timers (VBZ_HIP_PHASE_TIMING=1)
     DevBuf seqtab;    // encoding tables of the predefined sequence distributions
     DevBuf seqdtab;   // decoding tables of the same distributions
+    DevBuf segmeta;   // segment / span tables of the large-read path
+    int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
     bool phase_timing = false;
     void* pinned = nullptr;
@@ -241,6 +243,47 @@ struct MetaCarver
     }
 };
 
+// One read per workgroup (svb) / per wavefront (entropy stage) fills the GPU when a batch has thousands of reads.  A batch of
+// few, large reads (BASELINE configs[0] and [3]: one 400 k-sample read, one 10 M-element buffer; the HDF5 filter's one chunk
+// per call) takes the segmented kernels instead: every read is spread over many workgroups.  The rule looks at the batch
+// shape only (the sizes themselves live on the device): average read of half a megabyte or more.
+constexpr uint64_t SEGMENTED_MIN_AVG = 512u << 10;
+
+bool use_segments(const vbz_gpu_ctx* c, uint64_t raw_arena_bytes, uint32_t n)
+{
+    if (c->segmented >= 0) return c->segmented != 0;
+    return raw_arena_bytes / n >= SEGMENTED_MIN_AVG;
+}
+
+struct SegTables
+{
+    uint32_t* first = nullptr;  // [n + 1]
+    uint32_t* val = nullptr;    // [max_segs]
+    uint64_t* off = nullptr;    // [max_segs]
+    uint32_t* run = nullptr;    // [max_segs]
+    uint32_t max_segs = 0;
+};
+
+// segment tables for a batch whose raw bytes span `raw_arena_bytes`; sizes (device) are the reads' raw byte counts
+int plan_segments(vbz_gpu_ctx* c, uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint64_t raw_arena_bytes, uint32_t unit, SegTables* t)
+{
+    const uint64_t segs = raw_arena_bytes / unit + n + 1;
+    if (segs > 0x7FFFFFFFull) {
+        set_error(c, "batch too large for the segmented path");
+        return -1;
+    }
+    t->max_segs = (uint32_t)segs;
+    if (!ensure(c, c->segmeta, ((size_t)n + 1) * 4 + (size_t)segs * 16 + 256)) return -1;
+    MetaCarver mc(c->segmeta.p);
+    t->first = mc.take<uint32_t>((size_t)n + 1);
+    t->val = mc.take<uint32_t>(segs);
+    t->off = mc.take<uint64_t>(segs);
+    t->run = mc.take<uint32_t>(segs);
+    Timed tm(c, "seg_plan");
+    HIPCHK(c, launch_seg_plan(n, raw_size, unit, gate, t->first, c->stream), "seg_plan launch");
+    return 0;
+}
+
 int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
 {
     const uint32_t n = bt->n_reads;
@@ -262,9 +305,16 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
         HIPCHK(c, launch_copy_bytes(rb, hdr, s), "copy launch");
         return 0;
     }
+    const bool segmented = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n);
+    SegTables seg;
+    if (segmented && plan_segments(c, n, bt->src_size, nullptr, bt->src_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
     if (o->integer_size != 0 && o->zstd_compression_level == 0) {  // vbz.cpp:171-192: svb straight into dst
         Timed t(c, "svb_encode");
-        HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, half_codec(o), s), "svb_encode launch");
+        if (segmented)
+            HIPCHK(c, launch_svb_encode_seg(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, seg.first, seg.max_segs, seg.val, seg.off, s),
+                   "svb_encode (segmented) launch");
+        else
+            HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, half_codec(o), s), "svb_encode launch");
         return 0;
     }
     if (o->integer_size == 0) {  // zstd only
@@ -295,7 +345,11 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     a.gate = gate;
     {
         Timed t(c, "svb_encode");
-        HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, half_codec(o), s), "svb_encode launch");
+        if (segmented)
+            HIPCHK(c, launch_svb_encode_seg(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, seg.first, seg.max_segs, seg.val, seg.off, s),
+                   "svb_encode (segmented) launch");
+        else
+            HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, half_codec(o), s), "svb_encode launch");
     }
     ReadBatch z = rb;
     z.src = (const uint8_t*)c->scratch.p;
@@ -350,9 +404,16 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         HIPCHK(c, launch_copy_bytes(rb, 0, s), "copy launch");
         return 0;
     }
+    const bool segmented = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n);
+    SegTables seg;
+    if (segmented && plan_segments(c, n, rb.dst_cap, rb.gate, bt->dst_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
     if (o->zstd_compression_level == 0) {
         Timed t(c, "svb_decode");
-        HIPCHK(c, launch_svb_decode(rb, (int)o->integer_size, o->perform_delta_zig_zag, half_codec(o), s), "svb_decode launch");
+        if (segmented)
+            HIPCHK(c, launch_svb_decode_seg(rb, (int)o->integer_size, o->perform_delta_zig_zag, seg.first, seg.max_segs, seg.val, seg.off, seg.run, s),
+                   "svb_decode (segmented) launch");
+        else
+            HIPCHK(c, launch_svb_decode(rb, (int)o->integer_size, o->perform_delta_zig_zag, half_codec(o), s), "svb_decode launch");
         return 0;
     }
     if (o->integer_size == 0) {  // vbz.cpp:259-262: content larger than the destination -> DESTINATION_SIZE
@@ -391,7 +452,11 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     d.gate = gate;
     {
         Timed t(c, "svb_decode");
-        HIPCHK(c, launch_svb_decode(d, (int)o->integer_size, o->perform_delta_zig_zag, half_codec(o), s), "svb_decode launch");
+        if (segmented)
+            HIPCHK(c, launch_svb_decode_seg(d, (int)o->integer_size, o->perform_delta_zig_zag, seg.first, seg.max_segs, seg.val, seg.off, seg.run, s),
+                   "svb_decode (segmented) launch");
+        else
+            HIPCHK(c, launch_svb_decode(d, (int)o->integer_size, o->perform_delta_zig_zag, half_codec(o), s), "svb_decode launch");
     }
     return 0;
 }
@@ -436,6 +501,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     c->device = device;
     if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     {
         std::vector<uint8_t> host(seq_tables_bytes());
         seq_tables_build(host.data());
@@ -478,7 +544,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta })
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -42,6 +42,14 @@ struct ReadBatch
 // half: the v1 nibble codec for 1-byte integers (vbz/v1/vbz_streamvbyte_impl.h)
 hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, hipStream_t s);
 hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, bool half, hipStream_t s);
+// The same stage with one read spread over many workgroups ("segments" of svb_seg_unit_bytes raw bytes), for batches of few,
+// large reads (one 10 M-element buffer, one 400 k-sample read): seg_first[n_reads + 1] from launch_seg_plan; max_segs
+// bounds the total segment count (the grid); seg_* are scratch arrays of max_segs entries.  Not for the nibble codec.
+uint32_t svb_seg_unit_bytes(int integer_size);
+hipError_t launch_svb_encode_seg(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, const uint32_t* seg_first,
+                                 uint32_t max_segs, uint32_t* seg_bytes, uint64_t* seg_off, hipStream_t s);
+hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigzag, const uint32_t* seg_first, uint32_t max_segs,
+                                 uint32_t* seg_val, uint64_t* seg_pos, uint32_t* seg_run, hipStream_t s);
 
 // ---- zstd-format entropy stage (zstd_encode.hip / zstd_decode.hip) -----------------------------
 // encode: frame content = src read; key_elem = integer size whose key section (ceil(n/4) bytes, n
@@ -70,6 +78,9 @@ void seq_dtables_build(void* host_buffer);
 // gate_is_input: gate[] already holds per-read errors; those reads keep their error and get an empty slot.
 hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mul_num, uint32_t mul_den, uint64_t limit,
                                uint64_t* off, uint32_t* cap, uint32_t* gate, bool gate_is_input, hipStream_t s);
+// seg_first[i] = number of segments of reads 0..i-1, a read of `size` bytes having max(1, ceil(size / unit_bytes)) of them
+// (seg_first[n] = total); reads whose gate is an error get one segment.
+hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t* seg_first, hipStream_t s);
 // sized decode: read the 4-byte headers -> payload offsets/sizes, original sizes, gate errors
 hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
                               const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
