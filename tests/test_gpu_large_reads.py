@@ -1,0 +1,161 @@
+"""GPU tests (-m gpu) of the large-read path: batches of few, large reads (BASELINE.json configs[0] and [3]: one 400 k-sample
+int16 read, one 10 M-element uint32 buffer) are spread over many workgroups -- segmented svb kernels, one wavefront per
+span of the entropy stage, a span index behind the frame.  Results must be what the one-workgroup-per-read kernels
+give: svb bytes identical to the oracle's, frames that the reference's decoder (oracle + libzstd) reads, decoding of
+the oracle's frames, and an index that is verified, never trusted."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from vbz_compression_amd import _lib, batch
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+IDX_MAGIC, CP_MAGIC = 0x184D2A5C, 0x184D2A5B
+
+
+def _trailers(f):
+    """(body, [trailers...]) of a compressed buffer: the skippable frames this library appends, found from the end"""
+    out = []
+    while len(f) >= 24:
+        tb = int(f[-4:].view("<u4")[0])
+        if tb < 16 or tb > len(f) - 9:
+            break
+        m = f[len(f) - tb : len(f) - tb + 8].view("<u4")
+        if int(m[0]) not in (IDX_MAGIC, CP_MAGIC) or int(m[1]) != tb - 8:
+            break
+        out.append(f[len(f) - tb :])
+        f = f[: len(f) - tb]
+    return f, out
+
+
+def _large_cases():
+    rng = np.random.default_rng(8)
+    cases = [
+        ("config1 int16 400k", O.synth_signal(5, 0, 400000), (True, 2, 1, 1)),
+        ("int16 1.3M wraps", rng.integers(-32768, 32767, 1300003, endpoint=True).astype(np.int16), (True, 2, 1, 0)),
+        ("config4 uint32 3M", O.synth_u32(5, 3, 3_000_000), (False, 4, 3, 0)),
+        ("int32 zigzag 700k", rng.integers(-2**20, 2**20, 700001).astype(np.int32), (True, 4, 1, 0)),
+        ("int8 2M", rng.integers(-100, 100, 2_000_003).astype(np.int8), (True, 1, 1, 0)),
+        ("uint16 no zz 900k", rng.integers(0, 40000, 900001).astype(np.uint16), (False, 2, 1, 0)),
+        ("zeros int16 600k", np.zeros(600000, np.int16), (True, 2, 1, 1)),
+    ]
+    return cases
+
+
+@pytest.mark.parametrize("name,a,o", _large_cases(), ids=[c[0] for c in _large_cases()])
+def test_large_read_both_ways(name, a, o):
+    """One large read per call (n_reads = 1: the batch rule picks the large-read path by itself)."""
+    go = _lib.CompressionOptions(*o)
+    oo = O.options(*o)
+    for sized in (False, True):
+        # svb stage alone: byte-identical to the oracle
+        g0 = G.compress([a], _lib.CompressionOptions(o[0], o[1], 0, o[3]), sized=sized)[0]
+        r0 = O.compress(a, O.options(o[0], o[1], 0, o[3]), sized=sized)
+        assert not isinstance(g0, int) and g0.tobytes() == r0.tobytes()
+        assert G.decompress([r0], [a.nbytes], _lib.CompressionOptions(o[0], o[1], 0, o[3]), sized=sized)[0].tobytes() == a.tobytes()
+        # whole path
+        g = G.compress([a], go, sized=sized)[0]
+        assert not isinstance(g, int), hex(g)
+        back = O.decompress(g, a.nbytes, oo, sized=sized)             # the reference's decoder reads the device's frame
+        assert not isinstance(back, int) and back.tobytes() == a.tobytes()
+        r = O.compress(a, oo, sized=sized)
+        mine = G.decompress([r, g], [a.nbytes, a.nbytes], go, sized=sized)
+        assert not isinstance(mine[0], int) and mine[0].tobytes() == a.tobytes()    # libzstd's frame (no index: ordinary decoder)
+        assert not isinstance(mine[1], int) and mine[1].tobytes() == a.tobytes()    # own frame, decoded in spans
+        assert len(g) <= len(r) * 1.03, (len(g), len(r))
+        body, tr = _trailers(g[4:] if sized else g)
+        if a.nbytes * 1.0 > (600 << 10) and a.any():
+            assert tr and int(tr[0][:4].view("<u4")[0]) == IDX_MAGIC, "a frame of several spans carries the span index"
+
+
+def test_span_index_is_verified_not_trusted():
+    """Damage to the index (offsets that are no block boundaries, swapped entries, wrong counts, a missing or truncated
+    trailer) costs speed, never correctness: the frame still decodes to the same samples, as libzstd says it should."""
+    a = O.synth_signal(5, 1, 1_500_000)
+    o = (True, 2, 1, 1)
+    go, oo = _lib.CompressionOptions(*o), O.options(*o)
+    g = G.compress([a], go)[0]
+    body, tr = _trailers(g)
+    assert tr and int(tr[0][:4].view("<u4")[0]) == IDX_MAGIC
+    idx = tr[0]
+    ns = int(idx[8:12].view("<u4")[0])
+    assert ns >= 6 and len(idx) == 16 + 8 * ns
+    rng = np.random.default_rng(4)
+    variants = [g, np.ascontiguousarray(g[: len(g) - len(idx)])]
+    for k in range(24):
+        d = g.copy()
+        base = len(g) - len(idx)
+        e = base + 12 + 8 * int(rng.integers(0, ns))
+        if k % 4 == 0:      # a frame offset that is not a block boundary
+            d[e : e + 4] = np.array([int(d[e : e + 4].view("<u4")[0]) + int(rng.integers(1, 9))], "<u4").view(np.uint8)
+        elif k % 4 == 1:    # a content offset that is off
+            d[e + 4 : e + 8] = np.array([int(d[e + 4 : e + 8].view("<u4")[0]) + int(rng.integers(1, 4096))], "<u4").view(np.uint8)
+        elif k % 4 == 2:    # a bit anywhere in the trailer
+            at = base + int(rng.integers(0, len(idx)))
+            d[at] ^= 1 << int(rng.integers(0, 8))
+        else:               # two entries swapped
+            e2 = base + 12 + 8 * int(rng.integers(0, ns))
+            t = d[e : e + 8].copy()
+            d[e : e + 8] = d[e2 : e2 + 8]
+            d[e2 : e2 + 8] = t
+        variants.append(d)
+    # an index that points every span at a TRUE block boundary of a later span (treeless blocks there): must not be believed
+    d = g.copy()
+    base = len(g) - len(idx)
+    ent = d[base + 12 : base + 12 + 8 * ns].view("<u4").reshape(ns, 2).copy()
+    ent[2] = ent[3]
+    d[base + 12 + 16 : base + 12 + 24] = ent[2].view(np.uint8)
+    variants.append(d)
+    got = G.decompress(variants, [a.nbytes] * len(variants), go)
+    for v, gq in zip(variants, got):
+        lz = O.decompress(v, a.nbytes, oo)
+        if isinstance(lz, int):     # damage that breaks the skippable frame's own framing: both refuse
+            assert isinstance(gq, int), (gq, lz)
+        else:
+            assert not isinstance(gq, int), hex(gq)
+            assert gq.tobytes() == a.tobytes()
+
+
+def test_large_reads_in_one_batch_with_errors():
+    """Several large reads of different kinds of trouble in one batch: an empty read, a size that is not a multiple of the
+    integer size, a destination that is too small, a truncated frame -- each gets the oracle's verdict, the others are unaffected."""
+    c = G.codec()
+    o = (True, 2, 1, 1)
+    go, oo = _lib.CompressionOptions(*o), O.options(*o)
+    reads = [O.synth_signal(5, 10, 700000), np.zeros(0, np.int16), O.synth_signal(5, 11, 1200001), O.synth_signal(5, 12, 524288)]
+    odd = np.frombuffer(O.synth_signal(5, 13, 600000).tobytes()[:-1], np.uint8)
+    got = G.compress(reads + [odd], go)
+    for a, g in zip(reads, got):
+        assert not isinstance(g, int)
+        assert O.decompress(g, a.nbytes, oo).tobytes() == a.tobytes()
+    assert got[-1] == O.compress(odd, oo)      # VBZ_INPUT_SIZE_ERROR
+    frames = [got[0], got[1], got[2][: len(got[2]) // 2], got[3], got[0]]
+    sizes = [reads[0].nbytes, 0, reads[2].nbytes, reads[3].nbytes - 2, reads[0].nbytes + 2]
+    back = G.decompress(frames, sizes, go)
+    for f, n, b in zip(frames, sizes, back):
+        want = O.decompress(f, n, oo)
+        if isinstance(want, int):
+            assert isinstance(b, int) and (b == want or (b in (0xFFFFFFFB, 0xFFFFFFFF) and want in (0xFFFFFFFC, 0xFFFFFFFF, 0xFFFFFFFB))), (hex(b), hex(want))
+        else:
+            assert not isinstance(b, int) and b.tobytes() == want.tobytes()
+
+
+def test_whole_suite_on_the_large_read_path():
+    """VBZ_HIP_SEGMENTED=1 sends EVERY batch -- also the thousands of small reads of the other tests -- through the segmented
+    kernels: the bit-exact svb tests, the known answers, the corruption tests and the fuzz corpus must not notice."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBZ_HIP_SEGMENTED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_fuzz_corpus.py"), "-k",
+                        "not bench_line and not fast5 and not h5repack and not hdf5 and not cpp_caller and not many_threads"],
+                       capture_output=True, text=True, timeout=3000, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]

@@ -300,6 +300,10 @@ def test_checkpoint_trailer_is_optional_and_untrusted():
         assert not isinstance(f, int), f
         tb = int(f[-4:].view("<u4")[0])
         head = f[len(f) - tb : len(f) - tb + 12].view("<u4")
+        if head[0] == 0x184D2A5C:   # the span index of the large-read path (VBZ_HIP_SEGMENTED=1 forces it): not this test's subject
+            f = f[: len(f) - tb].copy()
+            tb = int(f[-4:].view("<u4")[0])
+            head = f[len(f) - tb : len(f) - tb + 12].view("<u4")
         assert head[0] == 0x184D2A5B and head[1] == tb - 8 and tb == 16 + 4 * (int(head[2]) >> 16)
         back = O.decompress(f, a.nbytes, O.options(True, 2, 1, 1))           # the reference path (libzstd) skips it
         assert not isinstance(back, int) and back.tobytes() == a.tobytes()

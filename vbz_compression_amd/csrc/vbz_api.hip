@@ -56,6 +56,8 @@ struct vbz_gpu_ctx
     DevBuf seqtab;    // encoding tables of the predefined sequence distributions
     DevBuf seqdtab;   // decoding tables of the same distributions
     DevBuf segmeta;   // segment / span tables of the large-read path
+    DevBuf spanmeta, spantmp;  // span tables and temporary slots of the entropy stage in the large-read path
+    bool index_trailer = true; // VBZ_HIP_INDEX_TRAILER=0: no span index behind large frames
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
     bool phase_timing = false;
@@ -355,6 +357,30 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     z.src = (const uint8_t*)c->scratch.p;
     z.src_off = svb_off;
     z.src_size = svb_size;
+    if (segmented) {  // few, large reads: one wavefront per span of a stream, then compaction
+        const uint32_t max_spans = zstd_span_max_spans(scratch_need, n);
+        if (!max_spans) {
+            set_error(c, "batch too large for the span path");
+            return -1;
+        }
+        const uint64_t tmp_bytes = zstd_span_tmp_bytes(scratch_need, n, max_spans);
+        if (!ensure(c, c->spantmp, tmp_bytes)) return -1;
+        if (!ensure(c, c->spanmeta, (size_t)max_spans * (zstd_span_desc_bytes() + 12) + ((size_t)n + 2) * 4 + 256)) return -1;
+        MetaCarver sm(c->spanmeta.p);
+        uint8_t* desc = sm.take<uint8_t>((size_t)max_spans * zstd_span_desc_bytes());
+        uint32_t* span_first = sm.take<uint32_t>((size_t)n + 1);
+        uint32_t* span_count = sm.take<uint32_t>(1);
+        uint32_t* span_size = sm.take<uint32_t>(max_spans);
+        uint32_t* span_trail = sm.take<uint32_t>(max_spans);
+        uint32_t* span_dst = sm.take<uint32_t>(max_spans);
+        z.gate = gate;
+        Timed t(c, "zstd_encode");
+        HIPCHK(c, launch_zstd_encode_spans(z, bt->src_size, o->integer_size, hdr, c->zero_run_sequences ? svb_cap : nullptr,
+                                           c->zero_run_sequences ? c->seqtab.p : nullptr, desc, span_first, span_count, max_spans,
+                                           (uint8_t*)c->spantmp.p, tmp_bytes, span_size, span_trail, span_dst, c->index_trailer, s),
+               "zstd_encode (spans) launch");
+        return 0;
+    }
     unsigned long long* dbg = dbg_begin(c, n);
     {
         Timed t(c, "zstd_encode");
@@ -437,8 +463,24 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     z.dst_cap = svb_cap;
     z.result = svb_size;
     z.gate = gate;
-    unsigned long long* dbg = dbg_begin(c, n);
-    {
+    unsigned long long* dbg = segmented ? nullptr : dbg_begin(c, n);
+    if (segmented) {  // few, large reads: frames with a span index are decoded one span per wavefront
+        const uint32_t max_spans = zstd_dspan_max_spans(scratch_need, n);
+        if (!max_spans) {
+            set_error(c, "batch too large for the span path");
+            return -1;
+        }
+        if (!ensure(c, c->spanmeta, (size_t)max_spans * (zstd_dspan_desc_bytes() + 12) + ((size_t)n + 2) * 8 + 256)) return -1;
+        MetaCarver sm(c->spanmeta.p);
+        uint8_t* desc = sm.take<uint8_t>((size_t)max_spans * zstd_dspan_desc_bytes());
+        uint32_t* dspan_first = sm.take<uint32_t>((size_t)n + 1);
+        uint32_t* dspan_count = sm.take<uint32_t>(1);
+        uint32_t* dspan_status = sm.take<uint32_t>((size_t)max_spans * 3);
+        uint32_t* redo = sm.take<uint32_t>(n);
+        Timed t(c, "zstd_decode");
+        HIPCHK(c, launch_zstd_decode_spans(z, E_STREAM, c->seqdtab.p, desc, dspan_first, dspan_count, max_spans, dspan_status, redo, s),
+               "zstd_decode (spans) launch");
+    } else {
         Timed t(c, "zstd_decode");
         // a frame whose content cannot be a valid svb stream of the expected size: the reference would
         // decode it and then fail in the svb stage with a stream error
@@ -502,6 +544,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_INDEX_TRAILER")) c->index_trailer = atoi(e) != 0;
     {
         std::vector<uint8_t> host(seq_tables_bytes());
         seq_tables_build(host.data());
@@ -544,7 +587,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp })
         if (b->p) (void)hipFree(b->p);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

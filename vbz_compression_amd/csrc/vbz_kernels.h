@@ -64,6 +64,16 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
                               hipStream_t s);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);
+// The same stage for batches of few, large reads: one wavefront per SPAN of a read's stream (see zstd_encode.hip).
+// stream_bytes bounds the total of the source streams.  span_desc: max_spans x zstd_span_desc_bytes(); span_first[n_reads + 1];
+// span_count[1]; span_size / span_trail / span_dst [max_spans]; span_tmp: zstd_span_tmp_bytes(...) bytes.
+size_t zstd_span_desc_bytes();
+uint32_t zstd_span_max_spans(uint64_t stream_bytes, uint32_t n_reads);  // 0: too large
+uint64_t zstd_span_tmp_bytes(uint64_t stream_bytes, uint32_t n_reads, uint32_t max_spans);
+hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
+                                    const void* seq_tables, void* span_desc, uint32_t* span_first, uint32_t* span_count, uint32_t max_spans,
+                                    uint8_t* span_tmp, uint64_t span_tmp_bytes, uint32_t* span_size, uint32_t* span_trail, uint32_t* span_dst,
+                                    bool index_trailer, hipStream_t s);
 // decode: result[i] = frame content size, E_ZSTD for a malformed frame, or `toosmall_code` when the
 // frame's content size exceeds dst_cap[i].
 // seq_dtables (device, from seq_dtables_build): decoding tables of the predefined LL / ML distributions.
@@ -71,6 +81,14 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
                               hipStream_t s);
 size_t seq_dtables_bytes();
 void seq_dtables_build(void* host_buffer);
+// The same for batches of few, large reads: frames that carry the encoder's span index are decoded one span per wavefront
+// (verified; anything else, and every error verdict, comes from the ordinary decoder in a second launch gated by redo[]).
+// content_bytes bounds the total frame content.  dspan_desc: max_spans x zstd_dspan_desc_bytes(); dspan_first[n_reads + 1];
+// dspan_count[1]; dspan_status[3 * max_spans]; redo[n_reads].
+size_t zstd_dspan_desc_bytes();
+uint32_t zstd_dspan_max_spans(uint64_t content_bytes, uint32_t n_reads);  // 0: too large
+hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* dspan_desc, uint32_t* dspan_first,
+                                    uint32_t* dspan_count, uint32_t max_spans, uint32_t* dspan_status, uint32_t* redo, hipStream_t s);
 
 // ---- helpers (helpers.hip) ---------------------------------------------------------------------
 // scratch slots for the intermediate svb streams: slot(i) = align16(ceil(raw_size[i]*num/den)+8)+48,

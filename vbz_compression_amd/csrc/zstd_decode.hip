@@ -1571,16 +1571,42 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
 #ifndef VBZ_DEC_WAVES
 #define VBZ_DEC_WAVES 1
 #endif
+// Span mode (batches of few, large reads): one wavefront decodes one SPAN of a frame -- a run of blocks that begins with a
+// block carrying its own Huffman tree -- as announced by the index trailer zstd_encode.hip writes behind large frames.
+// The index is verified, never trusted: a span must end exactly where the next one begins (in the frame and in the
+// content), spans other than the first may not contain sequences or lean on an earlier Huffman table; if anything is
+// off, the frame is decoded again by one wavefront the ordinary way, which is also what decides every error verdict.
+struct DecSpan
+{
+    uint32_t read;
+    uint32_t src_pos;   // first block of the span (offset in the read's source)
+    uint32_t src_end;   // where the span must end (the next span's first block); unused for the last span
+    uint32_t dst_pos;   // content offset of the span's first byte
+    uint32_t flags;     // DSPAN_*
+};
+constexpr uint32_t DSPAN_WHOLE = 1, DSPAN_LAST = 2, DSPAN_FIRST = 4;
+constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;      // zstd_encode.hip: the span index trailer
+constexpr uint32_t DSPAN_MIN_CONTENT = 128u << 10;  // an honest index has at most fcs / this + 4 spans
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
 template <bool TIMED>
-__global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs)
+__global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs,
+                                                                      const DecSpan* dspans, const uint32_t* dspan_count, uint32_t* dspan_status,
+                                                                      const uint32_t* only)
 {
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
-    const uint32_t r = blockIdx.x;
     const int lane = threadIdx.x;
+    DecSpan sp = {};
+    if (dspans) {
+        if (blockIdx.x >= *dspan_count) return;
+        sp = dspans[blockIdx.x];
+    }
+    // partial: this wave decodes one span of the frame and reports to dspan_status instead of the read's result
+    const bool partial = dspans != nullptr && !(sp.flags & DSPAN_WHOLE);
+    const uint32_t r = dspans ? sp.read : blockIdx.x;
+    if (only && !only[r]) return;  // second launch of span mode: only the frames whose spans did not work out
     if (b.gate && b.gate[r] >= E_FIRST) {
         if (lane == 0) b.result[r] = b.gate[r];
         return;
@@ -1607,10 +1633,13 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             PHASE(4);                                                                                                 \
         }                                                                                                             \
     } while (0)
-#define FAIL()                                   \
-    do {                                         \
-        if (lane == 0) b.result[r] = E_ZSTD;     \
-        return;                                  \
+#define FAIL()                                                          \
+    do {                                                                \
+        if (lane == 0) {                                                \
+            if (partial) dspan_status[3 * blockIdx.x] = 2;              \
+            else b.result[r] = E_ZSTD;                                  \
+        }                                                               \
+        return;                                                         \
     } while (0)
 
     // ---- frame header (RFC 8878 3.1.1.1)
@@ -1651,6 +1680,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     }
     __syncthreads();
     if (L.ctl[C_ERR] == 2) {
+        if (partial) FAIL();
         if (lane == 0) b.result[r] = toosmall_code;
         return;
     }
@@ -1664,27 +1694,37 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const uint8_t* cp_tab = nullptr;
     uint32_t cp_count = 0, cp_spacing = 0;
     if (n >= 64) {
-        uint32_t tb;
+        uint32_t tb, ne = n;  // ne: where the checkpoint trailer would end (an index trailer may follow it)
         __builtin_memcpy(&tb, src + n - 4, 4);
-        if (tb >= 20 && tb <= 8 + 4 + 4 * 63 + 4 && tb + 16 <= n) {
+        if (tb >= 24 && tb + 16 <= n && (tb & 7u) == 0) {
+            uint32_t m[2];
+            __builtin_memcpy(m, src + n - tb, 8);
+            if (m[0] == IDX_MAGIC && m[1] == tb - 8) {
+                ne = n - tb;
+                __builtin_memcpy(&tb, src + ne - 4, 4);
+            }
+        }
+        if (tb >= 20 && tb <= 8 + 4 + 4 * 63 + 4 && tb + 16 <= ne) {
             uint32_t m[3];
-            __builtin_memcpy(m, src + n - tb, 12);
+            __builtin_memcpy(m, src + ne - tb, 12);
             const uint32_t cnt = m[2] >> 16;
             if (m[0] == 0x184D2A5Bu && m[1] == tb - 8 && tb == 16 + 4 * cnt && cnt >= 1) {
-                cp_tab = src + n - tb + 12;
+                cp_tab = src + ne - tb + 12;
                 cp_count = cnt;
                 cp_spacing = m[2] & 0xFFFFu;
             }
         }
     }
-    const uint32_t first_block = pos;
+    const uint32_t first_block = partial ? sp.src_pos : pos;
+    const uint32_t first_opos = partial ? sp.dst_pos : 0u;
     uint32_t opos = 0, ntask = 0;
     for (int attempt = 0;; ++attempt) {
+    if (partial && attempt != 0) FAIL();  // a frame that needs the careful second attempt is not decoded in spans
     // attempt 0 lets the stream decoders' rings reuse the LDS of FSE tables that are (normally) dead; if a later
     // block turns out to repeat such a table, the frame is decoded again with the tables kept (attempt 1)
     bool restart = false;
     pos = first_block;
-    opos = 0;
+    opos = first_opos;
     ntask = 0;
     bool huf_valid = false;
     bool fse_live = attempt != 0;  // FSE tables must survive: flush_tasks parks them in registers
@@ -1830,6 +1870,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             uint32_t nseq = SQB(0), sq_used = 1;
             const bool has_seq = nseq != 0;
             if (!has_seq && sqn != 1) FAIL();
+            if (has_seq && partial && !(sp.flags & DSPAN_FIRST)) FAIL();  // matches and repeat offsets reach across spans
             if ((uint64_t)opos + regen > fcs) FAIL();
             // ---- literals: where do they go?
             //   no sequences : straight to the output (Huffman streams become pending tasks)
@@ -2318,6 +2359,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             pos += bsize;
         }
         if (last) break;
+        if (partial && !(sp.flags & DSPAN_LAST)) {
+            if (pos == sp.src_end) break;
+            if (pos > sp.src_end) FAIL();
+        }
     }
     if (restart) continue;
     PHASE(0);
@@ -2326,6 +2371,15 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     }
     PHASE(1);
     break;
+    }
+    if (partial && !(sp.flags & DSPAN_LAST)) {
+        // the span ended where the next one starts: report where the content stands
+        if (lane == 0) {
+            dspan_status[3 * blockIdx.x + 1] = pos;
+            dspan_status[3 * blockIdx.x + 2] = opos;
+            dspan_status[3 * blockIdx.x] = 1;
+        }
+        return;
     }
     if (has_checksum) {
         if (pos + 4 > n) FAIL();
@@ -2341,13 +2395,152 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     }
     if (pos != n) FAIL();
     if (opos != fcs) FAIL();
+    if (partial) {
+        if (lane == 0) {
+            dspan_status[3 * blockIdx.x + 1] = pos;
+            dspan_status[3 * blockIdx.x + 2] = opos;
+            dspan_status[3 * blockIdx.x] = 1;
+        }
+        return;
+    }
     if (lane == 0) b.result[r] = fcs;
-    if (TIMED && lane == 0)
+    if (TIMED && lane == 0 && !dspans)
         for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
 #undef SQB
 #undef PHASE
 #undef FLUSH
 #undef FAIL
+}
+
+// ---- span mode: plan and finish ----------------------------------------------------------------------------------------
+// One thread per read: frame header and index trailer -> the read's spans (or one WHOLE span when there is no usable index).
+__global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint32_t max_spans, DecSpan* spans, uint32_t* dspan_first,
+                                                               uint32_t* dspan_count, uint32_t* dspan_status)
+{
+    __shared__ uint32_t wcnt[16];
+    __shared__ uint32_t carry_c;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_c = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < b.n_reads; base += 1024) {
+        const uint32_t i = base + tid;
+        uint32_t cnt = 0, hl = 0;
+        const uint8_t* idx = nullptr;  // the index entries, if usable
+        if (i < b.n_reads) {
+            cnt = 1;
+            const uint32_t n = b.src_size[i];
+            const bool gated = (b.gate && b.gate[i] >= E_FIRST) || n >= E_FIRST;
+            if (!gated && n >= 64) {
+                const uint8_t* src = b.src + b.src_off[i];
+                // frame header: single segment, no dictionary, no checksum (what zstd_encode.hip writes)
+                uint32_t magic;
+                __builtin_memcpy(&magic, src, 4);
+                const uint32_t fhd = src[4];
+                const int fcs_flag = fhd >> 6;
+                uint64_t fcs = 0;
+                bool ok = magic == 0xFD2FB528u && (fhd & 0x3F) == 0x20;
+                if (ok) {
+                    const uint32_t fsz = fcs_flag == 0 ? 1u : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+                    for (uint32_t k = 0; k < fsz; ++k) fcs |= (uint64_t)src[5 + k] << (8 * k);
+                    if (fsz == 2) fcs += 256;
+                    hl = 5 + fsz;
+                    ok = fcs <= b.dst_cap[i] && fcs < 0xFFFFFFF0ull;
+                }
+                uint32_t tb = 0, ns = 0;
+                if (ok) {
+                    __builtin_memcpy(&tb, src + n - 4, 4);
+                    ok = tb >= 32 && (tb & 7u) == 0 && (uint64_t)tb + hl + 8 <= n;
+                }
+                if (ok) {
+                    uint32_t m[3];
+                    __builtin_memcpy(m, src + n - tb, 12);
+                    ns = m[2];
+                    ok = m[0] == IDX_MAGIC && m[1] == tb - 8 && ns >= 2 && tb == 16 + 8 * ns && ns <= fcs / DSPAN_MIN_CONTENT + 4;
+                }
+                if (ok) {
+                    // entries: strictly increasing in the frame and in the content, inside the frame, the first at the first block
+                    const uint8_t* e = src + n - tb + 12;
+                    uint32_t pf = 0, pc = 0;
+                    for (uint32_t j = 0; j < ns && ok; ++j) {
+                        uint32_t v[2];
+                        __builtin_memcpy(v, e + 8 * j, 8);
+                        if (j == 0) ok = v[0] == hl && v[1] == 0;
+                        else ok = v[0] > pf && v[1] > pc;
+                        ok = ok && (uint64_t)v[0] + 3 <= n - tb && v[1] < fcs;
+                        pf = v[0];
+                        pc = v[1];
+                    }
+                    if (ok) {
+                        cnt = ns;
+                        idx = e;
+                    }
+                }
+            }
+        }
+        const uint32_t ci = wave_incl_scan_u32(cnt);
+        if (lane == 63) wcnt[w] = ci;
+        __syncthreads();
+        uint32_t pc = carry_c;
+        for (int k = 0; k < w; ++k) pc += wcnt[k];
+        if (i < b.n_reads) {
+            uint32_t si = pc + ci - cnt;
+            if (si + cnt > max_spans) {  // cannot happen with the host's bound: fall back to one span per read
+                idx = nullptr;
+                if (cnt > 1) cnt = 1;    // (later reads shift; their own check repeats)
+            }
+            dspan_first[i] = si;
+            if (si + cnt <= max_spans) {
+                if (!idx) {
+                    DecSpan d = {};
+                    d.read = i;
+                    d.flags = DSPAN_WHOLE | DSPAN_FIRST | DSPAN_LAST;
+                    spans[si] = d;
+                    dspan_status[3 * si] = 0;
+                } else {
+                    for (uint32_t j = 0; j < cnt; ++j) {
+                        uint32_t v[2], nx[2] = { 0, 0 };
+                        __builtin_memcpy(v, idx + 8 * j, 8);
+                        if (j + 1 < cnt) __builtin_memcpy(nx, idx + 8 * (j + 1), 8);
+                        DecSpan d;
+                        d.read = i;
+                        d.src_pos = v[0];
+                        d.src_end = nx[0];
+                        d.dst_pos = v[1];
+                        d.flags = (j == 0 ? DSPAN_FIRST : 0u) | (j + 1 == cnt ? DSPAN_LAST : 0u);
+                        spans[si + j] = d;
+                        dspan_status[3 * (si + j)] = 0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry_c = pc + ci;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        dspan_first[b.n_reads] = carry_c;
+        *dspan_count = carry_c < max_spans ? carry_c : max_spans;
+    }
+}
+
+// one thread per read: did the spans work out?  redo[r] = 1 sends the frame to the ordinary one-wavefront decoder.
+__global__ void zstd_dspan_finish_kernel(ReadBatch b, const DecSpan* spans, const uint32_t* dspan_first, const uint32_t* dspan_status, uint32_t* redo)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= b.n_reads) return;
+    const uint32_t s0 = dspan_first[r], s1 = dspan_first[r + 1];
+    uint32_t again = 0;
+    if (s1 <= s0) again = 1;
+    else if (!(spans[s0].flags & DSPAN_WHOLE)) {
+        bool ok = true;
+        for (uint32_t k = s0; k < s1 && ok; ++k) {
+            ok = dspan_status[3 * k] == 1;
+            if (ok && k + 1 < s1) ok = dspan_status[3 * k + 1] == spans[k + 1].src_pos && dspan_status[3 * k + 2] == spans[k + 1].dst_pos;
+        }
+        if (ok) b.result[r] = dspan_status[3 * (s1 - 1) + 2];  // == the frame content size (checked by the last span)
+        else again = 1;
+    }
+    redo[r] = again;
 }
 
 }  // namespace
@@ -2358,10 +2551,33 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
     if (b.n_reads == 0) return hipSuccess;
     if (dbg)
         hipLaunchKernelGGL(zstd_decode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables));
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables));
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+// ---- span mode (few, large reads) ------------------------------------------------------------------------------------------
+size_t zstd_dspan_desc_bytes() { return sizeof(DecSpan); }
+
+uint32_t zstd_dspan_max_spans(uint64_t content_bytes, uint32_t n_reads)
+{
+    const uint64_t v = content_bytes / DSPAN_MIN_CONTENT + 5ull * n_reads + 1;
+    return v > 0x7FFFFFF0ull ? 0u : (uint32_t)v;
+}
+
+hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* dspan_desc, uint32_t* dspan_first,
+                                    uint32_t* dspan_count, uint32_t max_spans, uint32_t* dspan_status, uint32_t* redo, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    DecSpan* spans = reinterpret_cast<DecSpan*>(dspan_desc);
+    const SeqDTables* dt = reinterpret_cast<const SeqDTables*>(seq_dtables);
+    hipLaunchKernelGGL(zstd_dspan_plan_kernel, dim3(1), dim3(1024), 0, s, b, max_spans, spans, dspan_first, dspan_count, dspan_status);
+    hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(max_spans), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, spans, dspan_count, dspan_status,
+                       nullptr);
+    hipLaunchKernelGGL(zstd_dspan_finish_kernel, dim3((b.n_reads + 255) / 256), dim3(256), 0, s, b, spans, dspan_first, dspan_status, redo);
+    hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, nullptr, nullptr, nullptr, redo);
     return hipGetLastError();
 }
 

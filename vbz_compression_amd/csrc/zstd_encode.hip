@@ -39,6 +39,13 @@ constexpr uint32_t BLOCK_MAX = 128u << 10;
 constexpr uint32_t MIN_BLOCK = 4096;      // target block size is at least this
 constexpr uint32_t SPLIT_MIN = 2048;      // frames smaller than this are one region
 constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams = 64 lanes)
+// Large reads (span mode, see EncSpan): blocks of at most SPAN_BLOCK bytes, SPAN_BLOCKS of them per span.  A span is what ONE
+// wavefront encodes -- its own histogram, its own Huffman table (first block with the tree, the others treeless) -- into a
+// temporary slot; a compaction pass then strings the spans of a frame together.  16 KB blocks keep the decoder's streams
+// short (4 KB of content per lane) at 0.1 % of header overhead.
+constexpr uint32_t SPAN_BLOCK = 16u << 10;
+constexpr uint32_t SPAN_BLOCKS = MAXBLK;
+constexpr uint32_t SPAN_BYTES = SPAN_BLOCK * SPAN_BLOCKS;
 #ifndef VBZ_STEP_LANE
 #define VBZ_STEP_LANE 16
 #endif
@@ -46,6 +53,18 @@ constexpr int STEP_LANE = VBZ_STEP_LANE;    // symbols packed per lane per step 
 constexpr int STEP_DW = STEP_LANE / 4;      // dwords per lane chunk
 constexpr int STEP_SYMS = WAVE * STEP_LANE; // symbols packed per wave step
 constexpr int OBUF_WORDS = (STEP_SYMS * 11) / 32 + 8;  // one step packs at most 2048 symbols of 11 bits
+
+// One span of a frame in span mode (built by zstd_span_plan_kernel, one per workgroup of the encode kernel).
+struct EncSpan
+{
+    uint32_t read;       // index of the read in the batch
+    uint32_t r0, r1;     // byte range of the svb stream this span codes
+    uint32_t flags;      // SPAN_*
+    uint64_t tmp_off;    // where its output goes in the temporary arena
+    uint32_t tmp_cap;
+    uint32_t pad;
+};
+constexpr uint32_t SPAN_FIRST = 1, SPAN_LAST = 2, SPAN_KEYSEQ = 4, SPAN_SKIP = 8;
 
 struct EncLds
 {
@@ -617,26 +636,40 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
 template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
-                                                           const uint32_t* src_cap, const SeqCTables* seqtab)
+                                                           const uint32_t* src_cap, const SeqCTables* seqtab, const EncSpan* spans,
+                                                           const uint32_t* span_count, uint8_t* span_tmp, uint32_t* span_size,
+                                                           uint32_t* span_trail)
 {
     __shared__ __attribute__((aligned(16))) EncLds L;
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
-    const uint32_t r = blockIdx.x;
     const int lane = threadIdx.x;
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (lane == 0) b.result[r] = b.gate[r];
+    // classic mode: workgroup = read, the wave codes the whole frame into the read's destination slot.
+    // span mode:    workgroup = span, the wave codes bytes [r0, r1) of the read's stream into the span's temporary slot.
+    const bool span_mode = spans != nullptr;
+    EncSpan sp = {};
+    if (span_mode) {
+        if (blockIdx.x >= *span_count) return;
+        sp = spans[blockIdx.x];
+        if (lane == 0) { span_size[blockIdx.x] = 0; span_trail[blockIdx.x] = 0; }
+        if (sp.flags & SPAN_SKIP) return;  // the read failed earlier: zstd_span_finish_kernel reports it
+    }
+    const uint32_t r = span_mode ? sp.read : blockIdx.x;
+    // the bytes produced (or an error code): the read's result, or the span's size
+#define FINISH(v) do { if (lane == 0) { if (span_mode) span_size[blockIdx.x] = (v); else b.result[r] = (v); } } while (0)
+    if (!span_mode && b.gate && b.gate[r] >= E_FIRST) {
+        FINISH(b.gate[r]);
         return;
     }
     const uint32_t N = b.src_size[r];
-    if (N >= E_FIRST) {  // the svb stage reported an error for this read
-        if (lane == 0) b.result[r] = N;
+    if (!span_mode && N >= E_FIRST) {  // the svb stage reported an error for this read
+        FINISH(N);
         return;
     }
-    const uint32_t cap = b.dst_cap[r];
+    const uint32_t cap = span_mode ? sp.tmp_cap : b.dst_cap[r];
     const uint8_t* in = b.src + b.src_off[r];
-    uint8_t* out = b.dst + b.dst_off[r];
+    uint8_t* out = span_mode ? span_tmp + sp.tmp_off : b.dst + b.dst_off[r];
     uint32_t K = 0;
     if (N >= SPLIT_MIN) {
         if (key_bytes) K = key_bytes[r];
@@ -646,7 +679,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 #define NEED(bytes)                                              \
     do {                                                         \
         if ((uint64_t)opos + (uint64_t)(bytes) > cap) {          \
-            if (lane == 0) b.result[r] = E_ZSTD;                 \
+            FINISH(E_ZSTD);                                      \
             return;                                              \
         }                                                        \
     } while (0)
@@ -657,30 +690,34 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     }
     uint32_t opos = 0;
     bool frame_cp = false;  // a sequences section with checkpoints was written
-    NEED(hdr + 9 + (N == 0 ? 3 : 0));
-    if (lane == 0) {
-        if (hdr) put_le(out, orig_size[r], 4);
-        uint8_t* p = out + hdr;
-        put_le(p, 0xFD2FB528u, 4);
-        if (N < 256) { p[4] = 0x20; p[5] = (uint8_t)N; }
-        else if (N < 65536 + 256) { p[4] = 0x60; put_le(p + 5, N - 256, 2); }
-        else { p[4] = 0xA0; put_le(p + 5, N, 4); }
+    if (!span_mode || (sp.flags & SPAN_FIRST)) {
+        NEED(hdr + 9 + (N == 0 ? 3 : 0));
+        if (lane == 0) {
+            if (hdr) put_le(out, orig_size[r], 4);
+            uint8_t* p = out + hdr;
+            put_le(p, 0xFD2FB528u, 4);
+            if (N < 256) { p[4] = 0x20; p[5] = (uint8_t)N; }
+            else if (N < 65536 + 256) { p[4] = 0x60; put_le(p + 5, N - 256, 2); }
+            else { p[4] = 0xA0; put_le(p + 5, N, 4); }
+        }
+        opos = hdr + 5 + (N < 256 ? 1 : (N < 65536 + 256 ? 2 : 4));
     }
-    opos = hdr + 5 + (N < 256 ? 1 : (N < 65536 + 256 ? 2 : 4));
     if (N == 0) {
-        if (lane == 0) { put_le(out + opos, 1, 3); b.result[r] = opos + 3; }
+        if (lane == 0) put_le(out + opos, 1, 3);
+        FINISH(opos + 3);
         return;
     }
     uint32_t T = (N + 13) / 14;
     T = T < MIN_BLOCK ? MIN_BLOCK : (T > BLOCK_MAX ? BLOCK_MAX : T);
+    if (span_mode) T = SPAN_BLOCK;
 
     bool keys_one_block = false;
-    for (int region = 0; region < 2; ++region) {
-        const uint32_t r0 = region == 0 ? 0 : K;
-        const uint32_t r1 = region == 0 ? (K ? K : N) : N;
+    for (int region = 0; region < (span_mode ? 1 : 2); ++region) {
+        const uint32_t r0 = span_mode ? sp.r0 : (region == 0 ? 0 : K);
+        const uint32_t r1 = span_mode ? sp.r1 : (region == 0 ? (K ? K : N) : N);
         if (region == 1 && K == 0) break;
         uint32_t S = r1 - r0;
-        const bool lastRegion = (r1 == N);
+        const bool lastRegion = span_mode ? (sp.flags & SPAN_LAST) != 0 : (r1 == N);
         const uint8_t* rin = in + r0;
         uint32_t nblk = (S + T - 1) / T;
         if (region == 1 && keys_one_block) {
@@ -694,7 +731,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         bool seqmode = false;
         uint32_t nrec = 0;
         const uint2* rec = nullptr;
-        if (region == 0 && K != 0 && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
+        if ((span_mode ? (sp.flags & SPAN_KEYSEQ) != 0 : (region == 0 && K != 0)) && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
             const uint32_t slot = src_cap[r];
             const uint64_t need = (uint64_t)N + 16 + 8ull * (S / RMIN + 2);
             if (need <= slot) {
@@ -863,7 +900,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         curblk = st >> 2;
                         const uint32_t tsz = (b0 + curblk) == 0 ? treeSize : 0u;
                         const uint32_t hl = 3u + blk_lh(curblk) + tsz + (blk_bs(curblk) < 256u ? 0u : 6u);
-                        if ((uint64_t)ocur + hl > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
+                        if ((uint64_t)ocur + hl > cap) { FINISH(E_ZSTD); return; }
                         for (uint32_t i = lane; i < tsz; i += WAVE) out[ocur + 3u + blk_lh(curblk) + i] = L.tree[i];
                         spos = ocur + hl;
                     }
@@ -895,7 +932,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
                     const uint32_t allbits = base_bits + total;
                     const uint32_t full = allbits >> 5;
-                    if ((uint64_t)spos + flushed + 4ull * full + 8 > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
+                    if ((uint64_t)spos + flushed + 4ull * full + 8 > cap) { FINISH(E_ZSTD); return; }
                     const uint32_t pos = base_bits + incl - T;
                     uint32_t word = pos >> 5;
                     uint32_t accbits = pos & 31;
@@ -943,14 +980,14 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                             wave_lds_sync();
                             uint32_t seqBytes = 1;  // a plain block ends with Number_of_Sequences = 0
                             if (seqmode) {
-                                if ((uint64_t)spos + 8 + 8ull * nrec > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
+                                if ((uint64_t)spos + 8 + 8ull * nrec > cap) { FINISH(E_ZSTD); return; }
                                 seqBytes = encode_zero_run_sequences(L, out + spos, rec, nrec, lane);
                                 frame_cp = true;
                                 wave_lds_sync();
                                 for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;  // it used the bit buffer
                                 wave_lds_sync();
                             } else {
-                                if ((uint64_t)spos + 1 > cap) { if (lane == 0) b.result[r] = E_ZSTD; return; }
+                                if ((uint64_t)spos + 1 > cap) { FINISH(E_ZSTD); return; }
                                 if (lane == 0) out[spos] = 0;
                             }
                             if (lane == 0) {
@@ -990,6 +1027,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             PHASE(5);
         }
     }
+    const uint32_t main_bytes = opos;
     if (frame_cp) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
         wave_lds_sync();
         const uint32_t count = L.cpCount, tb = 8u + 4u + 4u * count + 4u;
@@ -1005,11 +1043,236 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             opos += tb;
         }
     }
-    if (lane == 0) b.result[r] = opos;
-    if (TIMED && lane == 0)
+    if (span_mode) {  // the trailer stays behind the span's blocks in its slot; the compaction pass moves it behind the frame
+        if (lane == 0) {
+            span_size[blockIdx.x] = main_bytes;
+            span_trail[blockIdx.x] = opos - main_bytes;
+        }
+    } else if (lane == 0) {
+        b.result[r] = opos;
+    }
+    if (TIMED && lane == 0 && !span_mode)
         for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
 #undef PHASE
 #undef NEED
+#undef FINISH
+}
+
+// ---- span mode: plan, finish, compaction --------------------------------------------------------------------------------
+// Span mode serves batches of few, large reads (a 10 M-element buffer, one 400 k-sample read): the svb stream of a read is cut
+// into spans of at most SPAN_BYTES (the control-byte region and the data-byte region separately; a control-byte region of up
+// to 128 KB stays ONE span so that its zero runs can become sequences), one wavefront codes one span into a temporary slot,
+// then the spans are strung together behind the frame header.  Behind the frame (and behind the checkpoint trailer, if
+// any) goes an INDEX of the spans in a second skippable frame -- where each span's first block starts in the frame and in
+// the content -- with which zstd_decode.hip decodes the spans on different wavefronts; like the checkpoints it is verified,
+// never trusted (a decoder without it, e.g. libzstd, walks the blocks one after the other).
+//   layout: magic 0x184D2A5C, u32 payload bytes, { u32 nspans, nspans x { u32 frame offset, u32 content offset }, u32 total bytes }
+constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;
+
+__device__ __forceinline__ uint32_t span_tmp_bytes(uint32_t S, bool keyseq)
+{
+    const uint32_t b = S + (S >> 7) + 1024u + (keyseq ? 8u * (S / RMIN + 2u) + 512u : 0u);
+    return (b + 15u) & ~15u;
+}
+
+// per read: how its stream is cut.  keyN = spans of the control-byte region, dataN = of the rest.
+__device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN, uint32_t& dataN)
+{
+    keyN = K == 0 ? 0u : (K <= BLOCK_MAX ? 1u : (K + SPAN_BYTES - 1) / SPAN_BYTES);
+    const uint32_t D = N - K;
+    dataN = D ? (D + SPAN_BYTES - 1) / SPAN_BYTES : 0u;
+    if (N == 0) dataN = 1;  // the empty frame
+}
+
+__global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const uint32_t* svb_size, const uint32_t* orig_size, uint32_t key_elem,
+                                                              const uint32_t* gate, uint32_t seq_enabled, uint32_t max_spans, uint64_t tmp_limit,
+                                                              EncSpan* spans, uint32_t* span_first, uint32_t* span_count)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint32_t wcnt[16];
+    __shared__ uint64_t carry_b;
+    __shared__ uint32_t carry_c;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) { carry_b = 0; carry_c = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + tid;
+        uint32_t cnt = 0, N = 0, K = 0, keyN = 0, dataN = 0;
+        uint64_t bytes = 0;
+        bool skip = false;
+        if (i < n) {
+            N = svb_size[i];
+            skip = (gate && gate[i] >= E_FIRST) || N >= E_FIRST;
+            if (skip) {
+                cnt = 1;
+            } else {
+                if (N >= SPLIT_MIN && key_elem) {
+                    K = (orig_size[i] / key_elem + 3u) >> 2;
+                    if (K >= N) K = 0;
+                }
+                span_cut(N, K, keyN, dataN);
+                cnt = keyN + dataN;
+                for (uint32_t j = 0; j < keyN; ++j) {
+                    const uint32_t a = (uint32_t)((uint64_t)K * j / keyN), e = (uint32_t)((uint64_t)K * (j + 1) / keyN);
+                    bytes += span_tmp_bytes(e - a, keyN == 1 && seq_enabled);
+                }
+                const uint32_t D = N - K;
+                for (uint32_t j = 0; j < dataN; ++j) {
+                    const uint32_t a = (uint32_t)((uint64_t)D * j / dataN), e = (uint32_t)((uint64_t)D * (j + 1) / dataN);
+                    bytes += span_tmp_bytes(e - a, false);
+                }
+            }
+        }
+        uint32_t ci = cnt;
+        uint64_t bi = bytes;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t tc = (uint32_t)__shfl_up((int)ci, d, 64);
+            const uint64_t tb = __shfl_up(bi, d, 64);
+            if (lane >= d) { ci += tc; bi += tb; }
+        }
+        if (lane == 63) { wcnt[w] = ci; wsum[w] = bi; }
+        __syncthreads();
+        uint32_t pc = carry_c;
+        uint64_t pb = carry_b;
+        for (int k = 0; k < w; ++k) { pc += wcnt[k]; pb += wsum[k]; }
+        if (i < n) {
+            uint32_t si = pc + ci - cnt;
+            uint64_t off = pb + bi - bytes;
+            span_first[i] = si;
+            // a plan that does not fit the arrays it was given (cannot happen with the host's bounds) skips the read
+            const bool fits = si + cnt <= max_spans && off + bytes <= tmp_limit;
+            if (skip || !fits) {
+                if (si < max_spans) {
+                    EncSpan e = {};
+                    e.read = i;
+                    e.flags = SPAN_SKIP | SPAN_FIRST | SPAN_LAST;
+                    spans[si] = e;
+                    for (uint32_t j = 1; j < cnt && si + j < max_spans; ++j) { e.flags = SPAN_SKIP; spans[si + j] = e; }
+                }
+            } else {
+                const uint32_t D = N - K;
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    EncSpan e = {};
+                    e.read = i;
+                    bool keyseq = false;
+                    if (j < keyN) {
+                        e.r0 = (uint32_t)((uint64_t)K * j / keyN);
+                        e.r1 = (uint32_t)((uint64_t)K * (j + 1) / keyN);
+                        keyseq = keyN == 1 && seq_enabled;
+                    } else {
+                        const uint32_t q = j - keyN;
+                        e.r0 = K + (uint32_t)((uint64_t)D * q / dataN);
+                        e.r1 = K + (uint32_t)((uint64_t)D * (q + 1) / dataN);
+                    }
+                    e.flags = (j == 0 ? SPAN_FIRST : 0u) | (j + 1 == cnt ? SPAN_LAST : 0u) | (keyseq ? SPAN_KEYSEQ : 0u);
+                    e.tmp_off = off;
+                    e.tmp_cap = span_tmp_bytes(e.r1 - e.r0, keyseq);
+                    off += e.tmp_cap;
+                    spans[si + j] = e;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) { carry_c = pc + ci; carry_b = pb + bi; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        span_first[n] = carry_c;
+        *span_count = carry_c < max_spans ? carry_c : max_spans;
+    }
+}
+
+// one workgroup per read: where its spans go in the destination slot, the trailers, the read's result
+__global__ __launch_bounds__(256) void zstd_span_finish_kernel(ReadBatch b, uint32_t hdr, const EncSpan* spans, const uint32_t* span_first,
+                                                               uint32_t max_spans, const uint32_t* span_size, const uint32_t* span_trail,
+                                                               uint32_t* span_dst, uint32_t index_enabled)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t bad_s;
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t s0 = span_first[r], s1 = span_first[r + 1];
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    if (s1 > max_spans || s0 >= s1) {
+        if (tid == 0) b.result[r] = E_OOM;
+        return;
+    }
+    if (spans[s0].flags & SPAN_SKIP) {
+        if (tid == 0) {
+            const uint32_t N = b.src_size[r];
+            b.result[r] = (b.gate && b.gate[r] >= E_FIRST) ? b.gate[r] : (N >= E_FIRST ? N : E_OOM);
+        }
+        return;
+    }
+    uint64_t carry = 0;
+    for (uint32_t base = s0; base < s1; base += 256) {
+        const uint32_t i = base + (uint32_t)tid;
+        uint32_t v = i < s1 ? span_size[i] : 0u;
+        if (v >= E_FIRST) { atomicOr(&bad_s, 1u); v = 0; }
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan_u32(v, wsum, tot);
+        if (i < s1) span_dst[i] = (uint32_t)(carry + ex);
+        carry += tot;
+    }
+    __syncthreads();
+    const uint32_t cap = b.dst_cap[r];
+    if (bad_s || carry > cap) {
+        if (tid == 0) b.result[r] = E_ZSTD;
+        // the compaction pass must not copy anything of this read
+        for (uint32_t i = s0 + tid; i < s1; i += 256) span_dst[i] = 0xFFFFFFFFu;
+        return;
+    }
+    uint32_t total = (uint32_t)carry;
+    uint8_t* out = b.dst + b.dst_off[r];
+    const uint32_t nsp = s1 - s0;
+    const uint32_t cp = span_trail[s0];           // the checkpoint trailer of the first span, moved by the compaction pass
+    if ((uint64_t)total + cp <= cap) total += cp;
+    else if (tid == 0) span_dst[s0] |= 0x80000000u;  // ... which drops it when this bit is set
+    const uint32_t ib = 8u + 4u + 8u * nsp + 4u;
+    if (index_enabled && nsp > 1 && (uint64_t)total + ib <= cap) {
+        uint8_t* tp = out + total;
+        if (tid == 0) {
+            put_le(tp, IDX_MAGIC, 4);
+            put_le(tp + 4, ib - 8u, 4);
+            put_le(tp + 8, nsp, 4);
+            put_le(tp + 12 + 8 * nsp, ib, 4);
+        }
+        __syncthreads();  // span_dst of every span is written
+        const uint32_t fhl = 5u + (b.src_size[r] < 256 ? 1u : (b.src_size[r] < 65536 + 256 ? 2u : 4u));  // frame header length
+        for (uint32_t j = tid; j < nsp; j += 256) {
+            const uint32_t fo = j == 0 ? fhl : (span_dst[s0 + j] & 0x7FFFFFFFu) - hdr;  // first block of the span, from the frame's magic
+            put_le(tp + 12 + 8 * j, fo, 4);
+            put_le(tp + 16 + 8 * j, spans[s0 + j].r0, 4);
+        }
+        total += ib;
+    }
+    if (tid == 0) b.result[r] = total;
+}
+
+// one workgroup per span: move it from its temporary slot to its place in the frame
+__global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, const EncSpan* spans, const uint32_t* span_count, const uint8_t* span_tmp,
+                                                                const uint32_t* span_size, const uint32_t* span_trail, const uint32_t* span_dst,
+                                                                const uint32_t* span_first)
+{
+    if (blockIdx.x >= *span_count) return;
+    const EncSpan sp = spans[blockIdx.x];
+    if (sp.flags & SPAN_SKIP) return;
+    const uint32_t d = span_dst[blockIdx.x];
+    if (d == 0xFFFFFFFFu) return;
+    const uint32_t size = span_size[blockIdx.x];
+    const uint8_t* s = span_tmp + sp.tmp_off;
+    uint8_t* o = b.dst + b.dst_off[sp.read] + (d & 0x7FFFFFFFu);
+    for (uint32_t i = threadIdx.x; i < size; i += 256) o[i] = s[i];
+    if ((sp.flags & SPAN_FIRST) && !(d & 0x80000000u)) {
+        // the checkpoint trailer goes behind the last span
+        const uint32_t last = span_first[sp.read + 1] - 1;
+        const uint32_t end = (span_dst[last] & 0x7FFFFFFFu) + span_size[last];
+        const uint32_t tb = span_trail[blockIdx.x];
+        uint8_t* t = b.dst + b.dst_off[sp.read] + end;
+        for (uint32_t i = threadIdx.x; i < tb; i += 256) t[i] = s[size + i];
+    }
 }
 
 }  // namespace
@@ -1021,10 +1284,42 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
     if (b.n_reads == 0) return hipSuccess;
     if (dbg)
         hipLaunchKernelGGL(zstd_encode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables));
+                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL(zstd_encode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables));
+                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+// ---- span mode (few, large reads) ------------------------------------------------------------------------------------------
+size_t zstd_span_desc_bytes() { return sizeof(EncSpan); }
+
+uint32_t zstd_span_max_spans(uint64_t stream_bytes, uint32_t n_reads)
+{
+    const uint64_t v = stream_bytes / SPAN_BYTES + 3ull * n_reads + 1;
+    return v > 0x7FFFFFF0ull ? 0u : (uint32_t)v;
+}
+
+uint64_t zstd_span_tmp_bytes(uint64_t stream_bytes, uint32_t n_reads, uint32_t max_spans)
+{
+    return stream_bytes + (stream_bytes >> 7) + (uint64_t)max_spans * 2048u + (uint64_t)n_reads * ((8ull * (BLOCK_MAX / RMIN + 2)) + 1024u) + 4096u;
+}
+
+hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
+                                    const void* seq_tables, void* span_desc, uint32_t* span_first, uint32_t* span_count, uint32_t max_spans,
+                                    uint8_t* span_tmp, uint64_t span_tmp_bytes, uint32_t* span_size, uint32_t* span_trail, uint32_t* span_dst,
+                                    bool index_trailer, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    EncSpan* spans = reinterpret_cast<EncSpan*>(span_desc);
+    hipLaunchKernelGGL(zstd_span_plan_kernel, dim3(1), dim3(1024), 0, s, b.n_reads, b.src_size, orig_size, key_elem, b.gate,
+                       (src_cap && seq_tables) ? 1u : 0u, max_spans, span_tmp_bytes, spans, span_first, span_count);
+    hipLaunchKernelGGL(zstd_encode_kernel<false>, dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
+                       reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail);
+    hipLaunchKernelGGL(zstd_span_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, hdr, spans, span_first, max_spans, span_size, span_trail,
+                       span_dst, index_trailer ? 1u : 0u);
+    hipLaunchKernelGGL(zstd_span_compact_kernel, dim3(max_spans), dim3(256), 0, s, b, spans, span_count, span_tmp, span_size, span_trail, span_dst,
+                       span_first);
     return hipGetLastError();
 }
 
