@@ -292,7 +292,7 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
 // A segment is SEG_TILES tiles of values.  seg_first[r] (exclusive scan of the reads' segment counts, seg_first[n_reads] =
 // total) maps a workgroup to its (read, segment).  Pass 1 counts the data bytes of every segment, a scan turns the
 // counts into data offsets (and gives the read's result), pass 2 encodes every segment at its offset.
-constexpr int SEG_TILES = 16;
+constexpr int SEG_TILES = 8;
 
 __device__ __forceinline__ bool seg_locate(const uint32_t* seg_first, uint32_t n_reads, uint32_t g, uint32_t& r, uint32_t& k)
 {

@@ -1586,7 +1586,7 @@ struct DecSpan
 };
 constexpr uint32_t DSPAN_WHOLE = 1, DSPAN_LAST = 2, DSPAN_FIRST = 4;
 constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;      // zstd_encode.hip: the span index trailer
-constexpr uint32_t DSPAN_MIN_CONTENT = 128u << 10;  // an honest index has at most fcs / this + 4 spans
+constexpr uint32_t DSPAN_MIN_CONTENT = 32u << 10;   // an honest index has at most fcs / this + 4 spans (spans are 64 KB or more, cut evenly)
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
 template <bool TIMED>
@@ -2413,27 +2413,28 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
 }
 
 // ---- span mode: plan and finish ----------------------------------------------------------------------------------------
-// One thread per read: frame header and index trailer -> the read's spans (or one WHOLE span when there is no usable index).
+// Frame header and index trailer of every read -> its spans (or one WHOLE span when there is no usable index).
 __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint32_t max_spans, DecSpan* spans, uint32_t* dspan_first,
                                                                uint32_t* dspan_count, uint32_t* dspan_status)
 {
     __shared__ uint32_t wcnt[16];
     __shared__ uint32_t carry_c;
+    __shared__ uint32_t q_ns[1024], q_tb[1024], q_ok[1024], q_first[1024], q_hl[1024], q_fcs[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) carry_c = 0;
     __syncthreads();
     for (uint32_t base = 0; base < b.n_reads; base += 1024) {
         const uint32_t i = base + tid;
-        uint32_t cnt = 0, hl = 0;
-        const uint8_t* idx = nullptr;  // the index entries, if usable
+        const uint32_t here = (b.n_reads - base) < 1024u ? (b.n_reads - base) : 1024u;
+        // (1) one thread per read: frame header (single segment, no dictionary, no checksum: what zstd_encode.hip writes)
+        // and the envelope of the index trailer
+        q_ok[tid] = 0;
         if (i < b.n_reads) {
-            cnt = 1;
             const uint32_t n = b.src_size[i];
             const bool gated = (b.gate && b.gate[i] >= E_FIRST) || n >= E_FIRST;
             if (!gated && n >= 64) {
                 const uint8_t* src = b.src + b.src_off[i];
-                // frame header: single segment, no dictionary, no checksum (what zstd_encode.hip writes)
-                uint32_t magic;
+                uint32_t magic, hl = 0;
                 __builtin_memcpy(&magic, src, 4);
                 const uint32_t fhd = src[4];
                 const int fcs_flag = fhd >> 6;
@@ -2457,60 +2458,74 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                     ns = m[2];
                     ok = m[0] == IDX_MAGIC && m[1] == tb - 8 && ns >= 2 && tb == 16 + 8 * ns && ns <= fcs / DSPAN_MIN_CONTENT + 4;
                 }
-                if (ok) {
-                    // entries: strictly increasing in the frame and in the content, inside the frame, the first at the first block
-                    const uint8_t* e = src + n - tb + 12;
-                    uint32_t pf = 0, pc = 0;
-                    for (uint32_t j = 0; j < ns && ok; ++j) {
-                        uint32_t v[2];
-                        __builtin_memcpy(v, e + 8 * j, 8);
-                        if (j == 0) ok = v[0] == hl && v[1] == 0;
-                        else ok = v[0] > pf && v[1] > pc;
-                        ok = ok && (uint64_t)v[0] + 3 <= n - tb && v[1] < fcs;
-                        pf = v[0];
-                        pc = v[1];
-                    }
-                    if (ok) {
-                        cnt = ns;
-                        idx = e;
-                    }
-                }
+                q_ok[tid] = ok ? 1u : 0u;
+                q_ns[tid] = ns;
+                q_tb[tid] = tb;
+                q_hl[tid] = hl;
+                q_fcs[tid] = (uint32_t)fcs;
             }
         }
+        __syncthreads();
+        // (2) all threads: the entries of each index are strictly increasing in the frame and in the content, lie inside
+        // the frame, and the first one is the first block
+        for (uint32_t q = 0; q < here; ++q) {
+            if (!q_ok[q]) continue;
+            const uint32_t n = b.src_size[base + q], tb = q_tb[q], ns = q_ns[q];
+            const uint8_t* e = b.src + b.src_off[base + q] + n - tb + 12;
+            bool bad = false;
+            for (uint32_t j = tid; j < ns; j += 1024) {
+                uint32_t v[2], pv[2] = { 0, 0 };
+                __builtin_memcpy(v, e + 8 * j, 8);
+                if (j) __builtin_memcpy(pv, e + 8 * (j - 1), 8);
+                bool ok = j == 0 ? (v[0] == q_hl[q] && v[1] == 0) : (v[0] > pv[0] && v[1] > pv[1]);
+                ok = ok && (uint64_t)v[0] + 3 <= n - tb && v[1] < q_fcs[q];
+                bad |= !ok;
+            }
+            if (bad) q_ok[q] = 0;  // (racing stores of the same value)
+        }
+        __syncthreads();
+        // (3) span counts -> first span of every read
+        const uint32_t cnt = i < b.n_reads ? (q_ok[tid] ? q_ns[tid] : 1u) : 0u;
         const uint32_t ci = wave_incl_scan_u32(cnt);
         if (lane == 63) wcnt[w] = ci;
         __syncthreads();
         uint32_t pc = carry_c;
         for (int k = 0; k < w; ++k) pc += wcnt[k];
         if (i < b.n_reads) {
-            uint32_t si = pc + ci - cnt;
-            if (si + cnt > max_spans) {  // cannot happen with the host's bound: fall back to one span per read
-                idx = nullptr;
-                if (cnt > 1) cnt = 1;    // (later reads shift; their own check repeats)
-            }
+            const uint32_t si = pc + ci - cnt;
             dspan_first[i] = si;
-            if (si + cnt <= max_spans) {
-                if (!idx) {
+            q_first[tid] = si;
+            if (si + cnt > max_spans) q_ok[tid] = 2;  // cannot happen with the host's bound: the read is left to the second launch
+        }
+        __syncthreads();
+        // (4) all threads: the descriptors
+        for (uint32_t q = 0; q < here; ++q) {
+            const uint32_t si = q_first[q];
+            if (q_ok[q] == 2) continue;
+            if (!q_ok[q]) {
+                if (tid == 0 && si < max_spans) {
                     DecSpan d = {};
-                    d.read = i;
+                    d.read = base + q;
                     d.flags = DSPAN_WHOLE | DSPAN_FIRST | DSPAN_LAST;
                     spans[si] = d;
                     dspan_status[3 * si] = 0;
-                } else {
-                    for (uint32_t j = 0; j < cnt; ++j) {
-                        uint32_t v[2], nx[2] = { 0, 0 };
-                        __builtin_memcpy(v, idx + 8 * j, 8);
-                        if (j + 1 < cnt) __builtin_memcpy(nx, idx + 8 * (j + 1), 8);
-                        DecSpan d;
-                        d.read = i;
-                        d.src_pos = v[0];
-                        d.src_end = nx[0];
-                        d.dst_pos = v[1];
-                        d.flags = (j == 0 ? DSPAN_FIRST : 0u) | (j + 1 == cnt ? DSPAN_LAST : 0u);
-                        spans[si + j] = d;
-                        dspan_status[3 * (si + j)] = 0;
-                    }
                 }
+                continue;
+            }
+            const uint32_t n = b.src_size[base + q], tb = q_tb[q], ns = q_ns[q];
+            const uint8_t* e = b.src + b.src_off[base + q] + n - tb + 12;
+            for (uint32_t j = tid; j < ns; j += 1024) {
+                uint32_t v[2], nx[2] = { 0, 0 };
+                __builtin_memcpy(v, e + 8 * j, 8);
+                if (j + 1 < ns) __builtin_memcpy(nx, e + 8 * (j + 1), 8);
+                DecSpan d;
+                d.read = base + q;
+                d.src_pos = v[0];
+                d.src_end = nx[0];
+                d.dst_pos = v[1];
+                d.flags = (j == 0 ? DSPAN_FIRST : 0u) | (j + 1 == ns ? DSPAN_LAST : 0u);
+                spans[si + j] = d;
+                dspan_status[3 * (si + j)] = 0;
             }
         }
         __syncthreads();
@@ -2523,24 +2538,36 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
     }
 }
 
-// one thread per read: did the spans work out?  redo[r] = 1 sends the frame to the ordinary one-wavefront decoder.
-__global__ void zstd_dspan_finish_kernel(ReadBatch b, const DecSpan* spans, const uint32_t* dspan_first, const uint32_t* dspan_status, uint32_t* redo)
+// one workgroup per read: did the spans work out?  redo[r] = 1 sends the frame to the ordinary one-wavefront decoder.
+__global__ __launch_bounds__(256) void zstd_dspan_finish_kernel(ReadBatch b, const DecSpan* spans, const uint32_t* dspan_first, uint32_t max_spans,
+                                                                const uint32_t* dspan_status, uint32_t* redo)
 {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= b.n_reads) return;
+    __shared__ uint32_t bad_s;
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
     const uint32_t s0 = dspan_first[r], s1 = dspan_first[r + 1];
-    uint32_t again = 0;
-    if (s1 <= s0) again = 1;
-    else if (!(spans[s0].flags & DSPAN_WHOLE)) {
-        bool ok = true;
-        for (uint32_t k = s0; k < s1 && ok; ++k) {
-            ok = dspan_status[3 * k] == 1;
-            if (ok && k + 1 < s1) ok = dspan_status[3 * k + 1] == spans[k + 1].src_pos && dspan_status[3 * k + 2] == spans[k + 1].dst_pos;
-        }
-        if (ok) b.result[r] = dspan_status[3 * (s1 - 1) + 2];  // == the frame content size (checked by the last span)
-        else again = 1;
+    if (tid == 0) bad_s = 0;
+    __syncthreads();
+    if (s1 <= s0 || s1 > max_spans) {
+        if (tid == 0) redo[r] = 1;
+        return;
     }
-    redo[r] = again;
+    if (spans[s0].flags & DSPAN_WHOLE) {  // the ordinary decoder has already given its verdict
+        if (tid == 0) redo[r] = 0;
+        return;
+    }
+    bool bad = false;
+    for (uint32_t k = s0 + tid; k < s1; k += 256) {
+        bool ok = dspan_status[3 * k] == 1;
+        if (ok && k + 1 < s1) ok = dspan_status[3 * k + 1] == spans[k + 1].src_pos && dspan_status[3 * k + 2] == spans[k + 1].dst_pos;
+        bad |= !ok;
+    }
+    if (bad) bad_s = 1;
+    __syncthreads();
+    if (tid == 0) {
+        if (!bad_s) b.result[r] = dspan_status[3 * (s1 - 1) + 2];  // == the frame content size (checked by the last span)
+        redo[r] = bad_s;
+    }
 }
 
 }  // namespace
@@ -2576,7 +2603,7 @@ hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, 
     hipLaunchKernelGGL(zstd_dspan_plan_kernel, dim3(1), dim3(1024), 0, s, b, max_spans, spans, dspan_first, dspan_count, dspan_status);
     hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(max_spans), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, spans, dspan_count, dspan_status,
                        nullptr);
-    hipLaunchKernelGGL(zstd_dspan_finish_kernel, dim3((b.n_reads + 255) / 256), dim3(256), 0, s, b, spans, dspan_first, dspan_status, redo);
+    hipLaunchKernelGGL(zstd_dspan_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, spans, dspan_first, max_spans, dspan_status, redo);
     hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, nullptr, nullptr, nullptr, redo);
     return hipGetLastError();
 }

@@ -44,8 +44,11 @@ constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams
 // temporary slot; a compaction pass then strings the spans of a frame together.  16 KB blocks keep the decoder's streams
 // short (4 KB of content per lane) at 0.1 % of header overhead.
 constexpr uint32_t SPAN_BLOCK = 16u << 10;
-constexpr uint32_t SPAN_BLOCKS = MAXBLK;
-constexpr uint32_t SPAN_BYTES = SPAN_BLOCK * SPAN_BLOCKS;
+// blocks per span: 4 (64 KB of stream per wavefront: a 40 MB buffer is 300 spans, one 400 k-sample read 8) up to 256 MB of
+// stream, 16 beyond (the decoder then has all 64 lanes of a wavefront busy).  A span costs its tree description, ~0.15 %.
+constexpr uint32_t SPAN_BYTES_SMALL = SPAN_BLOCK * 4, SPAN_BYTES_LARGE = SPAN_BLOCK * MAXBLK;
+constexpr uint32_t SPAN_LARGE_FROM = 256u << 20;
+__host__ __device__ constexpr uint32_t span_bytes_for(uint32_t N) { return N >= SPAN_LARGE_FROM ? SPAN_BYTES_LARGE : SPAN_BYTES_SMALL; }
 #ifndef VBZ_STEP_LANE
 #define VBZ_STEP_LANE 16
 #endif
@@ -1060,7 +1063,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 
 // ---- span mode: plan, finish, compaction --------------------------------------------------------------------------------
 // Span mode serves batches of few, large reads (a 10 M-element buffer, one 400 k-sample read): the svb stream of a read is cut
-// into spans of at most SPAN_BYTES (the control-byte region and the data-byte region separately; a control-byte region of up
+// into spans of at most span_bytes_for(N) (the control-byte region and the data-byte region separately; a control-byte region of up
 // to 128 KB stays ONE span so that its zero runs can become sequences), one wavefront codes one span into a temporary slot,
 // then the spans are strung together behind the frame header.  Behind the frame (and behind the checkpoint trailer, if
 // any) goes an INDEX of the spans in a second skippable frame -- where each span's first block starts in the frame and in
@@ -1078,9 +1081,10 @@ __device__ __forceinline__ uint32_t span_tmp_bytes(uint32_t S, bool keyseq)
 // per read: how its stream is cut.  keyN = spans of the control-byte region, dataN = of the rest.
 __device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN, uint32_t& dataN)
 {
-    keyN = K == 0 ? 0u : (K <= BLOCK_MAX ? 1u : (K + SPAN_BYTES - 1) / SPAN_BYTES);
+    const uint32_t SB = span_bytes_for(N);
+    keyN = K == 0 ? 0u : (K <= BLOCK_MAX ? 1u : (K + SB - 1) / SB);
     const uint32_t D = N - K;
-    dataN = D ? (D + SPAN_BYTES - 1) / SPAN_BYTES : 0u;
+    dataN = D ? (D + SB - 1) / SB : 0u;
     if (N == 0) dataN = 1;  // the empty frame
 }
 
@@ -1092,6 +1096,9 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
     __shared__ uint32_t wcnt[16];
     __shared__ uint64_t carry_b;
     __shared__ uint32_t carry_c;
+    // the plan of the reads of one round (1024 reads), read back by all threads when the span descriptors are written
+    __shared__ uint32_t q_N[1024], q_K[1024], q_keyN[1024], q_dataN[1024], q_first[1024];
+    __shared__ uint64_t q_off[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) { carry_b = 0; carry_c = 0; }
     __syncthreads();
@@ -1112,15 +1119,9 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                 }
                 span_cut(N, K, keyN, dataN);
                 cnt = keyN + dataN;
-                for (uint32_t j = 0; j < keyN; ++j) {
-                    const uint32_t a = (uint32_t)((uint64_t)K * j / keyN), e = (uint32_t)((uint64_t)K * (j + 1) / keyN);
-                    bytes += span_tmp_bytes(e - a, keyN == 1 && seq_enabled);
-                }
-                const uint32_t D = N - K;
-                for (uint32_t j = 0; j < dataN; ++j) {
-                    const uint32_t a = (uint32_t)((uint64_t)D * j / dataN), e = (uint32_t)((uint64_t)D * (j + 1) / dataN);
-                    bytes += span_tmp_bytes(e - a, false);
-                }
+                // every span of a region gets the slot of the region's largest span
+                if (keyN) bytes += (uint64_t)keyN * span_tmp_bytes((K + keyN - 1) / keyN, keyN == 1 && seq_enabled);
+                if (dataN) bytes += (uint64_t)dataN * span_tmp_bytes((N - K + dataN - 1) / dataN, false);
             }
         }
         uint32_t ci = cnt;
@@ -1137,40 +1138,54 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
         uint64_t pb = carry_b;
         for (int k = 0; k < w; ++k) { pc += wcnt[k]; pb += wsum[k]; }
         if (i < n) {
-            uint32_t si = pc + ci - cnt;
-            uint64_t off = pb + bi - bytes;
+            const uint32_t si = pc + ci - cnt;
+            const uint64_t off = pb + bi - bytes;
             span_first[i] = si;
             // a plan that does not fit the arrays it was given (cannot happen with the host's bounds) skips the read
             const bool fits = si + cnt <= max_spans && off + bytes <= tmp_limit;
-            if (skip || !fits) {
-                if (si < max_spans) {
+            q_first[tid] = si;
+            q_off[tid] = off;
+            q_N[tid] = N;
+            q_K[tid] = K;
+            q_keyN[tid] = (skip || !fits) ? 0xFFFFFFFFu : keyN;   // marks a skipped read
+            q_dataN[tid] = (skip || !fits) ? cnt : dataN;
+        }
+        __syncthreads();
+        const uint32_t here = (n - base) < 1024u ? (n - base) : 1024u;
+        for (uint32_t q = 0; q < here; ++q) {  // all threads write the spans of read base + q
+            const uint32_t si = q_first[q];
+            if (q_keyN[q] == 0xFFFFFFFFu) {
+                for (uint32_t j = tid; j < q_dataN[q] && si + j < max_spans; j += 1024) {
                     EncSpan e = {};
-                    e.read = i;
-                    e.flags = SPAN_SKIP | SPAN_FIRST | SPAN_LAST;
-                    spans[si] = e;
-                    for (uint32_t j = 1; j < cnt && si + j < max_spans; ++j) { e.flags = SPAN_SKIP; spans[si + j] = e; }
-                }
-            } else {
-                const uint32_t D = N - K;
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    EncSpan e = {};
-                    e.read = i;
-                    bool keyseq = false;
-                    if (j < keyN) {
-                        e.r0 = (uint32_t)((uint64_t)K * j / keyN);
-                        e.r1 = (uint32_t)((uint64_t)K * (j + 1) / keyN);
-                        keyseq = keyN == 1 && seq_enabled;
-                    } else {
-                        const uint32_t q = j - keyN;
-                        e.r0 = K + (uint32_t)((uint64_t)D * q / dataN);
-                        e.r1 = K + (uint32_t)((uint64_t)D * (q + 1) / dataN);
-                    }
-                    e.flags = (j == 0 ? SPAN_FIRST : 0u) | (j + 1 == cnt ? SPAN_LAST : 0u) | (keyseq ? SPAN_KEYSEQ : 0u);
-                    e.tmp_off = off;
-                    e.tmp_cap = span_tmp_bytes(e.r1 - e.r0, keyseq);
-                    off += e.tmp_cap;
+                    e.read = base + q;
+                    e.flags = SPAN_SKIP | (j == 0 ? (SPAN_FIRST | SPAN_LAST) : 0u);
                     spans[si + j] = e;
                 }
+                continue;
+            }
+            const uint32_t qN = q_N[q], qK = q_K[q], kN = q_keyN[q], dN = q_dataN[q], D = qN - qK, cntq = kN + dN;
+            const bool keyseq1 = kN == 1 && seq_enabled;
+            const uint32_t slotK = kN ? span_tmp_bytes((qK + kN - 1) / kN, keyseq1) : 0u;
+            const uint32_t slotD = dN ? span_tmp_bytes((D + dN - 1) / dN, false) : 0u;
+            for (uint32_t j = tid; j < cntq; j += 1024) {
+                EncSpan e = {};
+                e.read = base + q;
+                bool keyseq = false;
+                if (j < kN) {
+                    e.r0 = (uint32_t)((uint64_t)qK * j / kN);
+                    e.r1 = (uint32_t)((uint64_t)qK * (j + 1) / kN);
+                    keyseq = keyseq1;
+                    e.tmp_off = q_off[q] + (uint64_t)j * slotK;
+                    e.tmp_cap = slotK;
+                } else {
+                    const uint32_t t = j - kN;
+                    e.r0 = qK + (uint32_t)((uint64_t)D * t / dN);
+                    e.r1 = qK + (uint32_t)((uint64_t)D * (t + 1) / dN);
+                    e.tmp_off = q_off[q] + (uint64_t)kN * slotK + (uint64_t)t * slotD;
+                    e.tmp_cap = slotD;
+                }
+                e.flags = (j == 0 ? SPAN_FIRST : 0u) | (j + 1 == cntq ? SPAN_LAST : 0u) | (keyseq ? SPAN_KEYSEQ : 0u);
+                spans[si + j] = e;
             }
         }
         __syncthreads();
@@ -1264,7 +1279,13 @@ __global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, con
     const uint32_t size = span_size[blockIdx.x];
     const uint8_t* s = span_tmp + sp.tmp_off;
     uint8_t* o = b.dst + b.dst_off[sp.read] + (d & 0x7FFFFFFFu);
-    for (uint32_t i = threadIdx.x; i < size; i += 256) o[i] = s[i];
+    const uint32_t nv = size >> 4;  // 16 bytes per lane and trip (the slot is 16-byte aligned, the destination need not be)
+    for (uint32_t i = threadIdx.x; i < nv; i += 256) {
+        uint4 v;
+        __builtin_memcpy(&v, s + 16ull * i, 16);
+        __builtin_memcpy(o + 16ull * i, &v, 16);
+    }
+    for (uint32_t i = (nv << 4) + threadIdx.x; i < size; i += 256) o[i] = s[i];
     if ((sp.flags & SPAN_FIRST) && !(d & 0x80000000u)) {
         // the checkpoint trailer goes behind the last span
         const uint32_t last = span_first[sp.read + 1] - 1;
@@ -1296,7 +1317,7 @@ size_t zstd_span_desc_bytes() { return sizeof(EncSpan); }
 
 uint32_t zstd_span_max_spans(uint64_t stream_bytes, uint32_t n_reads)
 {
-    const uint64_t v = stream_bytes / SPAN_BYTES + 3ull * n_reads + 1;
+    const uint64_t v = stream_bytes / SPAN_BYTES_SMALL + 3ull * n_reads + 1;
     return v > 0x7FFFFFF0ull ? 0u : (uint32_t)v;
 }
 
