@@ -71,7 +71,7 @@ def test_large_read_both_ways(name, a, o):
         mine = G.decompress([r, g], [a.nbytes, a.nbytes], go, sized=sized)
         assert not isinstance(mine[0], int) and mine[0].tobytes() == a.tobytes()    # libzstd's frame (no index: ordinary decoder)
         assert not isinstance(mine[1], int) and mine[1].tobytes() == a.tobytes()    # own frame, decoded in spans
-        assert len(g) <= len(r) * 1.03 + 200, (len(g), len(r))
+        assert len(r) < 2000 or len(g) <= len(r) * 1.03, (len(g), len(r))
         body, tr = _trailers(g[4:] if sized else g)
         if a.nbytes * 1.0 > (600 << 10) and a.any():
             assert tr and int(tr[0][:4].view("<u4")[0]) == IDX_MAGIC, "a frame of several spans carries the span index"

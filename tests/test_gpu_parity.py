@@ -885,21 +885,27 @@ def test_h5repack_through_filter_32020(tmp_path):
         pytest.skip("no libhdf5 >= 1.10.3 for the listing tool")
     sig = np.fromfile(str(tmp_path / "sig"), np.int16)
     chunks = np.fromfile(str(tmp_path / "chunks"), np.uint8)
-    assert chunks.tobytes() == np.fromfile(str(tmp_path / "bulk_chunks"), np.uint8).tobytes()
+    bulk_chunks = np.fromfile(str(tmp_path / "bulk_chunks"), np.uint8)
     assert [(r["name"], r["fnv1a64"]) for r in after] == [(r["name"], r["fnv1a64"]) for r in before]
-    assert [r["chunk_bytes"] for r in after] == [r["chunk_bytes"] for r in bulk]
     oo = O.options(True, 2, 1, 0)
-    spos = cpos = 0
-    for r in after:
+    spos = cpos = bpos = 0
+    for r, rb in zip(after, bulk):
         assert r["filters"] == [32020] and r["chunk_bytes"] == r["stored_bytes"] > 0
         want = sig[spos : spos + r["samples"]]
         chunk = chunks[cpos : cpos + r["chunk_bytes"]]
+        bchunk = bulk_chunks[bpos : bpos + rb["chunk_bytes"]]
         spos += r["samples"]
         cpos += r["chunk_bytes"]
-        back = O.decompress(chunk, want.nbytes, oo, sized=True)
-        assert not isinstance(back, int) and back.tobytes() == want.tobytes()
+        bpos += rb["chunk_bytes"]
         ref = O.compress(want, oo, sized=True)
-        assert abs(len(chunk) - len(ref)) <= 0.01 * len(ref) + 16, (r["name"], len(chunk), len(ref))
+        for ch in (chunk, bchunk):
+            back = O.decompress(ch, want.nbytes, oo, sized=True)
+            assert not isinstance(back, int) and back.tobytes() == want.tobytes()
+            assert abs(len(ch) - len(ref)) <= 0.01 * len(ref) + 16, (r["name"], len(ch), len(ref))
+        # one chunk per filter call: a read of half a megabyte or more takes the large-read path there (spans, smaller blocks),
+        # while the bulk tool's batch of ten takes the one-wavefront-per-read kernels; below that the two are the same bytes
+        if want.nbytes < (512 << 10):
+            assert chunk.tobytes() == bchunk.tobytes(), r["name"]
 
 
 @pytest.mark.gpu

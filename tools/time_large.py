@@ -30,6 +30,8 @@ def main():
     cases = [("config4: one 10M-element uint32 buffer, no zig-zag, level 3", 4, False, 3, 0, 10_000_000, "u32"),
              ("config1: one 400k-sample int16 read, zig-zag, level 1", 2, True, 1, 1, 400_000, "i16"),
              ("one 4M-sample int16 read", 2, True, 1, 1, 4_000_000, "i16")]
+    if len(sys.argv) > 1:
+        cases = [cases[int(k)] for k in sys.argv[1].split(",")]
     for name, size, zz, level, ver, count, kind in cases:
         opts = c.options(zz, size, level, ver)
         nbytes = count * size

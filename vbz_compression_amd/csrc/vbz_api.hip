@@ -470,12 +470,12 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
             set_error(c, "batch too large for the span path");
             return -1;
         }
-        if (!ensure(c, c->spanmeta, (size_t)max_spans * (zstd_dspan_desc_bytes() + 12) + ((size_t)n + 2) * 8 + 256)) return -1;
+        if (!ensure(c, c->spanmeta, (size_t)max_spans * (zstd_dspan_desc_bytes() + 16) + ((size_t)n + 2) * 8 + 256)) return -1;
         MetaCarver sm(c->spanmeta.p);
         uint8_t* desc = sm.take<uint8_t>((size_t)max_spans * zstd_dspan_desc_bytes());
         uint32_t* dspan_first = sm.take<uint32_t>((size_t)n + 1);
         uint32_t* dspan_count = sm.take<uint32_t>(1);
-        uint32_t* dspan_status = sm.take<uint32_t>((size_t)max_spans * 3);
+        uint32_t* dspan_status = sm.take<uint32_t>((size_t)max_spans * 4);
         uint32_t* redo = sm.take<uint32_t>(n);
         Timed t(c, "zstd_decode");
         HIPCHK(c, launch_zstd_decode_spans(z, E_STREAM, c->seqdtab.p, desc, dspan_first, dspan_count, max_spans, dspan_status, redo, s),

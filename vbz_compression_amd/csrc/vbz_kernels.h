@@ -84,7 +84,7 @@ void seq_dtables_build(void* host_buffer);
 // The same for batches of few, large reads: frames that carry the encoder's span index are decoded one span per wavefront
 // (verified; anything else, and every error verdict, comes from the ordinary decoder in a second launch gated by redo[]).
 // content_bytes bounds the total frame content.  dspan_desc: max_spans x zstd_dspan_desc_bytes(); dspan_first[n_reads + 1];
-// dspan_count[1]; dspan_status[3 * max_spans]; redo[n_reads].
+// dspan_count[1]; dspan_status[4 * max_spans]; redo[n_reads].
 size_t zstd_dspan_desc_bytes();
 uint32_t zstd_dspan_max_spans(uint64_t content_bytes, uint32_t n_reads);  // 0: too large
 hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* dspan_desc, uint32_t* dspan_first,

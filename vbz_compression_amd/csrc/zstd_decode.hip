@@ -1574,8 +1574,10 @@ __device__ __forceinline__ void stage_bytes(uint8_t* lds, const uint8_t* g, uint
 // Span mode (batches of few, large reads): one wavefront decodes one SPAN of a frame -- a run of blocks that begins with a
 // block carrying its own Huffman tree -- as announced by the index trailer zstd_encode.hip writes behind large frames.
 // The index is verified, never trusted: a span must end exactly where the next one begins (in the frame and in the
-// content), spans other than the first may not contain sequences or lean on an earlier Huffman table; if anything is
-// off, the frame is decoded again by one wavefront the ordinary way, which is also what decides every error verdict.
+// content), spans other than the first may not lean on an earlier Huffman table and may contain sequences only of the
+// zero-run kind (offset = repeat offset 1 = 1 throughout, which every span confirms for itself; such a match never reads
+// a byte outside its own block); if anything is off, the frame is decoded again by one wavefront the ordinary way, which
+// is also what decides every error verdict.
 struct DecSpan
 {
     uint32_t read;
@@ -1583,10 +1585,14 @@ struct DecSpan
     uint32_t src_end;   // where the span must end (the next span's first block); unused for the last span
     uint32_t dst_pos;   // content offset of the span's first byte
     uint32_t flags;     // DSPAN_*
+    uint32_t ord;       // ordinal of the span in its frame
 };
 constexpr uint32_t DSPAN_WHOLE = 1, DSPAN_LAST = 2, DSPAN_FIRST = 4;
 constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;      // zstd_encode.hip: the span index trailer
-constexpr uint32_t DSPAN_MIN_CONTENT = 32u << 10;   // an honest index has at most fcs / this + 4 spans (spans are 64 KB or more, cut evenly)
+constexpr uint32_t DSPAN_MIN_CONTENT = 8u << 10;    // an honest index has at most fcs / this + 4 spans (spans are cut evenly, none below 16 KB)
+// A span whose block carries zero-run sequences stages its literals and (literal, match) length pairs behind the frame's
+// content in the destination slot, in a stripe of its own:
+constexpr uint32_t DSPAN_WS_STRIDE = 64u << 10;
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
 template <bool TIMED>
@@ -1636,7 +1642,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
 #define FAIL()                                                          \
     do {                                                                \
         if (lane == 0) {                                                \
-            if (partial) dspan_status[3 * blockIdx.x] = 2;              \
+            if (partial) dspan_status[4 * blockIdx.x] = 2;              \
             else b.result[r] = E_ZSTD;                                  \
         }                                                               \
         return;                                                         \
@@ -1718,6 +1724,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const uint32_t first_block = partial ? sp.src_pos : pos;
     const uint32_t first_opos = partial ? sp.dst_pos : 0u;
     uint32_t opos = 0, ntask = 0;
+    uint32_t rep0_end = 1;  // repeat offset 1 when the span is done (lane 0)
     for (int attempt = 0;; ++attempt) {
     if (partial && attempt != 0) FAIL();  // a frame that needs the careful second attempt is not decoded in spans
     // attempt 0 lets the stream decoders' rings reuse the LDS of FSE tables that are (normally) dead; if a later
@@ -1742,7 +1749,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     // byte i): by the time the block is done they have arrived
     uint32_t pf_byte = 0;
     bool pf_ok = false;
-    bool cp_avail = cp_count != 0;
+    bool cp_avail = cp_count != 0 && (!partial || (sp.flags & DSPAN_FIRST));  // the trailer describes the frame's first sequences section
 
     for (;;) {
         if (pos + 3 > n) FAIL();
@@ -1870,7 +1877,6 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             uint32_t nseq = SQB(0), sq_used = 1;
             const bool has_seq = nseq != 0;
             if (!has_seq && sqn != 1) FAIL();
-            if (has_seq && partial && !(sp.flags & DSPAN_FIRST)) FAIL();  // matches and repeat offsets reach across spans
             if ((uint64_t)opos + regen > fcs) FAIL();
             // ---- literals: where do they go?
             //   no sequences : straight to the output (Huffman streams become pending tasks)
@@ -1892,10 +1898,11 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         const uint32_t modes = SQB(used0);
                         const uint32_t llm = modes >> 6, ofm = (modes >> 4) & 3;
                         const uint32_t ofsym_at = used0 + 1 + (llm == 1 ? 1u : 0u);
-                        ws_lit = (fcs + 15u) & ~15u;
+                        ws_lit = ((fcs + 15u) & ~15u) + (partial ? sp.ord * DSPAN_WS_STRIDE : 0u);
                         ws_pairs = ws_lit + (ltype >= 2 ? ((regen + 7u) & ~7u) : 0u);
                         go = (ofm == 1 && llm != 2 && ofsym_at < sqn && SQB(ofsym_at) == 0 && rep0 == 1 &&
-                              (uint64_t)ws_pairs + 8ull * ns0 + 8 <= cap) ? 1u : 0u;
+                              (uint64_t)ws_pairs + 8ull * ns0 + 8 <= cap &&
+                              (!partial || (uint64_t)ws_pairs + 8ull * ns0 + 8 <= (uint64_t)ws_lit + DSPAN_WS_STRIDE)) ? 1u : 0u;
                         // predefined LL and ML tables (what zstd_encode.hip writes): nothing to build
                         if (go && modes == 0x10u && dtabs != nullptr) go = 2u | (used0 << 2) | (ns0 << 4);
                     }
@@ -1911,6 +1918,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             // Other blocks with sequences (libzstd's frames): if the slot has room behind the frame for the literals and
             // one 16-byte record per sequence, the sequences are decoded first and executed in parallel (see below);
             // otherwise they run one by one with the literals staged right-aligned at the end of the output.
+            // general sequences reach across spans (matches, repeat offsets): only the first span may have them
+            if (has_seq && !defer && partial && !(sp.flags & DSPAN_FIRST)) FAIL();
             bool par = false;
             uint32_t ws_plit = 0, ws_seq = 0;
             if (has_seq && !defer) {
@@ -2370,14 +2379,16 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         FLUSH();
     }
     PHASE(1);
+    rep0_end = rep0;
     break;
     }
     if (partial && !(sp.flags & DSPAN_LAST)) {
         // the span ended where the next one starts: report where the content stands
         if (lane == 0) {
-            dspan_status[3 * blockIdx.x + 1] = pos;
-            dspan_status[3 * blockIdx.x + 2] = opos;
-            dspan_status[3 * blockIdx.x] = 1;
+            dspan_status[4 * blockIdx.x + 1] = pos;
+            dspan_status[4 * blockIdx.x + 2] = opos;
+            dspan_status[4 * blockIdx.x + 3] = rep0_end;
+            dspan_status[4 * blockIdx.x] = 1;
         }
         return;
     }
@@ -2397,9 +2408,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     if (opos != fcs) FAIL();
     if (partial) {
         if (lane == 0) {
-            dspan_status[3 * blockIdx.x + 1] = pos;
-            dspan_status[3 * blockIdx.x + 2] = opos;
-            dspan_status[3 * blockIdx.x] = 1;
+            dspan_status[4 * blockIdx.x + 1] = pos;
+            dspan_status[4 * blockIdx.x + 2] = opos;
+            dspan_status[4 * blockIdx.x + 3] = rep0_end;
+            dspan_status[4 * blockIdx.x] = 1;
         }
         return;
     }
@@ -2508,7 +2520,7 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                     d.read = base + q;
                     d.flags = DSPAN_WHOLE | DSPAN_FIRST | DSPAN_LAST;
                     spans[si] = d;
-                    dspan_status[3 * si] = 0;
+                    dspan_status[4 * si] = 0;
                 }
                 continue;
             }
@@ -2524,8 +2536,9 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                 d.src_end = nx[0];
                 d.dst_pos = v[1];
                 d.flags = (j == 0 ? DSPAN_FIRST : 0u) | (j + 1 == ns ? DSPAN_LAST : 0u);
+                d.ord = j;
                 spans[si + j] = d;
-                dspan_status[3 * (si + j)] = 0;
+                dspan_status[4 * (si + j)] = 0;
             }
         }
         __syncthreads();
@@ -2558,14 +2571,16 @@ __global__ __launch_bounds__(256) void zstd_dspan_finish_kernel(ReadBatch b, con
     }
     bool bad = false;
     for (uint32_t k = s0 + tid; k < s1; k += 256) {
-        bool ok = dspan_status[3 * k] == 1;
-        if (ok && k + 1 < s1) ok = dspan_status[3 * k + 1] == spans[k + 1].src_pos && dspan_status[3 * k + 2] == spans[k + 1].dst_pos;
+        bool ok = dspan_status[4 * k] == 1;
+        // the span ended where the next one starts, and left repeat offset 1 at 1 (what a later zero-run span assumed)
+        if (ok && k + 1 < s1)
+            ok = dspan_status[4 * k + 1] == spans[k + 1].src_pos && dspan_status[4 * k + 2] == spans[k + 1].dst_pos && dspan_status[4 * k + 3] == 1;
         bad |= !ok;
     }
     if (bad) bad_s = 1;
     __syncthreads();
     if (tid == 0) {
-        if (!bad_s) b.result[r] = dspan_status[3 * (s1 - 1) + 2];  // == the frame content size (checked by the last span)
+        if (!bad_s) b.result[r] = dspan_status[4 * (s1 - 1) + 2];  // == the frame content size (checked by the last span)
         redo[r] = bad_s;
     }
 }

@@ -46,8 +46,18 @@ constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams
 constexpr uint32_t SPAN_BLOCK = 16u << 10;
 // blocks per span: 4 (64 KB of stream per wavefront: a 40 MB buffer is 300 spans, one 400 k-sample read 8) up to 256 MB of
 // stream, 16 beyond (the decoder then has all 64 lanes of a wavefront busy).  A span costs its tree description, ~0.15 %.
-constexpr uint32_t SPAN_BYTES_SMALL = SPAN_BLOCK * 4, SPAN_BYTES_LARGE = SPAN_BLOCK * MAXBLK;
+#ifndef VBZ_SPAN_SMALL_BLOCKS
+#define VBZ_SPAN_SMALL_BLOCKS 2
+#endif
+constexpr uint32_t SPAN_BYTES_SMALL = SPAN_BLOCK * VBZ_SPAN_SMALL_BLOCKS, SPAN_BYTES_LARGE = SPAN_BLOCK * MAXBLK;
 constexpr uint32_t SPAN_LARGE_FROM = 256u << 20;
+// The control-byte region is cut into spans of at most KEYSPAN_BYTES, each ONE block whose zero runs become sequences
+// (what the one-wavefront path does with the whole region): tokenising and the serial sequence chain are the long pole of
+// a lone wavefront, so these spans are short.
+#ifndef VBZ_KEYSPAN_KB
+#define VBZ_KEYSPAN_KB 16
+#endif
+constexpr uint32_t KEYSPAN_BYTES = VBZ_KEYSPAN_KB << 10;
 __host__ __device__ constexpr uint32_t span_bytes_for(uint32_t N) { return N >= SPAN_LARGE_FROM ? SPAN_BYTES_LARGE : SPAN_BYTES_SMALL; }
 #ifndef VBZ_STEP_LANE
 #define VBZ_STEP_LANE 16
@@ -65,7 +75,7 @@ struct EncSpan
     uint32_t flags;      // SPAN_*
     uint64_t tmp_off;    // where its output goes in the temporary arena
     uint32_t tmp_cap;
-    uint32_t pad;
+    uint32_t ord;        // ordinal of the span in its frame
 };
 constexpr uint32_t SPAN_FIRST = 1, SPAN_LAST = 2, SPAN_KEYSEQ = 4, SPAN_SKIP = 8;
 
@@ -631,6 +641,22 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
     return hdr + flushed + nbytes;
 }
 
+__device__ __forceinline__ uint32_t span_tmp_bytes(uint32_t S, bool keyseq)
+{
+    const uint32_t b = S + (S >> 7) + 1024u + (keyseq ? 8u * (S / RMIN + 2u) + 512u : 0u);
+    return (b + 15u) & ~15u;
+}
+
+// per read: how its stream is cut.  keyN = spans of the control-byte region, dataN = of the rest.
+__device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN, uint32_t& dataN)
+{
+    const uint32_t SB = span_bytes_for(N);
+    keyN = K == 0 ? 0u : (K + KEYSPAN_BYTES - 1) / KEYSPAN_BYTES;
+    const uint32_t D = N - K;
+    dataN = D ? (D + SB - 1) / SB : 0u;
+    if (N == 0) dataN = 1;  // the empty frame
+}
+
 #ifndef VBZ_ENC_WAVES
 #define VBZ_ENC_WAVES 4   // measured: 2.2 ms (4 waves/SIMD, 16 symbols/lane) vs 2.85 ms (2 waves, 32 symbols/lane)
 #endif
@@ -736,9 +762,16 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         const uint2* rec = nullptr;
         if ((span_mode ? (sp.flags & SPAN_KEYSEQ) != 0 : (region == 0 && K != 0)) && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
             const uint32_t slot = src_cap[r];
-            const uint64_t need = (uint64_t)N + 16 + 8ull * (S / RMIN + 2);
+            // records of all control-byte spans of the frame live behind the stream, each span's at its own offset
+            uint32_t keyN = 1, dataN = 0, ord = 0;
+            if (span_mode) {
+                span_cut(N, K, keyN, dataN);
+                ord = sp.ord;
+            }
+            const uint32_t recs_all = K / RMIN + 2u * keyN + 2u;
+            const uint64_t need = (uint64_t)N + 16 + 8ull * recs_all;
             if (need <= slot) {
-                uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * (S / RMIN + 2)) & ~7u);
+                uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * recs_all) & ~7u) + 8u * (r0 / RMIN + 2u * ord);
                 uint32_t Lit = 0;
                 tokenise_zero_runs(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, lane);
                 __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
@@ -1031,7 +1064,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         }
     }
     const uint32_t main_bytes = opos;
-    if (frame_cp) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
+    if (frame_cp && (!span_mode || (sp.flags & SPAN_FIRST))) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
         wave_lds_sync();
         const uint32_t count = L.cpCount, tb = 8u + 4u + 4u * count + 4u;
         if (count != 0 && (uint64_t)opos + tb <= cap) {
@@ -1072,22 +1105,6 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 //   layout: magic 0x184D2A5C, u32 payload bytes, { u32 nspans, nspans x { u32 frame offset, u32 content offset }, u32 total bytes }
 constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;
 
-__device__ __forceinline__ uint32_t span_tmp_bytes(uint32_t S, bool keyseq)
-{
-    const uint32_t b = S + (S >> 7) + 1024u + (keyseq ? 8u * (S / RMIN + 2u) + 512u : 0u);
-    return (b + 15u) & ~15u;
-}
-
-// per read: how its stream is cut.  keyN = spans of the control-byte region, dataN = of the rest.
-__device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN, uint32_t& dataN)
-{
-    const uint32_t SB = span_bytes_for(N);
-    keyN = K == 0 ? 0u : (K <= BLOCK_MAX ? 1u : (K + SB - 1) / SB);
-    const uint32_t D = N - K;
-    dataN = D ? (D + SB - 1) / SB : 0u;
-    if (N == 0) dataN = 1;  // the empty frame
-}
-
 __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const uint32_t* svb_size, const uint32_t* orig_size, uint32_t key_elem,
                                                               const uint32_t* gate, uint32_t seq_enabled, uint32_t max_spans, uint64_t tmp_limit,
                                                               EncSpan* spans, uint32_t* span_first, uint32_t* span_count)
@@ -1120,7 +1137,7 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                 span_cut(N, K, keyN, dataN);
                 cnt = keyN + dataN;
                 // every span of a region gets the slot of the region's largest span
-                if (keyN) bytes += (uint64_t)keyN * span_tmp_bytes((K + keyN - 1) / keyN, keyN == 1 && seq_enabled);
+                if (keyN) bytes += (uint64_t)keyN * span_tmp_bytes((K + keyN - 1) / keyN, seq_enabled != 0);
                 if (dataN) bytes += (uint64_t)dataN * span_tmp_bytes((N - K + dataN - 1) / dataN, false);
             }
         }
@@ -1164,7 +1181,7 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                 continue;
             }
             const uint32_t qN = q_N[q], qK = q_K[q], kN = q_keyN[q], dN = q_dataN[q], D = qN - qK, cntq = kN + dN;
-            const bool keyseq1 = kN == 1 && seq_enabled;
+            const bool keyseq1 = seq_enabled != 0;
             const uint32_t slotK = kN ? span_tmp_bytes((qK + kN - 1) / kN, keyseq1) : 0u;
             const uint32_t slotD = dN ? span_tmp_bytes((D + dN - 1) / dN, false) : 0u;
             for (uint32_t j = tid; j < cntq; j += 1024) {
@@ -1185,6 +1202,7 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                     e.tmp_cap = slotD;
                 }
                 e.flags = (j == 0 ? SPAN_FIRST : 0u) | (j + 1 == cntq ? SPAN_LAST : 0u) | (keyseq ? SPAN_KEYSEQ : 0u);
+                e.ord = j;
                 spans[si + j] = e;
             }
         }
@@ -1317,13 +1335,14 @@ size_t zstd_span_desc_bytes() { return sizeof(EncSpan); }
 
 uint32_t zstd_span_max_spans(uint64_t stream_bytes, uint32_t n_reads)
 {
-    const uint64_t v = stream_bytes / SPAN_BYTES_SMALL + 3ull * n_reads + 1;
+    const uint64_t v = stream_bytes / (KEYSPAN_BYTES / 2) + 4ull * n_reads + 1;  // spans are cut evenly: none is below half its limit
     return v > 0x7FFFFFF0ull ? 0u : (uint32_t)v;
 }
 
 uint64_t zstd_span_tmp_bytes(uint64_t stream_bytes, uint32_t n_reads, uint32_t max_spans)
 {
-    return stream_bytes + (stream_bytes >> 7) + (uint64_t)max_spans * 2048u + (uint64_t)n_reads * ((8ull * (BLOCK_MAX / RMIN + 2)) + 1024u) + 4096u;
+    // a span's slot: its bytes + 1/128 + 1 KB, and for a control-byte span 8 bytes per possible sequence (<= 8/RMIN per byte)
+    return stream_bytes + (stream_bytes >> 7) + stream_bytes * 8u / RMIN + (uint64_t)max_spans * 2048u + 4096u;
 }
 
 hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
