@@ -68,6 +68,28 @@ def launch_ranks(args, argv):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline leg
 # ---------------------------------------------------------------------------------------------------------------------
+def cpu_baseline_u32(n_buffers, count, min_seconds=6.0):
+    """CPU baseline of the config-4 workload: the oracle (streamvbyte restated from its published format + the pinned
+    libzstd at level 3) over `n_buffers` buffers of `count` uint32 values, one persistent thread per usable CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    cores, quota_note = usable_cpus()
+    opts = O.options(False, 4, 3, 0)
+    threads = min(cores, n_buffers)
+    one = O.bench_roundtrip(1, 1, 1.0, opts, u32_count=count)
+    allc = O.bench_roundtrip(n_buffers, threads, min_seconds, opts, u32_count=count)
+    return {
+        "value": round(allc["raw_bytes"] / allc["best_s"] / 1e6, 1), "unit": "MB/s", "cores": threads, "kind": "port",
+        "sample": "%d buffers of %d uint32 values of the same generator (%.1f MB raw), encode+decode, %d persistent threads (%s; one buffer "
+                  "per thread at a time: the reference has no internal threading), scalar svb + libzstd %s level 3, best of %d timed passes; "
+                  "one thread: %.1f MB/s" % (n_buffers, count, allc["raw_bytes"] / 1e6, threads, quota_note,
+                                             (O.lib().vbo_zstd_version() or b"?").decode(), allc["passes"], one["raw_bytes"] / one["best_s"] / 1e6),
+        "one_thread": round(one["raw_bytes"] / one["best_s"] / 1e6, 1),
+        "ratio": round(allc["raw_bytes"] / allc["comp_bytes"], 4),
+    }
+
+
 def cpu_baseline(min_seconds=8.0, n_reads=16384):
     """The oracle (port of the reference CPU path: scalar svb + the pinned libzstd, dlopen'd) timed on this box's
     host cores on a bounded sample of the same workload: reads [0, n_reads) of the same generator, encode+decode,
@@ -257,6 +279,12 @@ def run_rank(args):
 
     codec = batch.GpuCodec(local_rank)
     torch.cuda.set_stream(codec.stream)  # everything below (generation, events, kernels) runs on the codec's stream
+    if args.workload != "reads":
+        run_large(args, codec, dev, rank, world, coll_dev, barrier)
+        if world > 1:
+            barrier()
+            dist.destroy_process_group()
+        return 0
     opts = codec.options(*opts_tuple)
     L = codec.L
 
@@ -497,6 +525,138 @@ def run_rank(args):
     return 0
 
 
+def run_large(args, codec, dev, rank, world, coll_dev, barrier):
+    """BASELINE.json configs[3] (`--workload config4`: uint32, no zig-zag, level 3, 10 M-element buffers) and configs[0]
+    (`--workload config1`: one 400 k-sample int16 read): batches of few, large buffers, which the library spreads over many
+    workgroups (segmented svb kernels, one wavefront per span of the entropy stage)."""
+    import torch
+
+    from vbz_compression_amd import _lib, batch, shard, vbz
+
+    L = codec.L
+    if args.workload == "config4":
+        elem, zz, level, ver, count, nbuf, kind = 4, False, 3, 0, 10_000_000, args.buffers, "u32"
+        name = "configs[3]: uint32, no zig-zag, zstd level 3 (UD=32020,5,0,0,4,0,3), %d buffer(s) of 10M elements per step" % nbuf
+    else:
+        elem, zz, level, ver, count, nbuf, kind = 2, True, 1, 1, 400_000, 1, "i16"
+        name = "configs[0]: ONE 400k-sample int16 read per step, zig-zag + svb + zstd-format stage"
+    opts = codec.options(zz, elem, level, ver)
+    nbytes = count * elem
+    sizes = torch.full((nbuf,), nbytes, dtype=torch.int64)
+    off, total = batch.layout(sizes, 64)
+    cap = L.vbz_max_compressed_size(nbytes, ctypes.byref(opts))
+    coff, ctotal = batch.layout(torch.full((nbuf,), cap, dtype=torch.int64), 64)
+    raw = torch.zeros(total, dtype=torch.uint8, device=dev)
+    offd, coffd = off.to(dev), coff.to(dev)
+    lens = torch.full((nbuf,), count, dtype=torch.int32, device=dev)
+    first = rank * nbuf
+    (codec.synth_u32 if kind == "u32" else codec.synth_signal)(5, first, raw, offd, lens)
+    comp = torch.zeros(ctotal, dtype=torch.uint8, device=dev)
+    back = torch.zeros_like(raw)
+    size32 = sizes.to(torch.int32).to(dev)
+    cap32 = torch.full((nbuf,), cap, dtype=torch.int64).to(torch.int32).to(dev)
+    csize = torch.zeros(nbuf, dtype=torch.int32, device=dev)
+    res = torch.zeros(nbuf, dtype=torch.int32, device=dev)
+
+    def step(mid=None):
+        codec.compress(raw, offd, size32, comp, coffd, cap32, csize, opts)
+        if mid is not None:
+            mid.record()
+        codec.decompress(comp, coffd, csize, back, offd, size32, res, opts)
+
+    step()
+    torch.cuda.synchronize()
+    assert bool((res == size32).all()) and torch.equal(raw, back), "round trip mismatch"
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    codec.profile_reset()
+    codec.profile(True)
+    ev0 = torch.cuda.Event(enable_timing=True)
+    evm = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    eve = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(evm[i])
+        eve[i].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, coll_dev)
+    codec.profile(False)
+    prof = codec.profile_read()
+    raw_bytes = nbuf * nbytes * args.steps
+    comp_bytes = int(csize.to(torch.int64).sum())
+    ratio = nbuf * nbytes / comp_bytes
+    table, _ = shard.exchange_tallies(nbuf * args.steps, raw_bytes, comp_bytes * args.steps, coll_dev)
+    total_raw = int(table[:, 1].sum())
+    enc_ms = dec_ms = 0.0
+    prev = ev0
+    for i in range(args.steps):
+        enc_ms += prev.elapsed_time(evm[i])
+        dec_ms += evm[i].elapsed_time(eve[i])
+        prev = eve[i]
+    if rank != 0:
+        return
+    per_launch = {k: v[1] / max(v[0], 1) for k, v in prof.items()}
+    # per direction: elem + c bytes per value (SURVEY 8d: "for uint32 config: 4 + c4 per element per direction")
+    c = elem / ratio
+    alg_dir = (elem + c) * count * nbuf
+    t_enc = enc_ms / args.steps * 1e-3
+    t_dec = dec_ms / args.steps * 1e-3
+    dom = max((k for k in per_launch if k not in ("plan_scratch", "seg_plan")), key=lambda k: prof[k][1])
+    dom_dir = "encode" if "encode" in dom else "decode"
+    t_dom = t_enc if dom_dir == "encode" else t_dec
+    out = {
+        "metric": METRIC, "value": round(total_raw / elapsed / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "uint32" if kind == "u32" else "int16", "data": "synthetic",
+        "config": {"workload": name + ", encode then decode through the batched entry points, inputs resident in HBM",
+                   "buffers_per_step": nbuf, "elements_per_buffer": count,
+                   "options": "zigzag=%d,integer_size=%d,zstd_level=%d,vbz_version=%d" % (zz, elem, level, ver),
+                   "parallelism": "%d GPU(s), the same workload on each (buffers are independent; no data-path collective)" % world},
+        "ratio": round(ratio, 4),
+        "encode_MBps": round(raw_bytes / (enc_ms * 1e-3) / 1e6, 1), "decode_MBps": round(raw_bytes / (dec_ms * 1e-3) / 1e6, 1),
+        "encode_ms": round(enc_ms / args.steps, 4), "decode_ms": round(dec_ms / args.steps, 4),
+        "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
+        "roofline": {"bound": "hbm", "kernel": dom, "direction": dom_dir, "achieved": round(alg_dir / t_dom / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(alg_dir / t_dom / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(alg_dir), "algorithmic_bytes_per_value": round(elem + c, 4), "avg_launch_ms": round(t_dom * 1e3, 4),
+                     "definition": "SURVEY 8d: (integer size + c) bytes per value per direction over the duration of the direction's launch "
+                                   "sequence (HIP events on the codec's stream around every call); a batch of few buffers is bound by the latency "
+                                   "of one wavefront per span, not by HBM",
+                     "per_direction": {"encode": {"achieved": round(alg_dir / t_enc / 1e9, 2), "frac": round(alg_dir / t_enc / 1e9 / PEAK_HBM_GBS, 5)},
+                                       "decode": {"achieved": round(alg_dir / t_dec / 1e9, 2), "frac": round(alg_dir / t_dec / 1e9 / PEAK_HBM_GBS, 5)}}},
+    }
+    if world == 1:
+        # the single-buffer host API (vbz_compress / vbz_decompress: PCIe copies and synchronisation included; never `value`)
+        h = raw[:nbytes].cpu().numpy()
+        o2 = _lib.CompressionOptions(zz, elem, level, ver)
+        f = vbz.compress_raw(h, o2)
+        b2 = vbz.decompress_raw(f, nbytes, o2)
+        assert b2.tobytes() == h.tobytes()
+        k = 10
+        t0 = time.perf_counter()
+        for _ in range(k):
+            f = vbz.compress_raw(h, o2)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            b2 = vbz.decompress_raw(f, nbytes, o2)
+        t2 = time.perf_counter()
+        out["host_api"] = {"vbz_compress_ms": round((t1 - t0) / k * 1e3, 3), "vbz_decompress_ms": round((t2 - t1) / k * 1e3, 3),
+                           "encode_decode_MBps": round(nbytes / ((t2 - t0) / k) / 1e6, 1),
+                           "note": "one buffer per call through include/vbz.h, host memory in and out"}
+    if world == 1 and not args.no_cpu:
+        if kind == "u32":
+            out["cpu_baseline"] = cpu_baseline_u32(max(nbuf, usable_cpus()[0]), count)
+        else:
+            out["cpu_baseline"] = cpu_baseline(min_seconds=4.0, n_reads=16384)
+            out["cpu_baseline"]["note"] = "reads of ~100k samples of the same generator (a single 400k read is one core's work: see one_thread)"
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -504,6 +664,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per batch (one batch per step)")
     ap.add_argument("--resident", type=int, default=0, help="distinct batches kept in HBM and cycled (0: as many as fit, at most 16)")
+    ap.add_argument("--workload", default="reads", choices=["reads", "config4", "config1"],
+                    help="reads: BASELINE configs[1] (the headline); config4: uint32 10M-element buffers; config1: one 400k-sample read")
+    ap.add_argument("--buffers", type=int, default=8, help="config4: buffers per step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the work queue (nccl = RCCL)")
     ap.add_argument("--dry-run", action="store_true", help="launcher and work-queue plumbing only: no codec, no GPU (CPU test of the N > 1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

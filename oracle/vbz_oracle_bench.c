@@ -22,8 +22,9 @@ typedef struct {
     uint32_t n_reads;
     int threads;
     int16_t** reads;
-    uint32_t* nsamples;
+    uint32_t* nsamples;        /* values per read (int16 samples, or uint32 elements when elem == 4) */
     uint32_t max_samples;
+    uint32_t elem;             /* bytes per value: 2 = the int16 signal generator, 4 = the config-4 uint32 generator */
     const VboOptions* opts;
     pthread_barrier_t bar;
     atomic_uint next;          /* work queue: next unclaimed read */
@@ -49,12 +50,14 @@ static void* worker(void* arg)
 {
     worker_t* w = (worker_t*)arg;
     shared_t* sh = w->sh;
-    vbo_size_t cap = vbo_max_compressed_size(sh->max_samples * 2, sh->opts);
+    vbo_size_t cap = vbo_max_compressed_size(sh->max_samples * sh->elem, sh->opts);
     uint8_t* cbuf = (uint8_t*)malloc((size_t)cap + 64);
-    int16_t* dbuf = (int16_t*)malloc((size_t)sh->max_samples * 2 + 64);
+    int16_t* dbuf = (int16_t*)malloc((size_t)sh->max_samples * sh->elem + 64);
     if (!cbuf || !dbuf) atomic_store(&sh->failed, 1);
-    for (uint32_t i = (uint32_t)w->tid; i < sh->n_reads; i += (uint32_t)sh->threads)  /* generation, untimed */
-        vbo_synth_signal(5, i, sh->reads[i], sh->nsamples[i]);
+    for (uint32_t i = (uint32_t)w->tid; i < sh->n_reads; i += (uint32_t)sh->threads) {  /* generation, untimed */
+        if (sh->elem == 4) vbo_synth_u32(5, i, (uint32_t*)sh->reads[i], sh->nsamples[i]);
+        else vbo_synth_signal(5, i, sh->reads[i], sh->nsamples[i]);
+    }
     for (;;) {
         pthread_barrier_wait(&sh->bar);  /* pass start (the main thread resets the queue before it) */
         if (atomic_load(&sh->stop)) break;
@@ -63,7 +66,7 @@ static void* worker(void* arg)
         for (;;) {
             const uint32_t i = atomic_fetch_add(&sh->next, 1u);
             if (i >= sh->n_reads || atomic_load(&sh->failed)) break;
-            const uint32_t bytes = sh->nsamples[i] * 2;
+            const uint32_t bytes = sh->nsamples[i] * sh->elem;
             const double t0 = now_s();
             const vbo_size_t c = vbo_compress(sh->reads[i], bytes, cbuf, cap, sh->opts);
             const double t1 = now_s();
@@ -89,7 +92,20 @@ static void* worker(void* arg)
  * timed encode+decode passes on `threads` persistent threads until at least `min_seconds` have elapsed (at least
  * one).  out[0]=raw bytes per pass, out[1]=compressed bytes per pass, out[2]=best pass wall seconds, out[3]=sum of
  * per-thread encode seconds of that pass, out[4]=same for decode, out[5]=timed passes run.  Returns 0 on success. */
+static int bench_roundtrip(uint32_t n_reads, uint32_t elem, uint32_t fixed_count, int threads, double min_seconds, const VboOptions* opts, double* out);
+
 int vbo_bench_roundtrip(uint32_t n_reads, int threads, double min_seconds, const VboOptions* opts, double* out)
+{
+    return bench_roundtrip(n_reads, 2, 0, threads, min_seconds, opts, out);
+}
+
+/* The same harness over `n_buffers` buffers of `count` uint32 values of the config-4 generator (seed 5, buffer index i). */
+int vbo_bench_roundtrip_u32(uint32_t n_buffers, uint32_t count, int threads, double min_seconds, const VboOptions* opts, double* out)
+{
+    return bench_roundtrip(n_buffers, 4, count, threads, min_seconds, opts, out);
+}
+
+static int bench_roundtrip(uint32_t n_reads, uint32_t elem, uint32_t fixed_count, int threads, double min_seconds, const VboOptions* opts, double* out)
 {
     if (threads < 1) threads = 1;
     shared_t sh;
@@ -97,6 +113,7 @@ int vbo_bench_roundtrip(uint32_t n_reads, int threads, double min_seconds, const
     sh.n_reads = n_reads;
     sh.threads = threads;
     sh.opts = opts;
+    sh.elem = elem;
     sh.reads = (int16_t**)calloc(n_reads ? n_reads : 1, sizeof(*sh.reads));
     sh.nsamples = (uint32_t*)calloc(n_reads ? n_reads : 1, sizeof(*sh.nsamples));
     worker_t* ws = (worker_t*)calloc((size_t)threads, sizeof(*ws));
@@ -104,11 +121,11 @@ int vbo_bench_roundtrip(uint32_t n_reads, int threads, double min_seconds, const
     if (!sh.reads || !sh.nsamples || !ws || !th) return -1;
     uint64_t raw = 0;
     for (uint32_t i = 0; i < n_reads; ++i) {
-        sh.nsamples[i] = vbo_synth_read_length(5, i);
+        sh.nsamples[i] = fixed_count ? fixed_count : vbo_synth_read_length(5, i);
         if (sh.nsamples[i] > sh.max_samples) sh.max_samples = sh.nsamples[i];
-        sh.reads[i] = (int16_t*)malloc((size_t)sh.nsamples[i] * 2);
+        sh.reads[i] = (int16_t*)malloc((size_t)sh.nsamples[i] * elem);
         if (!sh.reads[i]) return -1;
-        raw += (uint64_t)sh.nsamples[i] * 2;
+        raw += (uint64_t)sh.nsamples[i] * elem;
     }
     pthread_barrier_init(&sh.bar, NULL, (unsigned)threads + 1u);
     atomic_init(&sh.next, 0u);

@@ -87,6 +87,8 @@ def lib():
         L.vbo_synth_u32.argtypes = [ctypes.c_uint64, ctypes.c_uint64, vp, sz]
         L.vbo_bench_roundtrip.restype = ctypes.c_int
         L.vbo_bench_roundtrip.argtypes = [u32, ctypes.c_int, ctypes.c_double, op, ctypes.POINTER(ctypes.c_double)]
+        L.vbo_bench_roundtrip_u32.restype = ctypes.c_int
+        L.vbo_bench_roundtrip_u32.argtypes = [u32, u32, ctypes.c_int, ctypes.c_double, op, ctypes.POINTER(ctypes.c_double)]
         L.vbo_fuzz_max_destination.restype = u32
         L.vbo_fuzz_max_destination.argtypes = [u32, op]
         L.vbo_fuzz_decompress_sweep.restype = ctypes.c_int
@@ -221,10 +223,14 @@ def fnv1a64(data):
     return "%016x" % h
 
 
-def bench_roundtrip(n_reads, threads, min_seconds, opts):
-    """Threaded CPU timing of encode+decode over reads [0, n_reads) of the synthetic workload."""
+def bench_roundtrip(n_reads, threads, min_seconds, opts, u32_count=0):
+    """Threaded CPU timing of encode+decode over reads [0, n_reads) of the synthetic workload (u32_count: buffers of that
+    many uint32 values of the config-4 generator instead of int16 reads)."""
     out = (ctypes.c_double * 6)()
-    rc = lib().vbo_bench_roundtrip(n_reads, threads, min_seconds, ctypes.byref(opts), out)
+    if u32_count:
+        rc = lib().vbo_bench_roundtrip_u32(n_reads, u32_count, threads, min_seconds, ctypes.byref(opts), out)
+    else:
+        rc = lib().vbo_bench_roundtrip(n_reads, threads, min_seconds, ctypes.byref(opts), out)
     if rc != 0:
         raise RuntimeError("oracle bench failed (%d)" % rc)
     return dict(raw_bytes=out[0], comp_bytes=out[1], best_s=out[2], enc_thread_s=out[3], dec_thread_s=out[4], passes=int(out[5]))

@@ -536,7 +536,7 @@ def test_config3_uint32_ten_million_elements():
     r = O.compress(a, oo, sized=True)
     mine = vbz.decompress_raw(r, a.nbytes, go, sized=True)
     assert not isinstance(mine, int) and mine.tobytes() == a.tobytes()
-    assert abs(len(g) / len(r) - 1.0) < 0.03, (len(g), len(r))   # no control-byte sequences on this path: Huffman only
+    assert abs(len(g) / len(r) - 1.0) < 0.01, (len(g), len(r))   # T2: within 1 % of the oracle (libzstd level 3) on config 4
 
 
 def test_cpp_caller_relinked_against_libvbz_hip(tmp_path):
