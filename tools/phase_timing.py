@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock cycles of the two entropy kernels for ONE read on an otherwise idle GPU (a lone wavefront):
+
+    VBZ_HIP_PHASE_TIMING=1 VBZ_HIP_SEGMENTED=0 python tools/phase_timing.py [samples ...]
+
+The library prints the phase lines on stderr (see dbg_end in vbz_api.hip).  The kernels are latency-bound per wavefront
+(a lone wavefront issues about one instruction every ten cycles), so these numbers track what a change does to a frame's
+critical path; what it does to throughput under load is bench.py's business."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib as O  # noqa: E402  (test infrastructure: only generates the signal and checks the round trip here)
+import gpu_util as G  # noqa: E402
+from vbz_compression_amd import _lib  # noqa: E402
+
+opts = _lib.CompressionOptions(True, 2, 1, 1)
+for n in [int(x) for x in sys.argv[1:]] or [100000, 100000]:
+    a = O.synth_signal(5, 1, n)
+    f = G.compress([a], opts)
+    b = G.decompress(f, [a.nbytes], opts)
+    assert b[0].tobytes() == a.tobytes()

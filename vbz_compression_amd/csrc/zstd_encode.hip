@@ -62,7 +62,8 @@ __host__ __device__ constexpr uint32_t span_bytes_for(uint32_t N) { return N >= 
 #ifndef VBZ_STEP_LANE
 #define VBZ_STEP_LANE 16
 #endif
-constexpr int STEP_LANE = VBZ_STEP_LANE;    // symbols packed per lane per step (16 or 32)
+constexpr int STEP_LANE = VBZ_STEP_LANE;    // symbols packed per lane per step
+static_assert(STEP_LANE == 16, "the packing step is written for 16 symbols per lane");
 constexpr int STEP_DW = STEP_LANE / 4;      // dwords per lane chunk
 constexpr int STEP_SYMS = WAVE * STEP_LANE; // symbols packed per wave step
 constexpr int OBUF_WORDS = (STEP_SYMS * 11) / 32 + 8;  // one step packs at most 2048 symbols of 11 bits
@@ -955,58 +956,77 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     const int32_t room = (int32_t)(scnt - done) - STEP_LANE * lane;
                     const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
                     uint32_t ent[STEP_LANE];
-                    uint32_t T = 0;
 #pragma unroll
                     for (int k = 0; k < STEP_LANE; ++k) ent[k] = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
                     if (skip != 0) {  // only the last step of a stream has lanes in front of its start
 #pragma unroll
                         for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
                     }
+                    uint32_t Tb = 0;  // bits of this lane's codes
 #pragma unroll
-                    for (int k = 0; k < STEP_LANE; ++k) T += ent[k] >> 16;
-                    const uint32_t incl = wave_incl_scan_u32(T);
+                    for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k] >> 16;
+                    const uint32_t incl = wave_incl_scan_u32(Tb);
                     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-                    const uint32_t allbits = base_bits + total;
-                    const uint32_t full = allbits >> 5;
-                    if ((uint64_t)spos + flushed + 4ull * full + 8 > cap) { FINISH(E_ZSTD); return; }
-                    const uint32_t pos = base_bits + incl - T;
-                    uint32_t word = pos >> 5;
-                    uint32_t accbits = pos & 31;
-                    uint64_t acc = 0;
+                    const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
+                    const uint32_t fq = allbits >> 7;             // complete 16-byte quads
+                    if ((uint64_t)spos + flushed + 16ull * fq + 24 > cap) { FINISH(E_ZSTD); return; }
+                    {
+                        const uint32_t pos = base_bits + incl - Tb;
+                        uint32_t word = pos >> 5;
+                        uint32_t accbits = pos & 31;
+                        uint64_t acc = 0;
 #pragma unroll
-                    for (int k = STEP_LANE - 1; k >= 0; k -= 2) {
-                        // two symbols (at most 22 bits) per flush check: accbits < 32 before, < 54 after
-                        const uint32_t e1 = ent[k], e0 = ent[k - 1];
-                        const uint32_t l1 = e1 >> 16;
-                        const uint64_t pair = (uint64_t)((e1 & 0xFFFF) | ((e0 & 0xFFFF) << l1));
-                        acc |= pair << accbits;
-                        accbits += l1 + (e0 >> 16);
-                        if (accbits >= 32) {
-                            atomicOr(&L.obuf[word], (uint32_t)acc);
-                            acc >>= 32;
-                            accbits -= 32;
-                            ++word;
+                        for (int k = STEP_LANE - 1; k >= 0; k -= 2) {
+                            // two symbols (at most 22 bits) per flush check: accbits < 32 before, < 54 after
+                            const uint32_t e1 = ent[k], e0 = ent[k - 1];
+                            const uint32_t l1 = e1 >> 16;
+                            const uint64_t pair = (uint64_t)((e1 & 0xFFFF) | ((e0 & 0xFFFF) << l1));
+                            acc |= pair << accbits;
+                            accbits += l1 + (e0 >> 16);
+                            if (accbits >= 32) {
+                                atomicOr(&L.obuf[word], (uint32_t)acc);
+                                acc >>= 32;
+                                accbits -= 32;
+                                ++word;
+                            }
+                        }
+                        if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
+                    }
+                    wave_lds_sync();
+                    {   // complete quads leave as 16-byte stores and are cleared on the way; the rest moves to the front
+                        uint4* obq = reinterpret_cast<uint4*>(L.obuf);
+                        for (uint32_t q = lane; q < fq; q += WAVE) {
+                            const uint4 v = obq[q];
+                            obq[q] = make_uint4(0u, 0u, 0u, 0u);
+                            __builtin_memcpy(sop + flushed + 16u * q, &v, 16);
+                        }
+                        if (fq) {
+                            const uint4 c = obq[fq];
+                            wave_lds_sync();
+                            if (lane == 0) {
+                                obq[fq] = make_uint4(0u, 0u, 0u, 0u);
+                                obq[0] = c;
+                            }
                         }
                     }
-                    if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
-                    wave_lds_sync();
-                    for (uint32_t i = lane; i < full; i += WAVE) {
-                        const uint32_t v = L.obuf[i];
-                        __builtin_memcpy(sop + flushed + 4 * i, &v, 4);
-                    }
-                    const uint32_t carry = L.obuf[full];
-                    wave_lds_sync();
-                    for (uint32_t i = lane; i <= full; i += WAVE) L.obuf[i] = 0;
-                    flushed += 4 * full;
-                    base_bits = allbits & 31;
+                    flushed += 16u * fq;
+                    base_bits = allbits & 127u;
                     wave_lds_sync();
                     if (nst != st) {
-                        // stream finished: end mark and the last partial word
-                        const uint32_t nbytes = (base_bits + 1 + 7) >> 3;
-                        if (lane == 0) {
-                            const uint32_t v = carry | (1u << base_bits);
-                            for (uint32_t k = 0; k < nbytes; ++k) sop[flushed + k] = (uint8_t)(v >> (8 * k));
-                            L.ssize[st] = flushed + nbytes;
+                        // stream finished: end mark and the bits still in quad 0 (lane k writes byte k)
+                        const uint32_t nbytes = (base_bits + 1 + 7) >> 3;  // <= 16
+                        {
+                            uint4* obq = reinterpret_cast<uint4*>(L.obuf);
+                            const uint4 c = obq[0];
+                            const uint32_t cw[4] = { c.x, c.y, c.z, c.w };
+                            uint32_t mine = cw[(lane >> 2) & 3];
+                            if ((uint32_t)(lane >> 2) == (base_bits >> 5)) mine |= 1u << (base_bits & 31u);
+                            if ((uint32_t)lane < nbytes) sop[flushed + lane] = (uint8_t)(mine >> (8 * (lane & 3)));
+                            wave_lds_sync();
+                            if (lane == 0) {
+                                obq[0] = make_uint4(0u, 0u, 0u, 0u);
+                                L.ssize[st] = flushed + nbytes;
+                            }
                         }
                         spos += flushed + nbytes;
                         base_bits = 0;
@@ -1048,9 +1068,6 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                             }
                             ocur = spos + seqBytes;
                         }
-                    } else {
-                        if (lane == 0) L.obuf[0] = carry;
-                        wave_lds_sync();
                     }
 #pragma unroll
                     for (int k = 0; k < STEP_DW; ++k) cur[k] = nxt[k];
