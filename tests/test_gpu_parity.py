@@ -600,7 +600,8 @@ def test_pyvbz_interface():
         vbz.compress(np.arange(4, dtype=np.int16), True)   # a bare zig-zag flag in the options slot is refused, not ignored
     sig = np.arange(0, 1000, dtype=np.int16)    # python/pyvbz/README.md:18-23
     c = vbz.compress(sig)
-    assert c[:4].view("<u4")[0] == 2000 and len(c) < 400
+    # the reference's answer is 27 bytes (libzstd finds the two runs); this encoder's run sequences get within 2x of it
+    assert c[:4].view("<u4")[0] == 2000 and len(c) <= 54, len(c)
     assert (vbz.decompress(c, np.int16) == sig).all()
 
 

@@ -393,7 +393,7 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
     wave_lds_sync();
 }
 
-// ---- zero-run sequences for the control-byte region -------------------------------------------------------
+// ---- run sequences for the control-byte region (and for frames too small to have one) ----------------------------------
 // Control bytes are mostly 0x00; a Huffman code cannot spend less than one bit on each of them, libzstd's
 // LZ stage does.  The device equivalent keeps everything data-parallel: every run of >= RMIN zero bytes
 // becomes one zstd sequence "copy run-1 bytes from offset 1" (offset 1 = repeat offset 1 of a fresh frame,
@@ -433,7 +433,8 @@ __device__ __forceinline__ uint64_t dilate_left(uint64_t w, uint32_t r)  // bit 
 __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit, uint32_t& nrec, int lane)
 {
     uint32_t lit_total = 0, rec_total = 0;
-    uint32_t carry60 = 0, carry61 = 0;  // zero masks of the 32 positions in front of the payload
+    uint32_t carry60 = 0, carry61 = 0;  // masks of the 32 positions in front of the payload
+    uint32_t carryw = 0;                // the dword that ends in front of the payload (its top byte precedes position pb)
     const uint64_t below = (1ull << lane) - 1ull;
     for (uint32_t pb = 0; pb < K; pb += TOK_PAYLOAD) {
         const int64_t lo = (int64_t)pb + 16 * ((int64_t)lane - 2);
@@ -445,9 +446,19 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
             w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
             const uint32_t nvalid = (K - (uint32_t)lo) >= 16 ? 16u : (K - (uint32_t)lo);
             valid = nvalid >= 16 ? 0xFFFFu : ((1u << nvalid) - 1u);
+        }
+        {
+            // bit i of the mask: byte i equals the byte in front of it (a run of r equal bytes is r - 1 ones)
+            uint32_t pw = (uint32_t)__shfl_up((int)w[3], 1, 64);
+            if (lane == 2) pw = carryw;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) zm |= (((w[i >> 2] >> (8 * (i & 3))) & 0xFF) == 0 ? 1u : 0u) << i;
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t x = w[q] ^ __builtin_amdgcn_alignbyte(w[q], q ? w[q - 1] : pw, 3);  // zero byte <=> equal neighbours
+#pragma unroll
+                for (int i = 0; i < 4; ++i) zm |= (((x >> (8 * i)) & 0xFF) == 0 ? 1u : 0u) << (4 * q + i);
+            }
             zm &= valid;
+            if (lane == 2 && pb == 0) zm &= ~1u;  // nothing in front of the first byte
         }
         if (lane == 0) zm = carry60;
         if (lane == 1) zm = carry61;
@@ -460,9 +471,8 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
         // window bit j <-> position lo - 24 + j
         const uint64_t W = (uint64_t)((m2 >> 8) & 0xFF) | ((uint64_t)m1 << 8) | ((uint64_t)zm << 24) | ((uint64_t)p1 << 40) |
                            ((uint64_t)(p2 & 0xFF) << 56);
-        const uint64_t Q = dilate_left(erode_right(W, RMIN), RMIN);  // positions inside runs of >= RMIN zeros
-        const uint64_t RM = Q & (W << 1);                            // ... except the first one of each run
-        const uint64_t END = RM & ~(W >> 1);                         // last position of such a run
+        const uint64_t RM = dilate_left(erode_right(W, RMIN - 1), RMIN - 1);  // runs of >= RMIN equal bytes, without their first byte
+        const uint64_t END = RM & ~(RM >> 1);                                  // last position of such a run
         const bool payload = lane >= 2 && lane < 62;
         const uint32_t r16 = payload ? (uint32_t)(RM >> 24) & 0xFFFFu : 0u;
         const uint32_t end16 = payload ? (uint32_t)(END >> 24) & 0xFFFFu & valid : 0u;
@@ -491,6 +501,7 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
         lit_total += tot;
         carry60 = (uint32_t)__shfl((int)zm, 60, 64);
         carry61 = (uint32_t)__shfl((int)zm, 61, 64);
+        carryw = (uint32_t)__shfl((int)w[3], 61, 64);
     }
     Lit = lit_total;
     nrec = rec_total;
@@ -761,7 +772,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         bool seqmode = false;
         uint32_t nrec = 0;
         const uint2* rec = nullptr;
-        if ((span_mode ? (sp.flags & SPAN_KEYSEQ) != 0 : (region == 0 && K != 0)) && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
+        if ((span_mode ? (sp.flags & SPAN_KEYSEQ) != 0 : region == 0) && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
             const uint32_t slot = src_cap[r];
             // records of all control-byte spans of the frame live behind the stream, each span's at its own offset
             uint32_t keyN = 1, dataN = 0, ord = 0;
@@ -769,7 +780,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 span_cut(N, K, keyN, dataN);
                 ord = sp.ord;
             }
-            const uint32_t recs_all = K / RMIN + 2u * keyN + 2u;
+            const uint32_t recs_all = (K ? K : N) / RMIN + 2u * keyN + 2u;  // (a frame without a control-byte region is tokenised as a whole)
             const uint64_t need = (uint64_t)N + 16 + 8ull * recs_all;
             if (need <= slot) {
                 uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * recs_all) & ~7u) + 8u * (r0 / RMIN + 2u * ord);
@@ -1155,7 +1166,8 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                 cnt = keyN + dataN;
                 // every span of a region gets the slot of the region's largest span
                 if (keyN) bytes += (uint64_t)keyN * span_tmp_bytes((K + keyN - 1) / keyN, seq_enabled != 0);
-                if (dataN) bytes += (uint64_t)dataN * span_tmp_bytes((N - K + dataN - 1) / dataN, false);
+                // (a small frame without a control-byte region is one span that looks for runs, like the one-wavefront path)
+                if (dataN) bytes += (uint64_t)dataN * span_tmp_bytes((N - K + dataN - 1) / dataN, keyN == 0 && dataN == 1 && seq_enabled != 0);
             }
         }
         uint32_t ci = cnt;
@@ -1200,7 +1212,8 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
             const uint32_t qN = q_N[q], qK = q_K[q], kN = q_keyN[q], dN = q_dataN[q], D = qN - qK, cntq = kN + dN;
             const bool keyseq1 = seq_enabled != 0;
             const uint32_t slotK = kN ? span_tmp_bytes((qK + kN - 1) / kN, keyseq1) : 0u;
-            const uint32_t slotD = dN ? span_tmp_bytes((D + dN - 1) / dN, false) : 0u;
+            const bool dataseq = kN == 0 && dN == 1 && seq_enabled != 0 && D >= 256;
+            const uint32_t slotD = dN ? span_tmp_bytes((D + dN - 1) / dN, kN == 0 && dN == 1 && seq_enabled != 0) : 0u;
             for (uint32_t j = tid; j < cntq; j += 1024) {
                 EncSpan e = {};
                 e.read = base + q;
@@ -1217,6 +1230,7 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                     e.r1 = qK + (uint32_t)((uint64_t)D * (t + 1) / dN);
                     e.tmp_off = q_off[q] + (uint64_t)kN * slotK + (uint64_t)t * slotD;
                     e.tmp_cap = slotD;
+                    keyseq = dataseq;
                 }
                 e.flags = (j == 0 ? SPAN_FIRST : 0u) | (j + 1 == cntq ? SPAN_LAST : 0u) | (keyseq ? SPAN_KEYSEQ : 0u);
                 e.ord = j;
