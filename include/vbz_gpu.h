@@ -58,6 +58,14 @@ VBZ_EXPORT vbz_gpu_ctx* vbz_gpu_create(int device, void* stream);
 VBZ_EXPORT void vbz_gpu_destroy(vbz_gpu_ctx* ctx);
 VBZ_EXPORT void* vbz_gpu_stream(vbz_gpu_ctx* ctx);
 VBZ_EXPORT const char* vbz_gpu_last_error(vbz_gpu_ctx* ctx);
+/* Decoder hints behind the zstd frame.  By default a compressed buffer may end in zstd SKIPPABLE frames (RFC 8878 3.1.2;
+ * libzstd, hence the reference's vbz_decompress, ignores them): checkpoints of the sequences section (magic 0x184D2A5B,
+ * <= 272 bytes) and, for reads of half a megabyte or more, an index of the frame's spans (magic 0x184D2A5C, 8 bytes per
+ * 16-64 KB of content).  This library's decoder uses them to decode one frame on many lanes / wavefronts and verifies
+ * them; without them it decodes the same frames, more slowly.  enable = 0 writes plain single zstd frames (for consumers
+ * that insist on consumed == source size after ONE frame); the compression itself (run sequences included) is unchanged.
+ * The single-buffer API of vbz.h follows the environment variable VBZ_HIP_TRAILERS (0 / 1, default 1). */
+VBZ_EXPORT void vbz_gpu_set_trailers(vbz_gpu_ctx* ctx, int enable);
 /* wait for everything queued on the context's stream; returns 0 or a negative HIP error */
 VBZ_EXPORT int vbz_gpu_synchronize(vbz_gpu_ctx* ctx);
 

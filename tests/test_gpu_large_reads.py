@@ -159,3 +159,27 @@ def test_whole_suite_on_the_large_read_path():
                         "not bench_line and not fast5 and not h5repack and not hdf5 and not cpp_caller and not many_threads"],
                        capture_output=True, text=True, timeout=3000, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_trailers_are_an_option_of_the_context():
+    """vbz_gpu_set_trailers(ctx, 0): every compressed buffer is ONE plain zstd frame (nothing behind it), with the same
+    blocks -- run sequences included -- as with the trailers; both decode on the device and through libzstd."""
+    c = G.codec()
+    o = (True, 2, 1, 1)
+    go, oo = _lib.CompressionOptions(*o), O.options(*o)
+    reads = [O.synth_signal(5, 20, 100000), O.synth_signal(5, 21, 900000)]   # the one-wavefront path and the span path
+    with_tr = [G.compress([a], go)[0] for a in reads]
+    c.set_trailers(False)
+    try:
+        without = [G.compress([a], go)[0] for a in reads]
+    finally:
+        c.set_trailers(True)
+    for a, w, p in zip(reads, with_tr, without):
+        body, tr = _trailers(w)
+        assert tr, "by default the buffer ends in skippable frames"
+        assert _trailers(p)[1] == [] and p.tobytes() == body.tobytes()       # the same frame, nothing behind it
+        assert O.zstd_content_size(p) == O.zstd_content_size(w)
+        for f in (w, p):
+            assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes()
+        back = G.decompress([w, p], [a.nbytes, a.nbytes], go)
+        assert back[0].tobytes() == a.tobytes() and back[1].tobytes() == a.tobytes()

@@ -65,6 +65,7 @@ GPU_API = [
     "vbz_gpu_destroy",
     "vbz_gpu_stream",
     "vbz_gpu_last_error",
+    "vbz_gpu_set_trailers",
     "vbz_gpu_synchronize",
     "vbz_gpu_compress_batch",
     "vbz_gpu_decompress_batch",
@@ -118,6 +119,8 @@ def load():
     L.vbz_gpu_stream.argtypes = [vp]
     L.vbz_gpu_last_error.restype = ctypes.c_char_p
     L.vbz_gpu_last_error.argtypes = [vp]
+    L.vbz_gpu_set_trailers.restype = None
+    L.vbz_gpu_set_trailers.argtypes = [vp, ctypes.c_int]
     L.vbz_gpu_synchronize.restype = ctypes.c_int
     L.vbz_gpu_synchronize.argtypes = [vp]
     for name in ("vbz_gpu_compress_batch", "vbz_gpu_decompress_batch"):

@@ -44,6 +44,10 @@ class GpuCodec:
         if cur != self.stream:
             cur.wait_stream(self.stream)
 
+    def set_trailers(self, enable):
+        """Decoder hints (checkpoints, span index) in skippable frames behind the zstd frame: on by default (include/vbz_gpu.h)."""
+        self.L.vbz_gpu_set_trailers(self.ctx, int(bool(enable)))
+
     def close(self):
         if getattr(self, "ctx", None):
             self.L.vbz_gpu_destroy(self.ctx)

@@ -57,7 +57,7 @@ struct vbz_gpu_ctx
     DevBuf seqdtab;   // decoding tables of the same distributions
     DevBuf segmeta;   // segment / span tables of the large-read path
     DevBuf spanmeta, spantmp;  // span tables and temporary slots of the entropy stage in the large-read path
-    bool index_trailer = true; // VBZ_HIP_INDEX_TRAILER=0: no span index behind large frames
+    bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
     bool phase_timing = false;
@@ -321,7 +321,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
@@ -377,7 +377,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
         Timed t(c, "zstd_encode");
         HIPCHK(c, launch_zstd_encode_spans(z, bt->src_size, o->integer_size, hdr, c->zero_run_sequences ? svb_cap : nullptr,
                                            c->zero_run_sequences ? c->seqtab.p : nullptr, desc, span_first, span_count, max_spans,
-                                           (uint8_t*)c->spantmp.p, tmp_bytes, span_size, span_trail, span_dst, c->index_trailer, s),
+                                           (uint8_t*)c->spantmp.p, tmp_bytes, span_size, span_trail, span_dst, c->trailers, s),
                "zstd_encode (spans) launch");
         return 0;
     }
@@ -385,7 +385,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     {
         Timed t(c, "zstd_encode");
         HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, c->zero_run_sequences ? svb_cap : nullptr,
-                                     c->zero_run_sequences ? c->seqtab.p : nullptr, s),
+                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, s),
                "zstd_encode launch");
     }
     dbg_end(c, n, "zstd_encode: setup hist plan size hdr encode", dbg);
@@ -544,7 +544,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
-    if (const char* e = getenv("VBZ_HIP_INDEX_TRAILER")) c->index_trailer = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
     {
         std::vector<uint8_t> host(seq_tables_bytes());
         seq_tables_build(host.data());
@@ -595,6 +595,11 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
 }
 
 void* vbz_gpu_stream(vbz_gpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+void vbz_gpu_set_trailers(vbz_gpu_ctx* c, int enable)
+{
+    if (c) c->trailers = enable != 0;
+}
 const char* vbz_gpu_last_error(vbz_gpu_ctx* c) { return c ? c->error.c_str() : "no context"; }
 
 int vbz_gpu_synchronize(vbz_gpu_ctx* c)
@@ -666,7 +671,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, c->stream), "zstd_encode launch");
     return 0;
 }
 

@@ -59,8 +59,9 @@ hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigz
 // dbg (nullable): 8 x u64 per read, shader-clock cycles spent per phase (debug aid, VBZ_HIP_PHASE_TIMING=1)
 // src_cap + seq_tables (both nullable): the source streams live in library-owned scratch slots of that
 // capacity, which lets the encoder rewrite the control-byte region as literals + zero-run sequences.
+// trailers: append the decoder-checkpoint skippable frame when a sequences section was written (see zstd_encode.hip)
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                              uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables,
+                              uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
                               hipStream_t s);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);
@@ -73,7 +74,7 @@ uint64_t zstd_span_tmp_bytes(uint64_t stream_bytes, uint32_t n_reads, uint32_t m
 hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
                                     const void* seq_tables, void* span_desc, uint32_t* span_first, uint32_t* span_count, uint32_t max_spans,
                                     uint8_t* span_tmp, uint64_t span_tmp_bytes, uint32_t* span_size, uint32_t* span_trail, uint32_t* span_dst,
-                                    bool index_trailer, hipStream_t s);
+                                    bool trailers, hipStream_t s);  // trailers: checkpoints and span index behind the frame
 // decode: result[i] = frame content size, E_ZSTD for a malformed frame, or `toosmall_code` when the
 // frame's content size exceeds dst_cap[i].
 // seq_dtables (device, from seq_dtables_build): decoding tables of the predefined LL / ML distributions.

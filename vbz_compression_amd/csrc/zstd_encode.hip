@@ -679,7 +679,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab, const EncSpan* spans,
                                                            const uint32_t* span_count, uint8_t* span_tmp, uint32_t* span_size,
-                                                           uint32_t* span_trail)
+                                                           uint32_t* span_trail, uint32_t trailers)
 {
     __shared__ __attribute__((aligned(16))) EncLds L;
     unsigned long long tph[PHASE_SLOTS] = {};
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         }
     }
     const uint32_t main_bytes = opos;
-    if (frame_cp && (!span_mode || (sp.flags & SPAN_FIRST))) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
+    if (frame_cp && trailers && (!span_mode || (sp.flags & SPAN_FIRST))) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
         wave_lds_sync();
         const uint32_t count = L.cpCount, tb = 8u + 4u + 4u * count + 4u;
         if (count != 0 && (uint64_t)opos + tb <= cap) {
@@ -1348,16 +1348,17 @@ __global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, con
 }  // namespace
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                              uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables,
+                              uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
                               hipStream_t s)
 {
+    const uint32_t tr = trailers ? 1u : 0u;
     if (b.n_reads == 0) return hipSuccess;
     if (dbg)
         hipLaunchKernelGGL(zstd_encode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr);
+                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
     else
         hipLaunchKernelGGL(zstd_encode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr);
+                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
     return hipGetLastError();
 }
 
@@ -1386,7 +1387,7 @@ hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_siz
     hipLaunchKernelGGL(zstd_span_plan_kernel, dim3(1), dim3(1024), 0, s, b.n_reads, b.src_size, orig_size, key_elem, b.gate,
                        (src_cap && seq_tables) ? 1u : 0u, max_spans, span_tmp_bytes, spans, span_first, span_count);
     hipLaunchKernelGGL(zstd_encode_kernel<false>, dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
-                       reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail);
+                       reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u);
     hipLaunchKernelGGL(zstd_span_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, hdr, spans, span_first, max_spans, span_size, span_trail,
                        span_dst, index_trailer ? 1u : 0u);
     hipLaunchKernelGGL(zstd_span_compact_kernel, dim3(max_spans), dim3(256), 0, s, b, spans, span_count, span_tmp, span_size, span_trail, span_dst,
