@@ -434,10 +434,10 @@ __device__ __forceinline__ bool svb_decode_range(const uint8_t* in, const uint8_
             keybits = kp[0];
             if (VPL == 8 && valid > 4) keybits |= (uint32_t)kp[1] << 8;
         }
-        uint32_t L = 0;
-#pragma unroll
-        for (int k = 0; k < VPL; ++k)
-            if (k < valid) L += ((keybits >> (2 * k)) & 3u) + 1u;
+        // bytes of the lane's values: each 2-bit code is length - 1; the sum of the 2-bit fields of a word is
+        // (word & 0x5555) + ((word >> 1) & 0x5555) folded -- two population counts
+        const uint32_t kb = valid == VPL ? keybits : (keybits & ((1u << (2 * valid)) - 1u));
+        const uint32_t L = (uint32_t)valid + (uint32_t)__popc(kb & 0x5555u) + 2u * (uint32_t)__popc(kb & 0xAAAAu);
         uint32_t tot;
         const uint32_t ex = block_excl_scan_u32(L, wsum, tot);
         if (MODE == 1) {
