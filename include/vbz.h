@@ -67,8 +67,11 @@ struct CompressionOptions
     bool perform_delta_zig_zag;
     /* 0 (no streamvbyte stage), 1, 2 or 4 */
     unsigned int integer_size;
-    /* 0 = no zstd stage; any other value selects this library's zstd-format entropy stage
-     * (the level is accepted for compatibility; the GPU encoder has one operating point) */
+    /* 0 = no zstd stage; any other value selects this library's zstd-format entropy stage.  The reference hands the level to
+     * libzstd (vbz/vbz.cpp:194-207); here it picks how hard the encoder looks for matches: 1-3 = Huffman-coded literals plus
+     * run sequences (what libzstd levels 1-3 get out of nanopore signal); >= 4 additionally searches the data bytes for ONE
+     * long repeat distance (a read that repeats a template: the reference's own perf generator) and codes the repeats as
+     * matches at that distance.  Decoding does not depend on the level. */
     unsigned int zstd_compression_level;
     /* 0 or 1 (identical for integer_size 2 and 4, reference vbz/v1/vbz_streamvbyte.cpp:46-61) */
     unsigned int vbz_version;

@@ -1,0 +1,82 @@
+"""GPU tests (-m gpu) of the long-repeat matcher (zstd_compression_level >= 4).
+
+The reference hands any level to libzstd (vbz/vbz.cpp:194-207) and its own perf generator fills reads by cycling a
+15 643-sample template (vbz/perf/test_data_generator.h:61-67), on which libzstd reaches ratios of 15-30.  Levels 1-3 of
+this library find runs only (distance 1); from level 4 the encoder also looks for ONE repeat distance in the data bytes and
+codes every period after the first as matches with that explicit offset."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from vbz_compression_amd import _lib
+
+import gpu_util as G
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _cycled(n, phase=0):
+    t = np.fromfile(os.path.join(GOLDEN, "test_data_read.i16"), dtype="<i2")     # the reference's real read (data fixture)
+    idx = (np.arange(n) + phase) % len(t)
+    return t[idx].astype(np.int16)
+
+
+def test_template_cycling_reads_compress_like_libzstd():
+    rng = np.random.default_rng(12)
+    lengths = [30000, 47011, 65536, 100000, 123457, 200000]
+    reads = [_cycled(n, int(rng.integers(0, 15643))) for n in lengths]
+    reads.append(O.synth_signal(5, 3, 100000))                       # nothing periodic: must not get worse
+    reads.append(np.tile(O.synth_signal(5, 4, 5000), 20)[:99999])    # a short period (5 000 samples)
+    oo1, oo4 = O.options(True, 2, 1, 1), O.options(True, 2, 4, 1)
+    g1 = G.compress(reads, _lib.CompressionOptions(True, 2, 1, 1))
+    g4 = G.compress(reads, _lib.CompressionOptions(True, 2, 4, 1))
+    back = G.decompress(g4, [a.nbytes for a in reads], _lib.CompressionOptions(True, 2, 4, 1))
+    for i, (a, f1, f4, b) in enumerate(zip(reads, g1, g4, back)):
+        assert not isinstance(f4, int) and not isinstance(b, int)
+        assert b.tobytes() == a.tobytes()                                           # device decodes its own frame
+        assert O.decompress(f4, a.nbytes, oo4).tobytes() == a.tobytes()              # ... and so does the reference's decoder
+        ref = O.compress(a, oo1)                                                     # libzstd level 1
+        r4, r1, rr = a.nbytes / len(f4), a.nbytes / len(f1), a.nbytes / len(ref)
+        if i < len(lengths):
+            assert r1 < 3.0                              # runs alone do not see the period
+            assert r4 > 0.8 * rr and r4 > 1.7 * r1, (i, r4, rr, r1)   # the matcher does: about what libzstd gets
+            print("cycled read of %d samples: level 1 %.2f, level 4 %.2f, libzstd %.2f" % (len(a), r1, r4, rr))
+        elif i == len(lengths):
+            assert abs(len(f4) - len(f1)) <= 16, (len(f4), len(f1))
+        else:
+            assert r4 > 0.5 * rr, (r4, rr)
+
+
+def test_level_four_on_every_dtype_and_shape():
+    """The matcher must never cost correctness: every integer size, zig-zag or not, periodic or not, sizes around the tile
+    and block boundaries, sized and unsized -- decoded by the device and by the reference's decoder."""
+    rng = np.random.default_rng(13)
+    cases = []
+    for dt, size in ((np.int16, 2), (np.int32, 4), (np.int8, 1), (np.uint32, 4), (np.uint16, 2)):
+        info = np.iinfo(dt)
+        base = rng.integers(max(info.min, -5000), min(info.max, 5000), 7001).astype(dt)
+        for n in (0, 100, 9000, 32768, 70001, 150000, 300001):
+            cases.append((np.tile(base, n // len(base) + 1)[:n].copy(), size))                    # period 7001 values
+        cases.append((rng.integers(info.min // 2, info.max // 2, 50000).astype(dt), size))        # nothing to find
+        wavy = np.tile(base, 20)[:120000].copy()
+        wavy[::977] = wavy[::977] + 1                                                              # the period, with mismatches
+        cases.append((wavy.astype(dt), size))
+    for zz in (True, False):
+        for sized in (False, True):
+            bufs = [a for a, _ in cases]
+            for size in (1, 2, 4):
+                sel = [a for a, sz in cases if sz == size]
+                go, oo = _lib.CompressionOptions(zz, size, 4, 0), O.options(zz, size, 4, 0)
+                frames = G.compress(sel, go, sized=sized)
+                back = G.decompress(frames, [a.nbytes for a in sel], go, sized=sized)
+                for a, f, b in zip(sel, frames, back):
+                    assert not isinstance(f, int) and not isinstance(b, int), (len(a), size, zz, sized)
+                    assert b.tobytes() == a.tobytes()
+                    assert O.decompress(f, a.nbytes, oo, sized=sized).tobytes() == a.tobytes()
+                    if len(a) >= 32768 and len(a) <= 150000:
+                        ref = O.compress(a, oo, sized=sized)      # libzstd level 4
+                        assert len(f) <= 1.6 * len(ref) + 64 or len(f) <= 0.45 * a.nbytes, (len(a), size, zz, len(f), len(ref))

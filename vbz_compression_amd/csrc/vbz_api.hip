@@ -321,12 +321,14 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, false, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
     uint32_t num, den;
     svb_factor(o->integer_size, o->perform_delta_zig_zag, &num, &den);
+    // level >= 4 (long-repeat matcher): room behind every stream for one record per 16 data bytes and a mask bit per byte
+    if (o->zstd_compression_level >= 4 && !segmented) num *= 2;
     const size_t scratch_need = (size_t)(((unsigned __int128)bt->src_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
     if (!ensure(c, c->scratch, scratch_need)) return -1;
     if (!ensure(c, c->meta, (size_t)n * 32 + 256)) return -1;
@@ -385,7 +387,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     {
         Timed t(c, "zstd_encode");
         HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, c->zero_run_sequences ? svb_cap : nullptr,
-                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, s),
+                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, o->zstd_compression_level >= 4, s),
                "zstd_encode launch");
     }
     dbg_end(c, n, "zstd_encode: setup hist plan size hdr encode", dbg);
@@ -671,7 +673,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, false, c->stream), "zstd_encode launch");
     return 0;
 }
 

@@ -60,9 +60,10 @@ hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigz
 // src_cap + seq_tables (both nullable): the source streams live in library-owned scratch slots of that
 // capacity, which lets the encoder rewrite the control-byte region as literals + zero-run sequences.
 // trailers: append the decoder-checkpoint skippable frame when a sequences section was written (see zstd_encode.hip)
+// deep: also look for one long repeat distance in the data bytes (zstd_compression_level >= 4)
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              hipStream_t s);
+                              bool deep, hipStream_t s);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);
 // The same stage for batches of few, large reads: one wavefront per SPAN of a read's stream (see zstd_encode.hip).

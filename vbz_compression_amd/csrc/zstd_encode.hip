@@ -430,7 +430,11 @@ __device__ __forceinline__ uint64_t dilate_left(uint64_t w, uint32_t r)  // bit 
 
 // all lanes.  Compacts the literals of k[0..K) in place (k[0..Lit)) and writes one record per qualifying
 // run, in order: rec[j] = (end position of the run, literals before that position).
-__device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit, uint32_t& nrec, int lane)
+// PERIOD: the mask "byte p equals byte p - D" was computed beforehand (period_mask) and is read from `mask16` (one 16-bit
+// word per 16 positions); a run of RPER or more such positions is one match, none of its bytes stays a literal.
+constexpr uint32_t RPER = 16;
+template <bool PERIOD>
+__device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit, uint32_t& nrec, const uint16_t* mask16, int lane)
 {
     uint32_t lit_total = 0, rec_total = 0;
     uint32_t carry60 = 0, carry61 = 0;  // masks of the 32 positions in front of the payload
@@ -447,7 +451,9 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
             const uint32_t nvalid = (K - (uint32_t)lo) >= 16 ? 16u : (K - (uint32_t)lo);
             valid = nvalid >= 16 ? 0xFFFFu : ((1u << nvalid) - 1u);
         }
-        {
+        if (PERIOD) {
+            zm = (lane >= 2 && lo < (int64_t)K) ? (uint32_t)mask16[(uint32_t)lo >> 4] & valid : 0u;
+        } else {
             // bit i of the mask: byte i equals the byte in front of it (a run of r equal bytes is r - 1 ones)
             uint32_t pw = (uint32_t)__shfl_up((int)w[3], 1, 64);
             if (lane == 2) pw = carryw;
@@ -460,8 +466,13 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
             zm &= valid;
             if (lane == 2 && pb == 0) zm &= ~1u;  // nothing in front of the first byte
         }
-        if (lane == 0) zm = carry60;
-        if (lane == 1) zm = carry61;
+        if (!PERIOD) {
+            if (lane == 0) zm = carry60;
+            if (lane == 1) zm = carry61;
+        } else if (lane < 2) {  // the 32 positions in front of the payload: their masks are in memory too
+            const int64_t lb = (int64_t)pb + 16 * ((int64_t)lane - 2);
+            zm = lb >= 0 ? (uint32_t)mask16[(uint32_t)lb >> 4] : 0u;
+        }
         uint32_t m1 = (uint32_t)__shfl_up((int)zm, 1, 64), m2 = (uint32_t)__shfl_up((int)zm, 2, 64);
         uint32_t p1 = (uint32_t)__shfl_down((int)zm, 1, 64), p2 = (uint32_t)__shfl_down((int)zm, 2, 64);
         if (lane < 1) m1 = 0;
@@ -471,7 +482,8 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
         // window bit j <-> position lo - 24 + j
         const uint64_t W = (uint64_t)((m2 >> 8) & 0xFF) | ((uint64_t)m1 << 8) | ((uint64_t)zm << 24) | ((uint64_t)p1 << 40) |
                            ((uint64_t)(p2 & 0xFF) << 56);
-        const uint64_t RM = dilate_left(erode_right(W, RMIN - 1), RMIN - 1);  // runs of >= RMIN equal bytes, without their first byte
+        // d = 1: runs of >= RMIN equal bytes, without their first byte; period: runs of >= RPER matching positions
+        const uint64_t RM = PERIOD ? dilate_left(erode_right(W, RPER), RPER) : dilate_left(erode_right(W, RMIN - 1), RMIN - 1);
         const uint64_t END = RM & ~(RM >> 1);                                  // last position of such a run
         const bool payload = lane >= 2 && lane < 62;
         const uint32_t r16 = payload ? (uint32_t)(RM >> 24) & 0xFFFFu : 0u;
@@ -507,6 +519,87 @@ __device__ void tokenise_zero_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t&
     nrec = rec_total;
 }
 
+// ---- long repeats at ONE distance (zstd_compression_level >= 4) ---------------------------------------------------------
+// Signal that repeats a template (the reference's own perf generator cycles a 15 643-sample read: vbz/perf/
+// test_data_generator.h:61-67) makes the data bytes of the svb stream periodic; libzstd's match finder turns every period
+// after the first into one long match.  The device equivalent looks for ONE distance D per region: an 8-byte probe from the
+// front of the region is searched for further down (all lanes, 16 positions each per trip), the first hit gives D, two
+// more places confirm it; then every position is marked "equals the byte D before" and runs of RPER or more marked
+// positions become sequences with the explicit offset D (OF table in RLE mode with code floor(log2(D + 3))).
+// Returns 0 when the region shows no such distance.
+__device__ uint32_t detect_period(const uint8_t* in, uint32_t S, int lane)
+{
+    if (S < 8192) return 0;
+    const uint32_t p0 = 256;
+    uint32_t pr[2];
+    __builtin_memcpy(pr, in + p0, 8);
+    // a probe of one repeated byte would find runs, not periods
+    if (pr[0] == pr[1] && pr[0] == ((pr[0] & 0xFFu) * 0x01010101u)) return 0;
+    uint32_t D = 0;
+    for (uint32_t q0 = p0 + 8; q0 + 24 <= S; q0 += 16 * WAVE) {
+        const uint32_t q = q0 + 16u * (uint32_t)lane;
+        uint32_t w[6] = { 0, 0, 0, 0, 0, 0 };
+        uint32_t hit = 0;
+        if (q + 24 <= S) {
+            uint4 a;
+            uint2 c;
+            __builtin_memcpy(&a, in + q, 16);
+            __builtin_memcpy(&c, in + q + 16, 8);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t lo = __builtin_amdgcn_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3);
+                const uint32_t hi = __builtin_amdgcn_alignbyte(w[(i >> 2) + 2], w[(i >> 2) + 1], i & 3);
+                hit |= (lo == pr[0] && hi == pr[1]) ? (1u << i) : 0u;
+            }
+        }
+        const uint64_t any = __ballot(hit != 0);
+        if (any) {
+            const int fl = __ffsll((long long)any) - 1;
+            const uint32_t fh = (uint32_t)__shfl((int)hit, fl, 64);
+            D = q0 + 16u * (uint32_t)fl + ((uint32_t)__ffs((int)fh) - 1u) - p0;
+            break;
+        }
+    }
+    if (D == 0 || D < 64) return 0;  // (short distances: the d = 1 tokeniser and the Huffman code do better)
+    // eight more places are asked (one lane each); most of them must agree (a template repeated with a few changed samples
+    // still matches nearly everywhere)
+    bool agree = false;
+    if (lane < 8) {
+        const uint32_t t = D + 8u + (uint32_t)(((uint64_t)(S - D - 16u) * (uint32_t)lane) / 8u);  // spread over what has a predecessor
+        if (S >= D + 32u && t >= D + 8 && t + 8 <= S) {
+            uint32_t x[2], y[2];
+            __builtin_memcpy(x, in + t, 8);
+            __builtin_memcpy(y, in + t - D, 8);
+            agree = x[0] == y[0] && x[1] == y[1];
+        }
+    }
+    const bool ok = __popcll(__ballot(agree)) >= 5;
+    return ok ? D : 0u;
+}
+
+// all lanes: mask16[p >> 4] bit (p & 15) = byte p equals byte p - D (0 for p < D)
+__device__ void period_mask(const uint8_t* in, uint32_t S, uint32_t D, uint16_t* mask16, int lane)
+{
+    for (uint32_t q0 = 0; q0 < S; q0 += 16 * WAVE) {
+        const uint32_t q = q0 + 16u * (uint32_t)lane;
+        if (q >= S) continue;
+        uint32_t m = 0;
+        if (q >= D) {
+            uint4 a, c;
+            __builtin_memcpy(&a, in + q, 16);       // (16+ bytes of slack behind the stream)
+            __builtin_memcpy(&c, in + q - D, 16);
+            const uint32_t x[4] = { a.x ^ c.x, a.y ^ c.y, a.z ^ c.z, a.w ^ c.w };
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m |= (((x[i >> 2] >> (8 * (i & 3))) & 0xFF) == 0 ? 1u : 0u) << i;
+        } else if (q + 16 > D) {
+            for (uint32_t i = D - q; i < 16; ++i) m |= (in[q + i] == in[q + i - D] ? 1u : 0u) << i;
+        }
+        const uint32_t nvalid = (S - q) >= 16 ? 16u : (S - q);
+        mask16[q >> 4] = (uint16_t)(m & (nvalid >= 16 ? 0xFFFFu : ((1u << nvalid) - 1u)));
+    }
+}
+
 // Decoder checkpoints.  The LL / ML state chain of a sequences section is serial for a decoder that starts at
 // the top of the bit stream; the encoder knows every intermediate state, so it publishes one checkpoint per
 // CP spacing sequences -- (unread bits, LL state, ML state) before sequence k * spacing -- in a zstd *skippable
@@ -524,8 +617,12 @@ constexpr uint32_t CP_MIN_SPACING = 32;
 // codes and extra bits; wave-uniform scalar code walks the two independent FSE state chains (match length / literal
 // length) and leave each step's output bits in LDS; every lane then assembles the <= 44 bits of its sequence,
 // a wave prefix sum places them, and the chunk is written out as dwords.  Returns the bytes written.
-__device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uint2* rec, uint32_t nseq, int lane)
+// of_dist: 0 = every sequence copies from repeat offset 1 (runs; OF code 0, checkpoints recorded); otherwise every sequence
+// carries the explicit distance of_dist (OF code floor(log2(of_dist + 3)), that many extra bits; no checkpoints).
+__device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uint2* rec, uint32_t nseq, int lane, uint32_t of_dist = 0)
 {
+    const uint32_t of_code = of_dist ? (uint32_t)hb32(of_dist + 3u) : 0u;
+    const uint32_t of_extra = of_dist ? (of_dist + 3u) - (1u << of_code) : 0u;
     uint32_t hdr = 0;
     if (lane == 0) {
         uint8_t* op = dst;
@@ -533,7 +630,7 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
         else if (nseq < 0x7F00) { *op++ = (uint8_t)((nseq >> 8) + 128); *op++ = (uint8_t)nseq; }
         else { *op++ = 255; *op++ = (uint8_t)(nseq - 0x7F00); *op++ = (uint8_t)((nseq - 0x7F00) >> 8); }
         *op++ = 0x10;  // LL predefined | OF RLE | ML predefined
-        *op++ = 0;     // OF code 0
+        *op++ = (uint8_t)of_code;
         hdr = (uint32_t)(op - dst);
     }
     hdr = (uint32_t)__shfl((int)hdr, 0, 64);
@@ -552,7 +649,7 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
     uint32_t base_bits = 0, flushed = 0;
     uint32_t spacing = CP_MIN_SPACING;  // at most 63 checkpoints + the start = 64 decoder lanes
     while ((nseq + spacing - 1) / spacing > 64) spacing *= 2;
-    if (lane == 0) {
+    if (lane == 0 && of_dist == 0) {
         L.cpSpacing = spacing;
         L.cpCount = (nseq - 1) / spacing;
     }
@@ -604,13 +701,15 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
             len += lnb;
             v |= (uint64_t)mex << len;
             len += mnb;
+            v |= (uint64_t)of_extra << len;   // (at most 44 + 17 bits)
+            len += of_code;
         }
         const uint32_t incl = wave_incl_scan_u32(len);
         const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
         const uint32_t pos = base_bits + incl - len;
         if (t < nseq) {
             const uint32_t n = nseq - 1 - t;  // checkpoint: everything up to and including this sequence's bits is unread
-            if (n != 0 && n % spacing == 0)
+            if (of_dist == 0 && n != 0 && n % spacing == 0)
                 L.cp[n / spacing - 1] = (8u * flushed + base_bits + incl) | ((plv >> 24) << 20) | ((pmv >> 24) << 26);
         }
         if (len) {
@@ -753,15 +852,46 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     if (span_mode) T = SPAN_BLOCK;
 
     bool keys_one_block = false;
-    for (int region = 0; region < (span_mode ? 1 : 2); ++region) {
-        const uint32_t r0 = span_mode ? sp.r0 : (region == 0 ? 0 : K);
-        const uint32_t r1 = span_mode ? sp.r1 : (region == 0 ? (K ? K : N) : N);
+    // level >= 4 (one wavefront per frame only): look for one repeat distance in the data bytes.  Behind the stream, below
+    // the control-byte region's records: the data bytes' records, and below them one mask bit per data byte.  A data
+    // region of more than a block is then coded in chunks of at most a block (a match may not cross a block boundary).
+    uint32_t deepD = 0, nunit = 2, chunk = 0;
+    uint16_t* mask16 = nullptr;
+    uint8_t* deep_recs = nullptr;
+    if (!span_mode && (trailers & 2u) && K != 0 && src_cap && seqtab && N - K >= 8192) {
+        const uint32_t SD = N - K, slot = src_cap[r];
+        const uint32_t nch = (SD + (BLOCK_MAX - 16u) - 1u) / (BLOCK_MAX - 16u);
+        const uint32_t recs_keys = K / RMIN + 4u;
+        const uint32_t recs_data = SD / RPER + 2u * nch + 2u;
+        const uint32_t mask_bytes = 2u * ((SD + 15u) >> 4) + 16u;
+        const uint64_t need = (uint64_t)N + 16 + 8ull * (recs_keys + recs_data) + mask_bytes + 16;
+        if (need <= slot) {
+            const uint32_t keybase = (slot - 8u * recs_keys) & ~7u;
+            const uint32_t recbase = keybase - 8u * recs_data;
+            const uint32_t maskbase = (recbase - mask_bytes) & ~1u;
+            const uint32_t D = detect_period(in + K, SD, lane);
+            if (D) {
+                uint8_t* base = const_cast<uint8_t*>(in);
+                mask16 = reinterpret_cast<uint16_t*>(base + maskbase);
+                deep_recs = base + recbase;
+                period_mask(in + K, SD, D, mask16, lane);
+                __syncthreads();
+                deepD = D;
+                chunk = ((SD + nch - 1u) / nch + 15u) & ~15u;
+                nunit = 1u + nch;
+            }
+        }
+    }
+    for (int region = 0; region < (span_mode ? 1 : (int)nunit); ++region) {
+        const uint32_t cidx = region > 0 ? (uint32_t)region - 1u : 0u;  // chunk of the data region (0 unless long repeats were found)
+        const uint32_t r0 = span_mode ? sp.r0 : (region == 0 ? 0 : K + cidx * chunk);
+        const uint32_t r1 = span_mode ? sp.r1 : (region == 0 ? (K ? K : N) : ((deepD && N - r0 > chunk) ? r0 + chunk : N));
         if (region == 1 && K == 0) break;
         uint32_t S = r1 - r0;
         const bool lastRegion = span_mode ? (sp.flags & SPAN_LAST) != 0 : (r1 == N);
         const uint8_t* rin = in + r0;
         uint32_t nblk = (S + T - 1) / T;
-        if (region == 1 && keys_one_block) {
+        if (region >= 1 && keys_one_block) {
             // the control bytes took one block (4 streams): the data bytes get the other 15 x 4 lanes of the decoder
             uint32_t Td = (S + DATA_BLOCKS - 1) / DATA_BLOCKS;
             Td = Td < MIN_BLOCK ? MIN_BLOCK : (Td > BLOCK_MAX ? BLOCK_MAX : Td);
@@ -785,7 +915,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             if (need <= slot) {
                 uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * recs_all) & ~7u) + 8u * (r0 / RMIN + 2u * ord);
                 uint32_t Lit = 0;
-                tokenise_zero_runs(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, lane);
+                tokenise_runs<false>(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, nullptr, lane);
                 __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
                 if (nrec) {
                     seqmode = true;
@@ -794,6 +924,20 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     nblk = 1;
                     keys_one_block = true;
                 }
+            }
+        }
+        uint32_t of_dist = 0;  // != 0: this region's sequences carry this explicit distance (long repeats)
+        if (deepD && region >= 1) {
+            uint32_t Lit = 0;
+            uint2* recs = reinterpret_cast<uint2*>(deep_recs + 8u * ((r0 - K) / RPER + 2u * cidx));
+            tokenise_runs<true>(const_cast<uint8_t*>(rin), S, recs, Lit, nrec, mask16 + ((r0 - K) >> 4), lane);
+            __syncthreads();
+            if (nrec) {  // (without a single match nothing was moved)
+                seqmode = true;
+                of_dist = deepD;
+                rec = recs;
+                S = Lit;
+                nblk = 1;
             }
         }
         PHASE(0);
@@ -814,8 +958,8 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 else put_le(bp + 3, (S << 4) | 12u, 3);
             }
             for (uint32_t i = lane; i < S; i += WAVE) bp[3 + lh + i] = rin[i];
-            const uint32_t sb = encode_zero_run_sequences(L, bp + 3 + lh + S, rec, nrec, lane);
-            frame_cp = true;
+            const uint32_t sb = encode_zero_run_sequences(L, bp + 3 + lh + S, rec, nrec, lane, of_dist);
+            frame_cp = frame_cp || of_dist == 0;
             if (lane == 0) put_le(bp, ((lh + S + sb) << 3) | (2u << 1) | (lastRegion ? 1u : 0u), 3);
             opos += 3 + lh + S + sb;
             continue;
@@ -1048,8 +1192,8 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                             uint32_t seqBytes = 1;  // a plain block ends with Number_of_Sequences = 0
                             if (seqmode) {
                                 if ((uint64_t)spos + 8 + 8ull * nrec > cap) { FINISH(E_ZSTD); return; }
-                                seqBytes = encode_zero_run_sequences(L, out + spos, rec, nrec, lane);
-                                frame_cp = true;
+                                seqBytes = encode_zero_run_sequences(L, out + spos, rec, nrec, lane, of_dist);
+                                frame_cp = frame_cp || of_dist == 0;
                                 wave_lds_sync();
                                 for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;  // it used the bit buffer
                                 wave_lds_sync();
@@ -1092,7 +1236,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         }
     }
     const uint32_t main_bytes = opos;
-    if (frame_cp && trailers && (!span_mode || (sp.flags & SPAN_FIRST))) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
+    if (frame_cp && (trailers & 1u) && (!span_mode || (sp.flags & SPAN_FIRST))) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
         wave_lds_sync();
         const uint32_t count = L.cpCount, tb = 8u + 4u + 4u * count + 4u;
         if (count != 0 && (uint64_t)opos + tb <= cap) {
@@ -1349,9 +1493,9 @@ __global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, con
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              hipStream_t s)
+                              bool deep, hipStream_t s)
 {
-    const uint32_t tr = trailers ? 1u : 0u;
+    const uint32_t tr = (trailers ? 1u : 0u) | (deep ? 2u : 0u);
     if (b.n_reads == 0) return hipSuccess;
     if (dbg)
         hipLaunchKernelGGL(zstd_encode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
