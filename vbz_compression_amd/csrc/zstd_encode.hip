@@ -773,7 +773,8 @@ __device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN,
 #endif
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
-template <bool TIMED>
+// DEEP: with the long-repeat matcher (level >= 4); a separate instantiation so that the ordinary kernel does not carry its registers
+template <bool TIMED, bool DEEP>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab, const EncSpan* spans,
@@ -858,7 +859,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     uint32_t deepD = 0, nunit = 2, chunk = 0;
     uint16_t* mask16 = nullptr;
     uint8_t* deep_recs = nullptr;
-    if (!span_mode && (trailers & 2u) && K != 0 && src_cap && seqtab && N - K >= 8192) {
+    if (DEEP && !span_mode && K != 0 && src_cap && seqtab && N - K >= 8192) {
         const uint32_t SD = N - K, slot = src_cap[r];
         const uint32_t nch = (SD + (BLOCK_MAX - 16u) - 1u) / (BLOCK_MAX - 16u);
         const uint32_t recs_keys = K / RMIN + 4u;
@@ -927,7 +928,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             }
         }
         uint32_t of_dist = 0;  // != 0: this region's sequences carry this explicit distance (long repeats)
-        if (deepD && region >= 1) {
+        if (DEEP && deepD && region >= 1) {
             uint32_t Lit = 0;
             uint2* recs = reinterpret_cast<uint2*>(deep_recs + 8u * ((r0 - K) / RPER + 2u * cidx));
             tokenise_runs<true>(const_cast<uint8_t*>(rin), S, recs, Lit, nrec, mask16 + ((r0 - K) >> 4), lane);
@@ -1495,13 +1496,16 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
                               bool deep, hipStream_t s)
 {
-    const uint32_t tr = (trailers ? 1u : 0u) | (deep ? 2u : 0u);
+    const uint32_t tr = trailers ? 1u : 0u;
     if (b.n_reads == 0) return hipSuccess;
     if (dbg)
-        hipLaunchKernelGGL(zstd_encode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+        hipLaunchKernelGGL((zstd_encode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
+    else if (deep)
+        hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                            src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
     else
-        hipLaunchKernelGGL(zstd_encode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+        hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                            src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
     return hipGetLastError();
 }
@@ -1530,7 +1534,7 @@ hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_siz
     EncSpan* spans = reinterpret_cast<EncSpan*>(span_desc);
     hipLaunchKernelGGL(zstd_span_plan_kernel, dim3(1), dim3(1024), 0, s, b.n_reads, b.src_size, orig_size, key_elem, b.gate,
                        (src_cap && seq_tables) ? 1u : 0u, max_spans, span_tmp_bytes, spans, span_first, span_count);
-    hipLaunchKernelGGL(zstd_encode_kernel<false>, dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
+    hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
                        reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u);
     hipLaunchKernelGGL(zstd_span_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, hdr, spans, span_first, max_spans, span_size, span_trail,
                        span_dst, index_trailer ? 1u : 0u);
