@@ -183,3 +183,36 @@ def test_trailers_are_an_option_of_the_context():
             assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes()
         back = G.decompress([w, p], [a.nbytes, a.nbytes], go)
         assert back[0].tobytes() == a.tobytes() and back[1].tobytes() == a.tobytes()
+
+
+def test_buffer_that_ends_like_a_trailer_size():
+    """The trailers are found from the END of the buffer (their last word is their size).  A plain frame whose last bytes
+    happen to look like a size -- e.g. int16 samples stored without zig-zag whose last value is -8: the stream ends in
+    f8 ff ff ff -- must not send the decoder anywhere (found by tools/soak.py: 0xFFFFFFF8 + 16 wrapped around)."""
+    rng = np.random.default_rng(31)
+    go, oo = _lib.CompressionOptions(False, 2, 1, 0), O.options(False, 2, 1, 0)
+    reads = []
+    for last in (-8, -16, -24, -1, 24, 32, 64, 200, 272, 280):
+        for n in (40, 64, 200):
+            a = rng.integers(-32768, 32767, n, endpoint=True).astype(np.int16)
+            a[-1] = last
+            a[-2] = -1 if last < 0 else 0
+            reads.append(a)
+    for sized in (False, True):
+        frames = G.compress(reads, go, sized=sized)
+        back = G.decompress(frames, [a.nbytes for a in reads], go, sized=sized)
+        for a, f, b in zip(reads, frames, back):
+            assert not isinstance(f, int) and not isinstance(b, int)
+            assert b.tobytes() == a.tobytes()
+            assert O.decompress(f, a.nbytes, oo, sized=sized).tobytes() == a.tobytes()
+    # and arbitrary tails behind a valid frame body: whatever the last word says, the verdict is libzstd's
+    base = G.compress([O.synth_signal(5, 40, 30000)], _lib.CompressionOptions(True, 2, 1, 1))[0]
+    body, _ = _trailers(base)
+    variants = []
+    for tail in (0xFFFFFFF8, 0xFFFFFFF0, 0x18, 0x20, 0x110, len(body) - 8, len(body) + 8):
+        junk = np.concatenate([rng.integers(0, 256, 40, dtype=np.uint8), np.array([tail & 0xFFFFFFFF], "<u4").view(np.uint8)])
+        variants.append(np.concatenate([body, junk]))
+    got = G.decompress(variants, [60000] * len(variants), _lib.CompressionOptions(True, 2, 1, 1))
+    for v, gq in zip(variants, got):
+        lz = O.decompress(v, 60000, O.options(True, 2, 1, 1))
+        assert isinstance(gq, int) == isinstance(lz, int), (gq if isinstance(gq, int) else "data", lz if isinstance(lz, int) else "data")

@@ -4,7 +4,8 @@
     python tools/soak.py [--seconds 120] [--seed 1]
 
 Every round draws a batch of reads of random lengths and shapes (nanopore-like signal, noise, constants, ramps,
-extreme values, sparse spikes) and a random option set, then checks, read by read:
+extreme values, sparse spikes, repeated templates; every fourth round few large reads, which take the large-read path)
+and a random option set (levels 0, 1, 3, 4), then checks, read by read:
   * GPU compress -> oracle (reference path + libzstd) decompress == input
   * oracle compress -> GPU decompress == input
   * GPU compress -> GPU decompress == input
@@ -38,6 +39,13 @@ def make_read(rng, dt, kind, n):
         a = (np.arange(n) * int(rng.integers(1, 1000)) + int(rng.integers(0, 1000))) % (int(info.max) - int(info.min) + 1) + int(info.min)
     elif kind == 4:  # alternating extremes
         a = np.where(np.arange(n) & 1, info.max, info.min)
+    elif kind == 6:  # a template repeated, with a few changed values (what the level >= 4 matcher is for)
+        per = int(rng.integers(50, 9000))
+        t = make_read(rng, dt, int(rng.integers(0, 2)), per).astype(np.int64)
+        a = np.tile(t, n // per + 1)[:n].copy()
+        if n and rng.random() < 0.5:
+            k = max(1, n // 3001)
+            a[rng.integers(0, n, k)] = rng.integers(info.min, info.max, k, endpoint=True)
     else:  # sparse spikes on a flat line
         a = np.full(n, int(rng.integers(-100, 100)) if info.min < 0 else 7)
         k = max(1, n // 97)
@@ -50,6 +58,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--start-round", type=int, default=0, help="draw the earlier rounds' data (same random stream) but do not run them")
+    ap.add_argument("--verbose", action="store_true", help="print every round's parameters before it runs (to find a crashing one)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
@@ -58,12 +68,21 @@ def main():
         size = int(rng.choice([1, 2, 2, 2, 4]))
         dt = {1: np.int8, 2: np.int16, 4: np.int32}[size] if rng.random() < 0.7 else {1: np.uint8, 2: np.uint16, 4: np.uint32}[size]
         zz = bool(rng.integers(0, 2))
-        level = int(rng.choice([0, 1, 1, 3]))
+        level = int(rng.choice([0, 1, 1, 3, 4, 4]))
         ver = int(rng.integers(0, 2))
         sized = bool(rng.integers(0, 2))
-        lens = [int(x) for x in rng.choice([0, 1, 2, 3, 5, 63, 64, 65, 255, 257, 1000, 4095, 4097, 20000, 100003, 300001], 24)]
-        lens += [int(x) for x in rng.integers(0, 150000, 8)]
-        bufs = [make_read(rng, dt, int(rng.integers(0, 6)), n) for n in lens]
+        if rng.random() < 0.25:  # few, large reads: the large-read path (segments and spans)
+            lens = [int(x) for x in rng.integers(300000, 1500000, int(rng.integers(1, 4)))]
+            lens += [int(x) for x in rng.choice([0, 5, 4097, 700001, 1048576], 2)]
+        else:
+            lens = [int(x) for x in rng.choice([0, 1, 2, 3, 5, 63, 64, 65, 255, 257, 1000, 4095, 4097, 20000, 100003, 300001], 24)]
+            lens += [int(x) for x in rng.integers(0, 150000, 8)]
+        bufs = [make_read(rng, dt, int(rng.integers(0, 7)), n) for n in lens]
+        if rounds < args.start_round:
+            rounds += 1
+            continue
+        if args.verbose:
+            print("round %d: dtype %s zigzag %d level %d version %d sized %d lens %s" % (rounds, np.dtype(dt).name, zz, level, ver, sized, lens), flush=True)
         go = G.codec().options(zz, size, level, ver)
         oo = O.options(zz, size, level, ver)
         gc = G.compress(bufs, go, sized=sized)

@@ -61,6 +61,7 @@ struct vbz_gpu_ctx
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
     bool phase_timing = false;
+    bool trace = false;        // VBZ_HIP_TRACE=1: synchronise after every launch group and name it on stderr (to find a faulting kernel)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     bool profiling = false;
@@ -128,6 +129,10 @@ struct Timed  // records a pair of events around one kernel launch when profilin
     }
     ~Timed()
     {
+        if (c->trace) {
+            const hipError_t e = hipStreamSynchronize(c->stream);
+            fprintf(stderr, "vbz_hip trace: %s %s\n", name, e == hipSuccess ? "ok" : hipGetErrorString(e));
+        }
         if (start) {
             hipEvent_t stop = get_event(c);
             (void)hipEventRecord(stop, c->stream);
@@ -544,6 +549,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     vbz_gpu_ctx* c = new vbz_gpu_ctx();
     c->device = device;
     if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_TRACE")) c->trace = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;

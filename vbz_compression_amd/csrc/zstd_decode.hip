@@ -1702,7 +1702,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     if (n >= 64) {
         uint32_t tb, ne = n;  // ne: where the checkpoint trailer would end (an index trailer may follow it)
         __builtin_memcpy(&tb, src + n - 4, 4);
-        if (tb >= 24 && tb + 16 <= n && (tb & 7u) == 0) {
+        if (tb >= 24 && tb <= n - 16 && (tb & 7u) == 0) {  // (n >= 64; no sum that could wrap: these are arbitrary bytes)
             uint32_t m[2];
             __builtin_memcpy(m, src + n - tb, 8);
             if (m[0] == IDX_MAGIC && m[1] == tb - 8) {
