@@ -216,3 +216,38 @@ def test_buffer_that_ends_like_a_trailer_size():
     for v, gq in zip(variants, got):
         lz = O.decompress(v, 60000, O.options(True, 2, 1, 1))
         assert isinstance(gq, int) == isinstance(lz, int), (gq if isinstance(gq, int) else "data", lz if isinstance(lz, int) else "data")
+
+
+def test_last_block_flag_inside_a_large_frame():
+    """A frame that says "last block" in the middle ends there for every zstd decoder; the rest is trailing garbage and
+    libzstd refuses the buffer.  The span decoder must not read on past it (found by tools/soak_corrupt.py: a span whose
+    final block carried the flag still ended where the next span starts)."""
+    a = O.synth_signal(5, 2, 1_000_000)
+    o = (True, 2, 1, 1)
+    go, oo = _lib.CompressionOptions(*o), O.options(*o)
+    g = G.compress([a], go)[0]
+    body, tr = _trailers(g)
+    idx = [t for t in tr if int(t[:4].view("<u4")[0]) == IDX_MAGIC][0]
+    ns = int(idx[8:12].view("<u4")[0])
+    starts = [int(idx[12 + 8 * j : 16 + 8 * j].view("<u4")[0]) for j in range(ns)]
+    # walk the blocks of the frame (3-byte headers: last | type << 1 | size << 3; an RLE block holds one byte)
+    pos, blocks = starts[0], []
+    while True:
+        h = int(body[pos]) | int(body[pos + 1]) << 8 | int(body[pos + 2]) << 16
+        blocks.append(pos)
+        pos += 3 + (1 if (h >> 1) & 3 == 1 else h >> 3)
+        if h & 1:
+            break
+    assert pos == len(body) and set(starts) <= set(blocks)
+    variants = []
+    for k in (1, ns // 2, ns - 1):                      # the final block of span k - 1 ...
+        d = g.copy()
+        d[blocks[blocks.index(starts[k]) - 1]] |= 1
+        variants.append(d)
+    d = g.copy()
+    d[blocks[blocks.index(starts[ns // 2]) + 1]] |= 1   # ... and a block in the middle of a span
+    variants.append(d)
+    got = G.decompress(variants, [a.nbytes] * len(variants), go)
+    for v, gq in zip(variants, got):
+        assert isinstance(O.decompress(v, a.nbytes, oo), int)
+        assert isinstance(gq, int), "the device decoded a frame that ends in the middle"

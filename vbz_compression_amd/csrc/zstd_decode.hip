@@ -2367,7 +2367,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             }
             pos += bsize;
         }
-        if (last) break;
+        if (last) {
+            if (partial && !(sp.flags & DSPAN_LAST)) FAIL();  // the frame ends here: nothing of it may follow in later spans
+            break;
+        }
         if (partial && !(sp.flags & DSPAN_LAST)) {
             if (pos == sp.src_end) break;
             if (pos > sp.src_end) FAIL();
