@@ -23,9 +23,10 @@ def lib():
     return _lib
 
 
-def tree_description(data):
+def tree_description(data, package_merge=False):
     """(table log, code lengths[256], tree description bytes) for the byte histogram of `data`,
-    as libzstd's HUF_buildCTable / HUF_writeCTable produce them for a block of len(data) <= 128 KiB."""
+    as libzstd's HUF_buildCTable / HUF_writeCTable produce them for a block of len(data) <= 128 KiB;
+    package_merge: code lengths by huf_build_pm (what the device encoder builds) instead of libzstd's construction."""
     H = lib()
     data = np.ascontiguousarray(data, dtype=np.uint8)
     cnt = np.bincount(data, minlength=256).astype(np.uint32)
@@ -35,7 +36,7 @@ def tree_description(data):
     hl = H.h_optimal_table_log(11, n, maxsym, 1)
     nb = np.zeros(256, np.uint8)
     code = np.zeros(256, np.uint16)
-    tl = H.h_huf_build(cnt.ctypes.data_as(u32p), maxsym, hl, nb.ctypes.data_as(u8p), code.ctypes.data_as(u16p))
+    tl = (H.h_huf_build_pm if package_merge else H.h_huf_build)(cnt.ctypes.data_as(u32p), maxsym, hl, nb.ctypes.data_as(u8p), code.ctypes.data_as(u16p))
     out = np.zeros(300, np.uint8)
     ts = H.h_huf_write_tree(out.ctypes.data_as(u8p), 300, nb.ctypes.data_as(u8p), maxsym, tl)
     return tl, nb, (bytes(out[:ts]) if ts > 0 else None)

@@ -14,6 +14,12 @@ int h_huf_build(const uint32_t* count, uint32_t maxSymbolValue, uint32_t maxNbBi
     return (int)huf_build(count, maxSymbolValue, maxNbBits, nbBits, code, &w);
 }
 
+int h_huf_build_pm(const uint32_t* count, uint32_t maxSymbolValue, uint32_t maxNbBits, uint8_t* nbBits, uint16_t* code)
+{
+    static HufPmWksp w;
+    return (int)huf_build_pm(count, maxSymbolValue, maxNbBits, nbBits, code, &w);
+}
+
 uint32_t h_optimal_table_log(uint32_t maxTableLog, uint32_t srcSize, uint32_t maxSymbolValue, uint32_t minus)
 {
     return optimal_table_log(maxTableLog, srcSize, maxSymbolValue, minus);

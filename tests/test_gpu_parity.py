@@ -714,9 +714,10 @@ def test_full_size_device_round_trip_properties():
     assert abs(gsum / osum - 1.0) < 0.01, (gsum, osum)                   # T2: size within 1 % of the oracle's on the sample
 
 
-def test_zstd_encoder_tables_match_libzstd_construction():
-    """The wave-parallel table construction on the device must give the tree description that the serial
-    host statement (zstd_entropy.h, itself checked byte-for-byte against libzstd) gives for the same bytes."""
+def test_zstd_encoder_tables_match_host_statement():
+    """The wave-parallel table construction on the device (bitonic sort, package-merge, FSE-coded weights) must give the
+    tree description that its serial host statement gives for the same bytes (zstd_entropy.h: huf_build_pm, checked for
+    optimality on the CPU; huf_write_tree, checked byte-for-byte against libzstd)."""
     import entropy_host as E
     import gpu_util as G
 
@@ -735,7 +736,7 @@ def test_zstd_encoder_tables_match_libzstd_construction():
         lit = E.parse_first_block_literals(f)
         if lit is None or lit[0] != 2:
             continue   # the encoder stored this region raw (too small to pay for a table)
-        log, nb, tree = E.tree_description(data)
+        log, nb, tree = E.tree_description(data, package_merge=True)
         assert lit[3] == tree, len(data)
         checked += 1
     assert checked >= 8

@@ -96,11 +96,8 @@ struct EncLds
     // planned only after this one is written: the two workspaces share their LDS (16 waves per CU instead of 13).
     union
     {
-        struct
-        {
-            HufBuildWksp hw;
-            FseWeightWksp fw;
-        };
+        HufPmWksp pm;       // table construction: sorted leaves, packages, per-level package masks
+        FseWeightWksp fw;   // FSE coding of the weights (after the construction)
         struct
         {
             uint32_t ssize[WAVE];   // compressed bytes of each stream of the current pass
@@ -131,8 +128,8 @@ __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
 // the end; every byte is one branch-free ds_add.
 __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane)
 {
-    static_assert(sizeof(HufBuildWksp) >= 4 * 256 * sizeof(uint32_t), "the sub-histograms live in the tree workspace");
-    uint32_t* sub = reinterpret_cast<uint32_t*>(&L.hw);
+    static_assert(sizeof(HufPmWksp) >= 4 * 256 * sizeof(uint32_t), "the sub-histograms live in the table-construction workspace");
+    uint32_t* sub = reinterpret_cast<uint32_t*>(&L.pm);
     for (int i = lane; i < 4 * 256; i += WAVE) sub[i] = 0;
     wave_lds_sync();
     uint32_t* mine = sub + 256 * (lane & 3);
@@ -169,12 +166,13 @@ __device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int l
 }
 
 // ---- table construction, wave-cooperative ---------------------------------------------------------------
-// Same result as huf_build()/huf_write_tree() of zstd_entropy.h (the serial statement of libzstd's
-// construction, checked against libzstd on the host), but every loop without a loop-carried dependency
-// runs across the 64 lanes: the sort becomes a rank computation (rank = number of symbols with a larger
-// (count, -symbol) key), code lengths come from each leaf walking its parent chain, canonical codes from
-// ballots in symbol order.  Lane 0 keeps only what is inherently serial: the two-queue tree merge, the
-// length-limit repair and the FSE coding of the weights.
+// Code lengths: the present symbols are sorted by a bitonic network over the 64 lanes (four keys per lane), the optimal
+// lengths under the limit come from package-merge with every list of a level merged by the whole wavefront (binary
+// searches of the leaves among the packages and of the packages among the leaves), canonical codes from ballots in symbol
+// order -- the same lengths and codes as huf_build_pm() of zstd_entropy.h, its serial statement, which the CPU suite checks
+// for optimality and the GPU suite against the tree descriptions in the device's frames.  libzstd builds the unlimited
+// Huffman tree and repairs it (HUF_setMaxHeight); package-merge is never longer (0.02 % shorter on signal data) and has no
+// serial chain of 255 merges.  The tree description (huf_write_tree_wave below) is libzstd's for these lengths.
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
 #pragma unroll
@@ -193,101 +191,204 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 }
 
 // all lanes.  L.hist[0..maxSym] -> L.nbBits / L.code; returns the table log (uniform).
-__device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBits, int lane)
+// sub-phase timers of the timed kernel build (tools/phase_timing.py): slots 6.. of the phase counters
+#define SUB(k) do { if (tsub) { unsigned long long tn = __builtin_readcyclecounter(); tsub[k] += tn - *tl; *tl = tn; } } while (0)
+// #{i : arr[i] < v} (STRICT) or #{i : arr[i] <= v} over a sorted array padded with 0xFFFFFFFF; at most 255 (top = the
+// largest power of two <= the number of real entries, wave-uniform).  One LDS read and three VALU operations per step.
+template <bool STRICT>
+__device__ __forceinline__ uint32_t sorted_count(const uint32_t* arr, uint32_t v, uint32_t top)
 {
-    HufNode* const node0 = L.hw.node;
-    HufNode* const node = node0 + 1;
+    uint32_t lo = 0;
+    for (uint32_t step = top; step; step >>= 1) {
+        const uint32_t x = arr[lo + step - 1];
+        lo += (STRICT ? x < v : x <= v) ? step : 0u;
+    }
+    return lo;
+}
+
+__device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBits, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
+{
+    HufPmWksp& K = L.pm;
+    // --- sort the present symbols by (count, 255 - symbol), ascending: bitonic network over 256 keys, element e = 4*lane + j
+    uint32_t key[4];
     {
-        uint2* z = reinterpret_cast<uint2*>(node0);
-        for (int i = lane; i < 513; i += WAVE) z[i] = make_uint2(0u, 0u);
-    }
-    wave_lds_sync();
-    uint32_t c[4], rank[4];
+        const uint4 h = *reinterpret_cast<const uint4*>(&L.hist[4 * lane]);
+        const uint32_t c[4] = { h.x, h.y, h.z, h.w };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t s = (uint32_t)lane + 64u * j;
-        c[j] = s <= maxSym ? L.hist[s] : 0u;
-        rank[j] = 0;
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t sy = 4u * (uint32_t)lane + (uint32_t)j;
+            key[j] = (sy <= maxSym && c[j]) ? ((c[j] << 8) | (255u - sy)) : 0xFFFFFFFFu;
+        }
     }
-    for (uint32_t t0 = 0; t0 <= maxSym; t0 += 8) {
-        // eight counts per trip, the same addresses in every lane: two 16-byte LDS broadcasts, one round trip
-        const uint4 h0 = *reinterpret_cast<const uint4*>(&L.hist[t0]), h1 = *reinterpret_cast<const uint4*>(&L.hist[t0 + 4]);
-        const uint32_t ct8[8] = { h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w };
+    for (int i = lane; i < (HUF_MAX_BITS + 1) * 16; i += WAVE) (&K.isPkg[0][0])[i] = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t t = t0 + (uint32_t)u, ct = ct8[u];
-            if (t <= maxSym) {
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int d = k >> 1; d > 0; d >>= 1) {
+            if (d >= 4) {
+                const int m = d >> 2;  // the partner is m lanes away, same j
+                const bool up = ((4 * lane) & k) == 0, lower = (lane & m) == 0;
+                const bool keep_min = lower == up;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const uint32_t s = (uint32_t)lane + 64u * j;
-                    rank[j] += (ct > c[j]) || (ct == c[j] && t < s);
+                    const uint32_t o = (uint32_t)__shfl_xor((int)key[j], m, 64);
+                    const uint32_t mn = o < key[j] ? o : key[j], mx = o < key[j] ? key[j] : o;
+                    key[j] = keep_min ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int bb = a ^ d;
+                    if (bb > a) {
+                        const bool up = ((4 * lane + a) & k) == 0;
+                        const uint32_t mn = key[a] < key[bb] ? key[a] : key[bb], mx = key[a] < key[bb] ? key[bb] : key[a];
+                        key[a] = up ? mn : mx;
+                        key[bb] = up ? mx : mn;
+                    }
                 }
             }
         }
     }
-    uint32_t mine = 0;
+    uint32_t n = 0;
+    {
+        uint32_t w4 = 0;
+        uint4 lf;
+        uint32_t* lfp = &lf.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t s = (uint32_t)lane + 64u * j;
-        if (s <= maxSym) {
-            node[rank[j]].count = c[j];
-            node[rank[j]].byte = (uint8_t)s;
-            mine += c[j] != 0;
+        for (int j = 0; j < 4; ++j) {
+            const bool present = key[j] != 0xFFFFFFFFu;
+            n += (uint32_t)__popcll(__ballot(present));
+            lfp[j] = present ? key[j] >> 8 : 0xFFFFFFFFu;
+            w4 |= (255u - (key[j] & 255u)) << (8 * j);
         }
-    }
-    const uint32_t nleaf = wave_sum_u32(mine);
-    wave_lds_sync();
-    const int nonNullRank = (int)nleaf - 1;
-    const int nodeRoot = 256 + nonNullRank - 1;
-    if (lane == 0) {  // two-queue merge (zstd HUF_buildCTable_wksp), the only serial part of the tree
-        int lowS = nonNullRank, nodeNb = 256, lowN = 256;
-        node[nodeNb].count = node[lowS].count + node[lowS - 1].count;
-        node[lowS].parent = node[lowS - 1].parent = (uint16_t)nodeNb;
-        nodeNb++;
-        lowS -= 2;
-        for (int n = nodeNb; n <= nodeRoot; n++) node[n].count = 1u << 30;
-        node0[0].count = 1u << 31;
-        uint32_t cS = node[lowS].count, cN = node[lowN].count;
-        while (nodeNb <= nodeRoot) {
-            int n1, n2;
-            uint32_t a, bcount;
-            if (cS < cN) { n1 = lowS--; a = cS; cS = node[lowS].count; } else { n1 = lowN++; a = cN; cN = node[lowN].count; }
-            if (cS < cN) { n2 = lowS--; bcount = cS; cS = node[lowS].count; } else { n2 = lowN++; bcount = cN; cN = node[lowN].count; }
-            node[nodeNb].count = a + bcount;
-            if (lowN == nodeNb) cN = a + bcount;  // the node just created is the next internal candidate
-            node[n1].parent = node[n2].parent = (uint16_t)nodeNb;
-            nodeNb++;
-        }
+        *reinterpret_cast<uint4*>(&K.leaf[4 * lane]) = lf;
+        *reinterpret_cast<uint32_t*>(&K.sym[4 * lane]) = w4;
     }
     wave_lds_sync();
-    // code length of a leaf = length of its parent chain
+    SUB(6);
+    // --- package-merge (see huf_package_merge in zstd_entropy.h: the same lists, the same order of equal weights).
+    // From here on element e = lane + 64*j: the trip counts nj / mj are wave-uniform.
+    const uint32_t X0 = 2u * n - 2u;
+    const uint32_t nj = (n + 63u) >> 6;
+    const uint32_t ntop = 1u << (31 - __builtin_clz(n > 255u ? 255u : n));
+    uint32_t lv[4], pv[4], ln[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int rr = lane + 64 * j;
-        if (rr <= nonNullRank) {
-            int n = node[rr].parent, d = 1;
-            while (n != nodeRoot) {
-                n = node[n].parent;
-                ++d;
+        lv[j] = K.leaf[lane + 64 * j];
+        ln[j] = 0;
+    }
+    uint32_t m = n >> 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // packages of level 1: pairs of leaves (m <= 128)
+        const uint32_t t = (uint32_t)lane + 64u * j;
+        uint32_t v = 0xFFFFFFFFu;
+        if (t < m) {
+            const uint2 pr = *reinterpret_cast<const uint2*>(&K.leaf[2 * t]);
+            v = pr.x + pr.y;
+        }
+        pv[j] = v;
+        K.pkg[t] = v;
+    }
+    wave_lds_sync();
+    uint32_t levSame = maxNbBits;   // levels above this one equal it
+    for (uint32_t lev = 2; lev <= maxNbBits; ++lev) {
+        const bool last = lev == maxNbBits;
+        const uint32_t mj = (m + 63u) >> 6;
+        const uint32_t mtop = m ? 1u << (31 - __builtin_clz(m)) : 0u;
+        // positions in the merged list: a leaf goes behind the packages lighter than it, a package behind the leaves not
+        // heavier.  All searches of a lane advance together (up to eight independent LDS reads per step); elements past
+        // the end search with 0xFFFFFFFF and are not stored.
+        uint32_t lol[4] = { 0, 0, 0, 0 }, lop[4] = { 0, 0, 0, 0 };
+        for (uint32_t step = mtop > ntop ? mtop : ntop; step; step >>= 1) {
+            if (!last && step <= mtop) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)j < nj) lol[j] += K.pkg[lol[j] + step - 1] < lv[j] ? step : 0u;
             }
-            node[rr].nbBits = (uint8_t)d;
+            if (step <= ntop) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((uint32_t)j < mj) lop[j] += K.leaf[lop[j] + step - 1] <= pv[j] ? step : 0u;
+            }
+        }
+        if (!last) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t e = (uint32_t)lane + 64u * j, pos = e + lol[j];
+                if (e < n && pos < X0) K.merged[pos] = lv[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = (uint32_t)lane + 64u * j;
+            if (t < m) {
+                uint32_t cnt = lop[j];
+                if (n == 256u) cnt += (cnt == 255u && K.leaf[255] <= pv[j]) ? 1u : 0u;
+                const uint32_t pos = t + cnt;
+                if (pos < X0) {
+                    if (!last) K.merged[pos] = pv[j];
+                    atomicOr(&K.isPkg[lev][pos >> 5], 1u << (pos & 31u));
+                }
+            }
+        }
+        wave_lds_sync();
+        if (last) break;
+        const uint32_t size = n + m < X0 ? n + m : X0;
+        m = size >> 1;
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t t = (uint32_t)lane + 64u * j;
+            uint32_t v = 0xFFFFFFFFu;
+            if (t < m) {
+                const uint2 pr = *reinterpret_cast<const uint2*>(&K.merged[2 * t]);
+                v = pr.x + pr.y;
+            }
+            same = same && v == pv[j];
+            pv[j] = v;
+            K.pkg[t] = v;
+        }
+        wave_lds_sync();
+        if (__ballot(!same) == 0) {   // the same packages as one level down: every further level repeats this one
+            levSame = lev;
+            break;
         }
     }
-    wave_lds_sync();
-    if (lane == 0) L.huffLog = huf_set_max_height(node, (uint32_t)nonNullRank, maxNbBits);
+    SUB(7);
+    // --- which leaves each level takes: a prefix, known from the number of packages among the level's first X items
+    {
+        uint32_t X = X0;
+        for (uint32_t lev = maxNbBits; lev >= 2 && X; --lev) {
+            uint32_t c = 0;
+            if (lane < 16) {
+                const uint32_t w = K.isPkg[lev < levSame ? lev : levSame][lane];
+                const int32_t nb = (int32_t)X - 32 * lane;
+                const uint32_t mask = nb >= 32 ? 0xFFFFFFFFu : (nb > 0 ? (1u << nb) - 1u : 0u);
+                c = (uint32_t)__popc(w & mask);
+            }
+            const uint32_t pk = (uint32_t)__shfl((int)wave_incl_scan_u32(c), 63, 64);
+            const uint32_t nl = X - pk;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ln[j] += ((uint32_t)lane + 64u * j) < nl ? 1u : 0u;
+            X = 2u * pk;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ln[j] += ((uint32_t)lane + 64u * j) < X ? 1u : 0u;  // level 1 holds leaves only
+    }
+    SUB(8);
     for (int i = lane; i < 256; i += WAVE) L.nbBits[i] = 0;
     if (lane < 16) L.rankcnt[lane] = 0;
     wave_lds_sync();
-    maxNbBits = L.huffLog;
+    maxNbBits = (uint32_t)__builtin_amdgcn_readfirstlane((int)ln[0]);  // the lightest symbol has the longest code
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int rr = lane + 64 * j;
-        if (rr <= nonNullRank) {
-            const uint32_t nb = node[rr].nbBits;
-            L.nbBits[node[rr].byte] = (uint8_t)nb;
-            atomicAdd(&L.rankcnt[nb], 1u);
+        const uint32_t e = (uint32_t)lane + 64u * j;
+        if ((uint32_t)j < nj && e < n) {
+            L.nbBits[K.sym[e]] = (uint8_t)ln[j];
+            atomicAdd(&L.rankcnt[ln[j]], 1u);
         }
     }
+    SUB(9);
     wave_lds_sync();
     // first code of every length (zstd: longest codes get the smallest values)
     uint32_t val[HUF_ABS_MAX_BITS + 1];
@@ -320,8 +421,149 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
     return maxNbBits;
 }
 
+// all lanes: the Huffman tree description (huf_write_tree of zstd_entropy.h, byte for byte) with the wavefront on everything
+// that is not a chain: the weights' distribution is normalised one symbol per lane, the FSE table is spread and ranked with
+// ballots, the two interleaved state chains run on two lanes side by side and only note what they put out, and the bits are
+// packed from a wave prefix sum.  The table description (<= 13 symbols, data-dependent widths) stays on lane 0.  Anything
+// unusual -- a weight list too short or too uniform to compress, the second normalisation method, a description that does
+// not pay -- is left to the serial function.  L.weights[0..maxSym) and L.fw.count[] are filled by the caller.
+// (__forceinline__: as a called function this faulted on hardware with ROCm 7.2)
+__device__ __forceinline__ int huf_write_tree_wave(EncLds& L, uint32_t maxSym, uint32_t huffLog, int lane)
+{
+    FseWeightWksp& W = L.fw;
+    const uint32_t wtSize = maxSym;
+    const uint32_t cnt = lane <= HUF_ABS_MAX_BITS ? W.count[lane] : 0u;
+    const uint64_t nz = __ballot(cnt != 0);
+    const uint32_t maxCount = wave_max_u32(cnt);
+    bool fast = wtSize > 1 && nz != 0 && maxCount != wtSize && maxCount != 1;
+    uint32_t tableLog = 0, maxSV = 0;
+    int32_t nm = 0;
+    if (fast) {   // FSE_normalizeCount, first method
+        maxSV = 63u - (uint32_t)__builtin_clzll(nz);
+        tableLog = optimal_table_log(6, wtSize, maxSV, 2);
+        const uint32_t total = wtSize;
+        const uint64_t scale = 62 - tableLog, step = (1ull << 62) / total, vStep = 1ull << (scale - 20);
+        const uint32_t lowThreshold = total >> tableLog;
+        int32_t pm = 0;
+        if ((uint32_t)lane <= maxSV && cnt) {
+            if (cnt <= lowThreshold) nm = 1;
+            else {
+                int32_t proba = (int32_t)(int16_t)(((uint64_t)cnt * step) >> scale);
+                if (proba < 8) {
+                    uint32_t rtb = 830000u;   // { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 }
+                    rtb = proba == 0 ? 0u : proba == 1 ? 473195u : proba == 2 ? 504333u : proba == 3 ? 520860u
+                        : proba == 4 ? 550000u : proba == 5 ? 700000u : proba == 6 ? 750000u : rtb;
+                    const uint64_t restToBeat = vStep * rtb;
+                    proba += (((uint64_t)cnt * step) - ((uint64_t)proba << scale)) > restToBeat ? 1 : 0;
+                }
+                nm = proba;
+                pm = proba;
+            }
+        }
+        const int32_t still = (int32_t)(1u << tableLog) - (int32_t)wave_sum_u32((uint32_t)nm);
+        const uint32_t maxP = wave_max_u32((uint32_t)pm);
+        const uint64_t atMax = __ballot(pm > 0 && (uint32_t)pm == maxP);
+        const int largest = atMax ? (int)__builtin_ctzll(atMax) : 0;
+        const int32_t normLargest = __shfl(nm, largest, 64);
+        if (-still >= (normLargest >> 1)) fast = false;   // second method: serial
+        else if (lane == largest) nm += still;
+    }
+    if (fast) {
+        if (lane < 16) W.norm[lane] = (int16_t)nm;
+        for (int i = lane; i < 52; i += WAVE) W.bitbuf[i] = 0;
+        wave_lds_sync();
+        if (lane == 0) W.verdict = fse_write_ncount(L.tree + 1, 133, W.norm, maxSV, tableLog);
+        // FSE_buildCTable: cell (i * step) & mask holds the symbol of occurrence i; a symbol's states in cell order
+        const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1u;
+        const uint32_t cum = wave_incl_scan_u32((uint32_t)nm) - (uint32_t)nm;   // occurrences in front of symbol `lane`
+        if (lane < 16) W.cumul[lane] = cum;
+        wave_lds_sync();
+        const int hsz = W.verdict;
+        if (hsz < 0) fast = false;
+        else {
+            if ((uint32_t)lane < tableSize) {
+                uint32_t sy = 0;
+                for (uint32_t u = 1; u <= maxSV; ++u) sy += W.cumul[u] <= (uint32_t)lane ? 1u : 0u;
+                W.tableSymbol[((uint32_t)lane * ((tableSize >> 1) + (tableSize >> 3) + 3u)) & tableMask] = (uint8_t)sy;
+            }
+            if ((uint32_t)lane <= maxSV) {
+                uint32_t dnb, dfs = 0;
+                if (nm == 0) dnb = ((tableLog + 1) << 16) - tableSize;
+                else if (nm == 1) { dnb = (tableLog << 16) - tableSize; dfs = cum - 1u; }
+                else {
+                    const uint32_t maxBitsOut = tableLog - (uint32_t)hb32((uint32_t)nm - 1u);
+                    dnb = (maxBitsOut << 16) - ((uint32_t)nm << maxBitsOut);
+                    dfs = cum - (uint32_t)nm;
+                }
+                W.deltaNbBits[lane] = dnb;
+                W.deltaFindState[lane] = (int32_t)dfs;
+            }
+            wave_lds_sync();
+            {
+                const bool cell = (uint32_t)lane < tableSize;
+                const uint32_t sy = cell ? W.tableSymbol[lane] : 0xFFu;
+                uint32_t rank = 0;
+                const uint64_t below = (1ull << lane) - 1ull;
+                for (uint32_t u = 0; u <= maxSV; ++u) {
+                    const uint64_t same = __ballot(sy == u);
+                    if (sy == u) rank = (uint32_t)__popcll(same & below);
+                }
+                if (cell) W.stateTable[W.cumul[sy] + rank] = (uint16_t)(tableSize + (uint32_t)lane);
+            }
+            wave_lds_sync();
+            // FSE_compress_usingCTable: the chain that starts with the last weight takes the even steps, the other the odd
+            const uint32_t ne = wtSize - 2u;
+            if (lane < 2) {
+                const uint32_t s0 = L.weights[wtSize - 1u - (uint32_t)lane];
+                const uint32_t d0 = W.deltaNbBits[s0], nb0 = (d0 + (1u << 15)) >> 16;
+                uint32_t st = W.stateTable[(int32_t)(((nb0 << 16) - d0) >> nb0) + W.deltaFindState[s0]];
+                for (uint32_t k = (uint32_t)lane; k < ne; k += 2) {
+                    const uint32_t sy = L.weights[wtSize - 3u - k];
+                    const uint32_t nbo = (st + W.deltaNbBits[sy]) >> 16;
+                    W.emit[k] = (uint16_t)((st & ((1u << nbo) - 1u)) | (nbo << 8));
+                    st = W.stateTable[(int32_t)(st >> nbo) + W.deltaFindState[sy]];
+                }
+                // the final states: "state 2" first -- the odd chain for an odd number of weights, the even chain otherwise
+                const uint32_t slot = ne + (((wtSize & 1u) != 0) == (lane == 1) ? 0u : 1u);
+                W.emit[slot] = (uint16_t)((st & tableMask) | (tableLog << 8));
+                if (lane == 0) W.emit[ne + 2u] = (uint16_t)(1u | (1u << 8));   // end mark
+            }
+            wave_lds_sync();
+            uint32_t acc = 0, tb = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t k = 4u * (uint32_t)lane + (uint32_t)q;
+                const uint32_t e = k < ne + 3u ? W.emit[k] : 0u;
+                acc |= (e & 0xFFu) << tb;
+                tb += e >> 8;
+            }
+            const uint32_t incl = wave_incl_scan_u32(tb);
+            const uint32_t off = incl - tb, sh = off & 31u;
+            if (tb) {
+                atomicOr(&W.bitbuf[off >> 5], acc << sh);
+                if (sh + tb > 32u) atomicOr(&W.bitbuf[(off >> 5) + 1u], acc >> (32u - sh));
+            }
+            const uint32_t nbytes = ((uint32_t)__shfl((int)incl, 63, 64) + 7u) >> 3;
+            wave_lds_sync();
+            const uint32_t hSize = (uint32_t)hsz + nbytes;
+            if (hSize >= 133u || !(hSize > 1u && hSize < maxSym / 2u)) fast = false;
+            else {
+                for (uint32_t i = lane; i < nbytes; i += WAVE) L.tree[1u + (uint32_t)hsz + i] = (uint8_t)(W.bitbuf[i >> 2] >> (8u * (i & 3u)));
+                if (lane == 0) L.tree[0] = (uint8_t)hSize;
+                wave_lds_sync();
+                return (int)hSize + 1;
+            }
+        }
+    }
+    // the serial statement decides everything else (it starts over: the histogram of the weights is still there)
+    wave_lds_sync();
+    if (lane == 0) W.verdict = huf_write_tree(L.tree, 134, L.nbBits, maxSym, huffLog, L.weights, &W, true);
+    wave_lds_sync();
+    return W.verdict;
+}
+
 // all lanes: choose the coding mode of a region from its histogram and, for Huffman, build the table
-__device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
+__device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
 {
     uint32_t mx = 0, msym = 0;
 #pragma unroll
@@ -341,9 +583,9 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
     if (maxCount == S) return;
     if (S <= 63) return;                       // libzstd stores such literals raw (minLitSize)
     if (maxCount <= (S >> 7) + 4) return;      // libzstd's "probably not compressible" heuristic
-    // counts above 2^28 would overflow the node sums: scale the histogram down (still a valid code)
+    // the sort keys hold a count in 24 bits: scale the histogram of a larger region down (still a valid code)
     uint32_t shift = 0;
-    while ((S >> shift) >= (1u << 28)) shift++;
+    while ((S >> shift) >= (1u << 24)) shift++;
     if (shift) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -355,7 +597,8 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
     }
     const uint32_t logSrc = S < BLOCK_MAX ? S : BLOCK_MAX;
     uint32_t huffLog = optimal_table_log(HUF_MAX_BITS, logSrc, maxSym, 1);
-    huffLog = huf_build_wave(L, maxSym, huffLog, lane);
+    SUB(6);
+    huffLog = huf_build_wave(L, maxSym, huffLog, lane, tsub, tl);
     // weights (all but the last symbol's) and their histogram, in parallel
     if (lane < 16) L.fw.count[lane] = 0;
     wave_lds_sync();
@@ -376,8 +619,9 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d, 64);
     wave_lds_sync();
+    SUB(10);
+    const int ts = huf_write_tree_wave(L, maxSym, huffLog, lane);
     if (lane == 0) {
-        const int ts = huf_write_tree(L.tree, 134, L.nbBits, maxSym, huffLog, L.weights, &L.fw, true);
         bool ok = ts >= 0;
         if (ok) {
             const uint64_t est = ((bits << shift) >> 3) + (uint64_t)ts + 14ull * nblk;
@@ -391,6 +635,7 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane)
         }
     }
     wave_lds_sync();
+    SUB(11);
 }
 
 // ---- run sequences for the control-byte region (and for frames too small to have one) ----------------------------------
@@ -944,7 +1189,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         PHASE(0);
         region_histogram(L, rin, S, lane);
         PHASE(1);
-        region_plan(L, S, nblk, lane);
+        region_plan(L, S, nblk, lane, TIMED ? tph : nullptr, &tlast);
         wave_lds_sync();
         PHASE(2);
         const uint32_t mode = L.mode;

@@ -207,6 +207,101 @@ VBZ_HDN uint32_t huf_build(const uint32_t* count, uint32_t maxSymbolValue, uint3
 }
 
 // ------------------------------------------------------------------------------------------------
+// Optimal length-limited code lengths by package-merge (Larmore & Hirschberg 1990), in the form the device
+// encoder runs across a wavefront (zstd_encode.hip: huf_build_wave) -- this is its serial statement.
+//   w[0..n) ascending, n >= 2, 2^L >= n.  len[i] = code length of w[i], sum of 2^-len[i] == 1, len[i] <= L,
+//   sum of w[i] * len[i] minimal under that limit (libzstd builds the unlimited tree and repairs it with a
+//   heuristic, HUF_setMaxHeight: never shorter than this, sometimes longer).
+// Level 1 holds the leaves; level j holds the leaves merged with the packages (sums of consecutive pairs) of
+// level j-1, cut to the first 2n-2 items, a leaf in front of a package of the same weight.  The code takes the
+// first 2n-2 items of level L; a package taken at level j takes its two items at level j-1; a leaf's length is
+// the number of levels it is taken at.  Since every list is sorted, "taken" is a prefix of the leaves at every
+// level: all that has to be kept per level is which of its items are packages.
+struct HufPmWksp
+{
+    uint32_t leaf[256];     // weights of the present symbols, ascending (padded with 0xFFFFFFFF)
+    uint32_t pkg[256];      // packages of the previous level, ascending (padded with 0xFFFFFFFF)
+    uint32_t merged[512];   // the current level's list
+    uint32_t isPkg[HUF_MAX_BITS + 1][16];  // per level: bit p = item p of the list is a package
+    uint8_t sym[256];       // symbol of leaf i
+};
+
+VBZ_HDN void huf_package_merge(HufPmWksp* k, uint32_t n, uint32_t L, uint8_t* len)
+{
+    const uint32_t X0 = 2 * n - 2;
+    uint32_t m = n >> 1;
+    for (uint32_t t = 0; t < 256; ++t) k->pkg[t] = t < m ? k->leaf[2 * t] + k->leaf[2 * t + 1] : 0xFFFFFFFFu;
+    for (uint32_t j = 2; j <= L; ++j) {
+        for (int q = 0; q < 16; ++q) k->isPkg[j][q] = 0;
+        uint32_t a = 0, b = 0, p = 0;
+        while (p < X0 && (a < n || b < m)) {
+            const bool takeLeaf = a < n && (b >= m || k->leaf[a] <= k->pkg[b]);
+            if (takeLeaf) k->merged[p] = k->leaf[a++];
+            else {
+                k->merged[p] = k->pkg[b++];
+                k->isPkg[j][p >> 5] |= 1u << (p & 31);
+            }
+            ++p;
+        }
+        m = p >> 1;
+        for (uint32_t t = 0; t < 256; ++t) k->pkg[t] = t < m ? k->merged[2 * t] + k->merged[2 * t + 1] : 0xFFFFFFFFu;
+    }
+    for (uint32_t i = 0; i < n; ++i) len[i] = 0;
+    uint32_t X = X0;
+    for (uint32_t j = L; j >= 2 && X; --j) {
+        uint32_t pk = 0;
+        for (uint32_t p = 0; p < X; ++p) pk += (k->isPkg[j][p >> 5] >> (p & 31)) & 1u;
+        const uint32_t nl = X - pk;
+        for (uint32_t i = 0; i < nl; ++i) len[i]++;
+        X = 2 * pk;
+    }
+    for (uint32_t i = 0; i < X; ++i) len[i]++;   // level 1: leaves only
+}
+
+// Length-limited canonical Huffman code from a histogram, lengths by package-merge, codes numbered the way zstd
+// numbers them (HUF_buildCTable_wksp: within a length by increasing symbol, longest codes lowest).
+//   count[0..maxSymbolValue], at least two non-zero counts, every count < 2^24.  Returns the table log.
+// Order of equal counts: the higher symbol sorts first (gets the longer code).
+VBZ_HDN uint32_t huf_build_pm(const uint32_t* count, uint32_t maxSymbolValue, uint32_t maxNbBits, uint8_t* nbBits, uint16_t* code,
+                              HufPmWksp* k)
+{
+    uint32_t n = 0;
+    for (uint32_t s = 0; s <= maxSymbolValue; ++s) {   // insertion sort of (count << 8 | 255 - s), ascending
+        if (!count[s]) continue;
+        const uint32_t key = (count[s] << 8) | (255u - s);
+        uint32_t pos = n++;
+        while (pos > 0 && (((k->leaf[pos - 1] << 8) | (255u - k->sym[pos - 1])) > key)) {
+            k->leaf[pos] = k->leaf[pos - 1];
+            k->sym[pos] = k->sym[pos - 1];
+            --pos;
+        }
+        k->leaf[pos] = count[s];
+        k->sym[pos] = (uint8_t)s;
+    }
+    for (uint32_t i = n; i < 256; ++i) k->leaf[i] = 0xFFFFFFFFu;
+    uint8_t len[256];
+    huf_package_merge(k, n, maxNbBits, len);
+    maxNbBits = len[0];
+    uint16_t nbPerRank[HUF_ABS_MAX_BITS + 2], valPerRank[HUF_ABS_MAX_BITS + 2];
+    for (int i = 0; i < HUF_ABS_MAX_BITS + 2; ++i) nbPerRank[i] = valPerRank[i] = 0;
+    for (uint32_t s = 0; s <= maxSymbolValue; ++s) nbBits[s] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        nbBits[k->sym[i]] = len[i];
+        nbPerRank[len[i]]++;
+    }
+    {
+        uint16_t min = 0;
+        for (int r = (int)maxNbBits; r > 0; r--) {
+            valPerRank[r] = min;
+            min = (uint16_t)(min + nbPerRank[r]);
+            min >>= 1;
+        }
+    }
+    for (uint32_t s = 0; s <= maxSymbolValue; ++s) code[s] = nbBits[s] ? valPerRank[nbBits[s]]++ : 0;
+    return maxNbBits;
+}
+
+// ------------------------------------------------------------------------------------------------
 // FSE compression of the Huffman weights (zstd HUF_compressWeights / FSE_normalizeCount /
 // FSE_writeNCount / FSE_buildCTable / FSE_compress_usingCTable) -- alphabet <= 13, tableLog <= 6
 // ------------------------------------------------------------------------------------------------
@@ -219,6 +314,10 @@ struct FseWeightWksp
     uint32_t cumul[18];
     int32_t deltaFindState[16];
     uint32_t deltaNbBits[16];
+    // the device's wave-cooperative writer (zstd_encode.hip: huf_write_tree_wave) only:
+    uint16_t emit[256];    // what each step of the two state chains puts out: bits | count << 8
+    uint32_t bitbuf[52];   // the packed bit stream (at most 253 x 6 + 13 bits)
+    int32_t verdict;
 };
 
 struct BitW  // forward bit writer (little-endian), zstd BIT_CStream_t
