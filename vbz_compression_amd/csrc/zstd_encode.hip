@@ -83,9 +83,8 @@ constexpr uint32_t SPAN_FIRST = 1, SPAN_LAST = 2, SPAN_KEYSEQ = 4, SPAN_SKIP = 8
 struct EncLds
 {
     uint32_t hist[256];
-    uint32_t ctable[256];  // code | nbBits << 16
+    uint2 ctable[256];     // { code, length }: one 8-byte read per symbol, nothing to take apart in the packing loop
     uint8_t nbBits[256];
-    uint16_t code[256];
     uint8_t weights[260];
     uint8_t tree[136];
     int32_t treeSize;
@@ -104,6 +103,8 @@ struct EncLds
             uint32_t sbeg[WAVE];    // first byte (region offset) of each stream of the current pass
             uint32_t scnt[WAVE];    // symbols in each stream
             uint32_t obuf[OBUF_WORDS]; // bit buffer of the stream being packed
+            uint16_t seqcode[8 + 256];  // sequences section: codes of a round (+ the tail of the round before)
+            uint32_t seqpiece[256];     //                    what the state chains put out
         };
     };
     SeqCTables seq;             // encoding tables of the predefined LL / ML distributions
@@ -190,7 +191,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-// all lanes.  L.hist[0..maxSym] -> L.nbBits / L.code; returns the table log (uniform).
+// all lanes.  L.hist[0..maxSym] -> L.nbBits / L.ctable; returns the table log (uniform).
 // sub-phase timers of the timed kernel build (tools/phase_timing.py): slots 6.. of the phase counters
 #define SUB(k) do { if (tsub) { unsigned long long tn = __builtin_readcyclecounter(); tsub[k] += tn - *tl; *tl = tn; } } while (0)
 // #{i : arr[i] < v} (STRICT) or #{i : arr[i] <= v} over a sorted array padded with 0xFFFFFFFF; at most 255 (top = the
@@ -415,7 +416,7 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
             if (nb == (uint32_t)l) code = val[l] + (uint32_t)__popcll(m & below);
             val[l] += (uint32_t)__popcll(m);
         }
-        L.code[s] = (uint16_t)code;
+        L.ctable[s] = make_uint2(code, nb);
     }
     wave_lds_sync();
     return maxNbBits;
@@ -613,7 +614,6 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane, unsi
             atomicAdd(&L.fw.count[wt], 1u);
         }
         mybits += (uint64_t)L.hist[s] * nb;
-        L.ctable[s] = s <= maxSym ? ((uint32_t)L.code[s] | (nb << 16)) : 0u;
     }
     uint64_t bits = mybits;
 #pragma unroll
@@ -856,14 +856,38 @@ __device__ void period_mask(const uint8_t* in, uint32_t S, uint32_t D, uint16_t*
 constexpr uint32_t CP_MAGIC = 0x184D2A5Bu;
 constexpr uint32_t CP_MIN_SPACING = 32;
 
-// all lanes.  Sequences section (RFC 8878 3.1.1.3.2) for the records of tokenise_zero_runs: LL and ML with the
-// predefined distributions, OF in RLE mode with code 0 (repeat offset 1); same bit order as libzstd's
-// ZSTD_encodeSequences (last sequence first).  Per chunk of 64 sequences: every lane turns one record into
-// codes and extra bits; wave-uniform scalar code walks the two independent FSE state chains (match length / literal
-// length) and leave each step's output bits in LDS; every lane then assembles the <= 44 bits of its sequence,
-// a wave prefix sum places them, and the chunk is written out as dwords.  Returns the bytes written.
+// all lanes.  Sequences section (RFC 8878 3.1.1.3.2) for the records of tokenise_runs: LL and ML with the predefined
+// distributions, OF in RLE mode; same bit order as libzstd's ZSTD_encodeSequences (last sequence first).
+//
+// The two FSE state chains (match length, literal length) look serial -- a step's output is the low bits of the state the
+// previous step left -- but a step forgets almost everything: a symbol with c cells in the table (c <= 4 for both predefined
+// distributions) leaves one of c states, chosen by the top bits of the state before it, and the four states 64, 80, 96, 112
+// between them reach every cell of every symbol.  So a lane that is to encode sequences [a, b) walks the SEQ_WARM sequences
+// in front of a from those four states at once; when the four walks have met (a symbol with one cell joins them at once,
+// one with two cells every other time) the state before a is known without the history, and all lanes encode their
+// SEQ_PER_LANE sequences side by side.  A lane whose walks have not met waits for its neighbour's final state (one more pass
+// of the lanes concerned; the first lane always knows its state), so the result is the serial chain's, bit for bit, whatever
+// the data.  Per round of 64 x SEQ_PER_LANE sequences: codes and extra bits of every sequence (one per lane and chunk), the
+// chains, then chunk by chunk every lane assembles the <= 44 + 17 bits of its sequence, a wave prefix sum places them, the
+// chunk leaves as dwords.  Returns the bytes written.
 // of_dist: 0 = every sequence copies from repeat offset 1 (runs; OF code 0, checkpoints recorded); otherwise every sequence
 // carries the explicit distance of_dist (OF code floor(log2(of_dist + 3)), that many extra bits; no checkpoints).
+constexpr int SEQ_PER_LANE = 4, SEQ_ROUND = WAVE * SEQ_PER_LANE, SEQ_WARM = 8;
+
+struct SeqStep { uint32_t st; uint32_t piece; };   // piece: bits | count << 6
+
+__device__ __forceinline__ SeqStep seq_fse_init(uint32_t dnb, int32_t dfs, const uint16_t* stab)  // FSE_initCState2
+{
+    const uint32_t nbo = (dnb + (1u << 15)) >> 16;
+    return { stab[(int32_t)(((nbo << 16) - dnb) >> nbo) + dfs], 0u };
+}
+
+__device__ __forceinline__ SeqStep seq_fse_step(uint32_t st, uint32_t dnb, int32_t dfs, const uint16_t* stab)  // FSE_encodeSymbol
+{
+    const uint32_t nb = (st + dnb) >> 16;
+    return { stab[(int32_t)(st >> nb) + dfs], (st & ((1u << nb) - 1u)) | (nb << 6) };
+}
+
 __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uint2* rec, uint32_t nseq, int lane, uint32_t of_dist = 0)
 {
     const uint32_t of_code = of_dist ? (uint32_t)hb32(of_dist + 3u) : 0u;
@@ -880,17 +904,13 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
     }
     hdr = (uint32_t)__shfl((int)hdr, 0, 64);
     uint8_t* out = dst + hdr;
-    // LDS scratch inside the (idle) bit buffer of the stream packer: bit words of one chunk
-    uint32_t* bits = L.obuf;                 // 128 words: 64 sequences x 44 bits + carry
+    // LDS scratch inside the (idle) workspace of the stream packer
+    uint32_t* bits = L.obuf;                 // 128 words: 64 sequences x (44 + 17) bits + carry
+    uint16_t* code = L.seqcode;              // [SEQ_WARM + position in the round]: match-length code | literal-length code << 8
+    uint32_t* piece = L.seqpiece;            // [position in the round]: per chain bits | count << 6 | state after << 9; LL chain << 15
     for (int i = lane; i < 128; i += WAVE) bits[i] = 0;
-    // The two FSE state chains (match length, literal length) are serial; they run as wave-uniform code on the
-    // scalar unit with everything they look up held across the lanes of vector registers: the state tables (64
-    // entries each), the per-symbol deltas, the chunk's codes; each step's output lands in lane j of pmv / plv.
-    const uint32_t t_mstate = L.seq.ml_state[lane], t_lstate = L.seq.ll_state[lane];
-    const uint32_t t_mdnb = lane < SEQ_ML_SYMS ? L.seq.ml_dnb[lane] : 0u, t_ldnb = lane < SEQ_LL_SYMS ? L.seq.ll_dnb[lane] : 0u;
-    const uint32_t t_mdfs = lane < SEQ_ML_SYMS ? (uint32_t)L.seq.ml_dfs[lane] : 0u, t_ldfs = lane < SEQ_LL_SYMS ? (uint32_t)L.seq.ll_dfs[lane] : 0u;
-    auto rl = [](uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
-    uint32_t stM = 0, stL = 0;               // encoder states (table value: decoder state + 64), wave-uniform
+    if (lane < SEQ_WARM) code[lane] = 0;
+    uint32_t carryM = 0, carryL = 0;         // states after the last sequence of the previous round (wave-uniform)
     uint32_t base_bits = 0, flushed = 0;
     uint32_t spacing = CP_MIN_SPACING;  // at most 63 checkpoints + the start = 64 decoder lanes
     while ((nseq + spacing - 1) / spacing > 64) spacing *= 2;
@@ -898,95 +918,160 @@ __device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uin
         L.cpSpacing = spacing;
         L.cpCount = (nseq - 1) / spacing;
     }
-    for (uint32_t t0 = 0; t0 < nseq; t0 += WAVE) {
-        const uint32_t cnt = (nseq - t0) < (uint32_t)WAVE ? (nseq - t0) : (uint32_t)WAVE;
-        const uint32_t t = t0 + (uint32_t)lane;
-        uint32_t lex = 0, lnb = 0, mex = 0, mnb = 0, codes = 0;
-        if (t < nseq) {
-            const uint32_t n = nseq - 1 - t;
-            const uint2 cur = rec[n];
-            const uint2 prev = n ? rec[n - 1] : make_uint2(0u, 0u);
-            const uint32_t ll = cur.y - prev.y;
-            const uint32_t ml = (cur.x - prev.x) - ll;
-            uint32_t lc, mc;
-            seq_ll_code(ll, &lc, &lex, &lnb);
-            seq_ml_code(ml, &mc, &mex, &mnb);
-            codes = mc | (lc << 8);
+    for (uint32_t r0 = 0; r0 < nseq; r0 += SEQ_ROUND) {
+        const uint32_t rn = (nseq - r0) < (uint32_t)SEQ_ROUND ? (nseq - r0) : (uint32_t)SEQ_ROUND;  // sequences of this round
+        // --- codes and extra bits: chunk c, lane l is sequence r0 + 64 c + l of the section (= record nseq - 1 - that)
+        uint32_t lexv[SEQ_PER_LANE], mexv[SEQ_PER_LANE];   // extra bits | count << 16
+        wave_lds_sync();
+        if (r0) {   // the walks start among the last sequences of the round before
+            const uint32_t keep = lane < SEQ_WARM ? code[SEQ_ROUND + lane] : 0u;
+            wave_lds_sync();
+            if (lane < SEQ_WARM) code[lane] = (uint16_t)keep;
         }
-        uint32_t pmv = 0, plv = 0;  // lane j: value | nbits << 16 | decoder state before this sequence << 24
-        for (uint32_t j = 0; j < cnt; ++j) {
-            const uint32_t cc = rl(codes, j), mc = cc & 0xFF, lc = cc >> 8;
-            const uint32_t dm = rl(t_mdnb, mc), dl = rl(t_ldnb, lc);
-            const uint32_t fm = rl(t_mdfs, mc), fl = rl(t_ldfs, lc);
-            uint32_t pieceM = 0, pieceL = 0;
-            if (t0 + j == 0) {  // FSE_initCState2: the first symbol only selects the state
-                const uint32_t nm = (dm + (1u << 15)) >> 16, nl = (dl + (1u << 15)) >> 16;
-                stM = rl(t_mstate, (uint32_t)((int32_t)(((nm << 16) - dm) >> nm) + (int32_t)fm));
-                stL = rl(t_lstate, (uint32_t)((int32_t)(((nl << 16) - dl) >> nl) + (int32_t)fl));
-            } else {            // FSE_encodeSymbol
-                const uint32_t nm = (stM + dm) >> 16, nl = (stL + dl) >> 16;
-                pieceM = (stM & ((1u << nm) - 1u)) | (nm << 16);
-                pieceL = (stL & ((1u << nl) - 1u)) | (nl << 16);
-                stM = rl(t_mstate, (uint32_t)((int32_t)(stM >> nm) + (int32_t)fm));
-                stL = rl(t_lstate, (uint32_t)((int32_t)(stL >> nl) + (int32_t)fl));
+#pragma unroll
+        for (int c = 0; c < SEQ_PER_LANE; ++c) {
+            const uint32_t i = 64u * c + (uint32_t)lane;
+            uint32_t lex = 0, lnb = 0, mex = 0, mnb = 0, lc = 0, mc = 0;
+            if (i < rn) {
+                const uint32_t n = nseq - 1 - (r0 + i);
+                const uint2 cur = rec[n];
+                const uint2 prev = n ? rec[n - 1] : make_uint2(0u, 0u);
+                const uint32_t ll = cur.y - prev.y;
+                const uint32_t ml = (cur.x - prev.x) - ll;
+                seq_ll_code(ll, &lc, &lex, &lnb);
+                seq_ml_code(ml, &mc, &mex, &mnb);
             }
-            const bool here = (uint32_t)lane == j;
-            pmv = here ? (pieceM | ((stM & 63u) << 24)) : pmv;
-            plv = here ? (pieceL | ((stL & 63u) << 24)) : plv;
-        }
-        uint64_t v = 0;
-        uint32_t len = 0;
-        if (t < nseq) {
-            const uint32_t pm = pmv, pl = plv;
-            v = (uint64_t)(pm & 0xFFFF);
-            len = (pm >> 16) & 0xFF;
-            v |= (uint64_t)(pl & 0xFFFF) << len;
-            len += (pl >> 16) & 0xFF;
-            v |= (uint64_t)lex << len;
-            len += lnb;
-            v |= (uint64_t)mex << len;
-            len += mnb;
-            v |= (uint64_t)of_extra << len;   // (at most 44 + 17 bits)
-            len += of_code;
-        }
-        const uint32_t incl = wave_incl_scan_u32(len);
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-        const uint32_t pos = base_bits + incl - len;
-        if (t < nseq) {
-            const uint32_t n = nseq - 1 - t;  // checkpoint: everything up to and including this sequence's bits is unread
-            if (of_dist == 0 && n != 0 && n % spacing == 0)
-                L.cp[n / spacing - 1] = (8u * flushed + base_bits + incl) | ((plv >> 24) << 20) | ((pmv >> 24) << 26);
-        }
-        if (len) {
-            const uint32_t w = pos >> 5, sh = pos & 31;
-            const uint64_t lo = v << sh;                 // len <= 44, sh <= 31: may spill into a third word
-            atomicOr(&bits[w], (uint32_t)lo);
-            if (sh + len > 32) atomicOr(&bits[w + 1], (uint32_t)(lo >> 32));
-            if (sh + len > 64) atomicOr(&bits[w + 2], (uint32_t)(v >> (64 - sh)));
+            lexv[c] = lex | (lnb << 16);
+            mexv[c] = mex | (mnb << 16);
+            code[SEQ_WARM + i] = (uint16_t)(mc | (lc << 8));
         }
         wave_lds_sync();
-        const uint32_t allbits = base_bits + total;
-        const uint32_t full = allbits >> 5;
-        for (uint32_t i = lane; i < full; i += WAVE) {
-            const uint32_t wv = bits[i];
-            __builtin_memcpy(out + flushed + 4 * i, &wv, 4);
+        // --- the chains: this lane encodes positions [a, b) of the round
+        {
+            const uint32_t a = (uint32_t)SEQ_PER_LANE * (uint32_t)lane;
+            const uint32_t b = a + SEQ_PER_LANE < rn ? a + SEQ_PER_LANE : rn;
+            uint32_t cM[4], cL[4];
+            const bool first = r0 == 0 && a == 0;           // the very first sequence only selects the states
+            uint32_t w = 0;                                  // walk over positions [a - w, a)
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cM[q] = carryM; cL[q] = carryL; }
+            } else {
+                w = SEQ_WARM;
+                if (r0 == 0 && a <= (uint32_t)SEQ_WARM) w = a;   // from the first sequence of the section: exact
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { cM[q] = 64u + 16u * q; cL[q] = 64u + 16u * q; }
+            }
+            for (uint32_t k = SEQ_WARM; k > 0; --k) {       // position a - k
+                if (k <= w) {
+                    const uint32_t cc = code[SEQ_WARM + a - k], mc = cc & 0xFFu, lc = cc >> 8;
+                    const uint32_t dm = L.seq.ml_dnb[mc], dl = L.seq.ll_dnb[lc];
+                    const int32_t fm = L.seq.ml_dfs[mc], fl = L.seq.ll_dfs[lc];
+                    if (r0 == 0 && a == k) {                 // position 0 of the section
+                        const uint32_t sm = seq_fse_init(dm, fm, L.seq.ml_state).st, sl = seq_fse_init(dl, fl, L.seq.ll_state).st;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { cM[q] = sm; cL[q] = sl; }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            cM[q] = seq_fse_step(cM[q], dm, fm, L.seq.ml_state).st;
+                            cL[q] = seq_fse_step(cL[q], dl, fl, L.seq.ll_state).st;
+                        }
+                    }
+                }
+            }
+            bool known = cM[0] == cM[1] && cM[0] == cM[2] && cM[0] == cM[3] && cL[0] == cL[1] && cL[0] == cL[2] && cL[0] == cL[3];
+            bool done = a >= rn;                             // nothing to encode: nobody waits for this lane
+            known = known || done;
+            uint32_t stM = cM[0], stL = cL[0];
+            for (;;) {
+                if (known && !done) {
+                    for (uint32_t i = a; i < b; ++i) {
+                        const uint32_t cc = code[SEQ_WARM + i], mc = cc & 0xFFu, lc = cc >> 8;
+                        const uint32_t dm = L.seq.ml_dnb[mc], dl = L.seq.ll_dnb[lc];
+                        const int32_t fm = L.seq.ml_dfs[mc], fl = L.seq.ll_dfs[lc];
+                        const SeqStep m = (first && i == 0) ? seq_fse_init(dm, fm, L.seq.ml_state) : seq_fse_step(stM, dm, fm, L.seq.ml_state);
+                        const SeqStep l = (first && i == 0) ? seq_fse_init(dl, fl, L.seq.ll_state) : seq_fse_step(stL, dl, fl, L.seq.ll_state);
+                        stM = m.st;
+                        stL = l.st;
+                        piece[i] = (m.piece | ((stM & 63u) << 9)) | ((l.piece | ((stL & 63u) << 9)) << 15);
+                    }
+                    done = true;
+                }
+                if (__ballot(!done) == 0) break;
+                const uint32_t pM = (uint32_t)__shfl_up((int)stM, 1, 64), pL = (uint32_t)__shfl_up((int)stL, 1, 64);
+                const bool pdone = __shfl_up((int)done, 1, 64) != 0;
+                if (!known && pdone) {
+                    stM = pM;
+                    stL = pL;
+                    known = true;
+                }
+            }
+            const int lastLane = (int)((rn - 1u) / SEQ_PER_LANE);
+            carryM = (uint32_t)__shfl((int)stM, lastLane, 64);
+            carryL = (uint32_t)__shfl((int)stL, lastLane, 64);
         }
-        const uint32_t carry = bits[full];
         wave_lds_sync();
-        for (uint32_t i = lane; i <= full; i += WAVE) bits[i] = 0;
-        wave_lds_sync();
-        if (lane == 0) bits[0] = carry;
-        flushed += 4 * full;
-        base_bits = allbits & 31;
-        wave_lds_sync();
+        // --- assembly, 64 sequences at a time
+#pragma unroll
+        for (int c = 0; c < SEQ_PER_LANE; ++c) {
+            if (64u * c >= rn) break;
+            const uint32_t i = 64u * c + (uint32_t)lane;
+            const uint32_t t = r0 + i;
+            uint64_t v = 0;
+            uint32_t len = 0, pc = 0;
+            if (i < rn) {
+                pc = piece[i];
+                v = (uint64_t)(pc & 63u);
+                len = (pc >> 6) & 7u;
+                v |= (uint64_t)((pc >> 15) & 63u) << len;
+                len += (pc >> 21) & 7u;
+                v |= (uint64_t)(lexv[c] & 0xFFFFu) << len;
+                len += lexv[c] >> 16;
+                v |= (uint64_t)(mexv[c] & 0xFFFFu) << len;
+                len += mexv[c] >> 16;
+                v |= (uint64_t)of_extra << len;   // (at most 44 + 17 bits)
+                len += of_code;
+            }
+            const uint32_t incl = wave_incl_scan_u32(len);
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+            const uint32_t pos = base_bits + incl - len;
+            if (i < rn) {
+                const uint32_t n = nseq - 1 - t;  // checkpoint: everything up to and including this sequence's bits is unread
+                if (of_dist == 0 && n != 0 && n % spacing == 0)
+                    L.cp[n / spacing - 1] = (8u * flushed + base_bits + incl) | (((pc >> 24) & 63u) << 20) | (((pc >> 9) & 63u) << 26);
+            }
+            if (len) {
+                const uint32_t w = pos >> 5, sh = pos & 31;
+                const uint64_t lo = v << sh;                 // len <= 61, sh <= 31: may spill into a third word
+                atomicOr(&bits[w], (uint32_t)lo);
+                if (sh + len > 32) atomicOr(&bits[w + 1], (uint32_t)(lo >> 32));
+                if (sh + len > 64) atomicOr(&bits[w + 2], (uint32_t)(v >> (64 - sh)));
+            }
+            wave_lds_sync();
+            const uint32_t allbits = base_bits + total;
+            const uint32_t full = allbits >> 5;
+            for (uint32_t q = lane; q < full; q += WAVE) {
+                const uint32_t wv = bits[q];
+                __builtin_memcpy(out + flushed + 4 * q, &wv, 4);
+            }
+            const uint32_t carry = bits[full];
+            wave_lds_sync();
+            for (uint32_t q = lane; q <= full; q += WAVE) bits[q] = 0;
+            wave_lds_sync();
+            if (lane == 0) bits[0] = carry;
+            flushed += 4 * full;
+            base_bits = allbits & 31;
+            wave_lds_sync();
+        }
     }
     // final states (match length, then literal length) and the end mark
     uint32_t nbytes = 0;
     if (lane == 0) {
         uint64_t acc = bits[0];
         uint32_t nbit = base_bits;
-        acc |= (uint64_t)(stM & 63u) << nbit; nbit += SEQ_DEF_LOG;
-        acc |= (uint64_t)(stL & 63u) << nbit; nbit += SEQ_DEF_LOG;
+        acc |= (uint64_t)(carryM & 63u) << nbit; nbit += SEQ_DEF_LOG;
+        acc |= (uint64_t)(carryL & 63u) << nbit; nbit += SEQ_DEF_LOG;
         acc |= 1ull << nbit; nbit += 1;
         nbytes = (nbit + 7) >> 3;
         for (uint32_t i = 0; i < nbytes; ++i) out[flushed + i] = (uint8_t)(acc >> (8 * i));
@@ -1324,6 +1409,29 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     const uint32_t big = jbs > worst ? jbs : worst;
                     return 3u + (big >= 1024u ? 1u : 0u) + (big >= 16384u ? 1u : 0u);
                 };
+                // headers of block j of this pass, which starts at `at` (lane 0 writes; sizes of its streams are in L.ssize)
+                auto block_headers = [&](uint32_t j, uint32_t at, uint32_t seqBytes) {
+                    if (lane == 0) {
+                        const uint32_t jb = b0 + j, jbs = blk_bs(j);
+                        const bool jsingle = jbs < 256u;
+                        const uint32_t lh = blk_lh(j), tsz = jb == 0 ? treeSize : 0u;
+                        const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
+                        const uint32_t lit = tsz + (jsingle ? 0u : 6u) + s0 + s1 + s2 + s3;
+                        uint8_t* bp = out + at;
+                        const uint32_t last = (lastRegion && jb + 1 == nblk) ? 1u : 0u;
+                        put_le(bp, ((lh + lit + seqBytes) << 3) | (2u << 1) | last, 3);
+                        const uint64_t type = jb == 0 ? 2 : 3;  // Compressed_Literals_Block / Treeless
+                        if (lh == 3) put_le(bp + 3, type | ((jsingle ? 0ull : 1ull) << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 14), 3);
+                        else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 18), 4);
+                        else put_le(bp + 3, type | (3ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 22), 5);
+                        if (!jsingle) {
+                            uint8_t* tp = bp + 3 + lh + tsz;
+                            put_le(tp, s0, 2);
+                            put_le(tp + 2, s1, 2);
+                            put_le(tp + 4, s2, 2);
+                        }
+                    }
+                };
                 uint32_t ocur = opos;        // where the current block starts
                 uint32_t spos = 0;           // where the current stream starts
                 uint32_t curblk = 0xFFFFFFFFu;
@@ -1356,16 +1464,16 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     // the first `skip` of its 32 bytes lie before the stream (or the lane is past its start)
                     const int32_t room = (int32_t)(scnt - done) - STEP_LANE * lane;
                     const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
-                    uint32_t ent[STEP_LANE];
+                    uint2 ent[STEP_LANE];   // { code, length } of the lane's symbols
 #pragma unroll
                     for (int k = 0; k < STEP_LANE; ++k) ent[k] = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
                     if (skip != 0) {  // only the last step of a stream has lanes in front of its start
 #pragma unroll
-                        for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
+                        for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : make_uint2(0u, 0u);
                     }
                     uint32_t Tb = 0;  // bits of this lane's codes
 #pragma unroll
-                    for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k] >> 16;
+                    for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k].y;
                     const uint32_t incl = wave_incl_scan_u32(Tb);
                     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
                     const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
@@ -1379,11 +1487,10 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 #pragma unroll
                         for (int k = STEP_LANE - 1; k >= 0; k -= 2) {
                             // two symbols (at most 22 bits) per flush check: accbits < 32 before, < 54 after
-                            const uint32_t e1 = ent[k], e0 = ent[k - 1];
-                            const uint32_t l1 = e1 >> 16;
-                            const uint64_t pair = (uint64_t)((e1 & 0xFFFF) | ((e0 & 0xFFFF) << l1));
+                            const uint2 e1 = ent[k], e0 = ent[k - 1];
+                            const uint64_t pair = (uint64_t)(e1.x | (e0.x << e1.y));
                             acc |= pair << accbits;
-                            accbits += l1 + (e0 >> 16);
+                            accbits += e1.y + e0.y;
                             if (accbits >= 32) {
                                 atomicOr(&L.obuf[word], (uint32_t)acc);
                                 acc >>= 32;
@@ -1432,48 +1539,32 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         spos += flushed + nbytes;
                         base_bits = 0;
                         flushed = 0;
-                        if ((nst >> 2) != curblk) {
-                            // block finished: sequences section (or its one-byte stand-in), then the headers
+                        if ((nst >> 2) != curblk && !seqmode) {
+                            // block finished: a plain block ends with Number_of_Sequences = 0; then the headers
                             wave_lds_sync();
-                            uint32_t seqBytes = 1;  // a plain block ends with Number_of_Sequences = 0
-                            if (seqmode) {
-                                if ((uint64_t)spos + 8 + 8ull * nrec > cap) { FINISH(E_ZSTD); return; }
-                                seqBytes = encode_zero_run_sequences(L, out + spos, rec, nrec, lane, of_dist);
-                                frame_cp = frame_cp || of_dist == 0;
-                                wave_lds_sync();
-                                for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;  // it used the bit buffer
-                                wave_lds_sync();
-                            } else {
-                                if ((uint64_t)spos + 1 > cap) { FINISH(E_ZSTD); return; }
-                                if (lane == 0) out[spos] = 0;
-                            }
-                            if (lane == 0) {
-                                const uint32_t j = curblk, jb = b0 + j, jbs = blk_bs(j);
-                                const bool jsingle = jbs < 256u;
-                                const uint32_t lh = blk_lh(j), tsz = jb == 0 ? treeSize : 0u;
-                                const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
-                                const uint32_t lit = tsz + (jsingle ? 0u : 6u) + s0 + s1 + s2 + s3;
-                                uint8_t* bp = out + ocur;
-                                const uint32_t last = (lastRegion && jb + 1 == nblk) ? 1u : 0u;
-                                put_le(bp, ((lh + lit + seqBytes) << 3) | (2u << 1) | last, 3);
-                                const uint64_t type = jb == 0 ? 2 : 3;  // Compressed_Literals_Block / Treeless
-                                if (lh == 3) put_le(bp + 3, type | ((jsingle ? 0ull : 1ull) << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 14), 3);
-                                else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 18), 4);
-                                else put_le(bp + 3, type | (3ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 22), 5);
-                                if (!jsingle) {
-                                    uint8_t* tp = bp + 3 + lh + tsz;
-                                    put_le(tp, s0, 2);
-                                    put_le(tp + 2, s1, 2);
-                                    put_le(tp + 4, s2, 2);
-                                }
-                            }
-                            ocur = spos + seqBytes;
+                            if ((uint64_t)spos + 1 > cap) { FINISH(E_ZSTD); return; }
+                            if (lane == 0) out[spos] = 0;
+                            block_headers(curblk, ocur, 1u);
+                            ocur = spos + 1u;
                         }
                     }
 #pragma unroll
                     for (int k = 0; k < STEP_DW; ++k) cur[k] = nxt[k];
                     st = nst;
                     done = ndone;
+                }
+                if (seqmode && curblk != 0xFFFFFFFFu) {
+                    // a block with sequences is alone in its region: its sequences section and headers are written here, outside
+                    // the packing loop (the loop then carries none of the section's registers)
+                    wave_lds_sync();
+                    if ((uint64_t)spos + 8 + 8ull * nrec > cap) { FINISH(E_ZSTD); return; }
+                    const uint32_t seqBytes = encode_zero_run_sequences(L, out + spos, rec, nrec, lane, of_dist);
+                    frame_cp = frame_cp || of_dist == 0;
+                    wave_lds_sync();
+                    for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;  // it used the bit buffer
+                    wave_lds_sync();
+                    block_headers(curblk, ocur, seqBytes);
+                    ocur = spos + seqBytes;
                 }
                 opos = ocur;
             }
