@@ -1749,6 +1749,9 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     // byte i): by the time the block is done they have arrived
     uint32_t pf_byte = 0;
     bool pf_ok = false;
+    // fast path below: the one-byte sequences section ("no sequences") of a literals-only block is requested when the block is
+    // queued and looked at one block later (or when the frame ends): nobody waits for that load
+    uint32_t lazy_seq = 0;
     bool cp_avail = cp_count != 0 && (!partial || (sp.flags & DSPAN_FIRST));  // the trailer describes the frame's first sequences section
 
     for (;;) {
@@ -1782,7 +1785,46 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 pf_ok = true;
             }
         }
-        if (btype == 0) {  // Raw_Block
+        // ---- fast path: a compressed block of four treeless Huffman streams and nothing else (what the device encoder
+        // writes for the data bytes: 14 or 15 of a read's 16 or 17 blocks).  Same checks, same tasks as the general code
+        // below, without its detours; the verdict on the block's last byte -- it must say "no sequences" -- is collected
+        // later.  Anything else about the block sends it down the general path.
+        bool quick = false;
+        if (btype == 2 && huf_valid && ntask + 4 <= (uint32_t)WAVE && bsize >= 5 && bsize < BLOCK_MAX && (uint64_t)pos + bsize <= n) {
+            const uint64_t v = hwin(3);
+            const uint32_t h0 = (uint32_t)v & 0xFF, fmt = (h0 >> 2) & 3;
+            if ((h0 & 3) == 3 && fmt != 0) {
+                uint32_t lh, regen, csize;
+                if (fmt == 1) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; }
+                else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; }
+                else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; }
+                const uint64_t j = hwin(3 + lh);
+                const uint32_t s1 = (uint32_t)j & 0xFFFFu, s2 = (uint32_t)(j >> 16) & 0xFFFFu, s3 = (uint32_t)(j >> 32) & 0xFFFFu;
+                const uint32_t seg = (regen + 3) >> 2;
+                if (lh + csize + 1 == bsize && regen != 0 && csize >= 10 && regen <= BLOCK_MAX && regen <= block_max &&
+                    s1 + s2 + s3 <= csize - 6 && seg * 3 <= regen && (uint64_t)opos + regen <= fcs) {
+                    if (lazy_seq) FAIL();                   // the block before this one did have sequences after all
+                    lazy_seq = src[pos + bsize - 1];        // (every lane the same byte)
+                    const uint32_t q0 = pos + lh + 6, qn = csize - 6;
+                    if (lane < 4) {
+                        const uint32_t so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
+                        const uint32_t sz = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : qn - s1 - s2 - s3));
+                        L.t_src[ntask + lane] = q0 + so;
+                        L.t_size[ntask + lane] = sz;
+                        L.t_out[ntask + lane] = opos + (uint32_t)lane * seg;
+                        L.t_cnt[ntask + lane] = lane < 3 ? seg : regen - 3 * seg;
+                        L.t_tab[ntask + lane] = (uint32_t)cur_slot * (uint32_t)HUF_SLOT | ((uint32_t)cur_log << 16);
+                    }
+                    ntask += 4;
+                    wave_lds_sync();
+                    opos += regen;
+                    pos += bsize;
+                    quick = true;
+                }
+            }
+        }
+        if (quick) {
+        } else if (btype == 0) {  // Raw_Block
             if (bsize > block_max || pos + bsize > n || (uint64_t)opos + bsize > fcs) FAIL();
             for (uint32_t i = lane; i < bsize; i += WAVE) dst[opos + i] = src[pos + i];
             opos += bsize;
@@ -2377,6 +2419,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         }
     }
     if (restart) continue;
+    if (lazy_seq) FAIL();
     PHASE(0);
     if (ntask || d_active) {
         FLUSH();
