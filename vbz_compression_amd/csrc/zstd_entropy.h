@@ -1,15 +1,17 @@
-// zstd_entropy.h -- serial table construction for the zstd-format entropy stage.
+// zstd_entropy.h -- serial statements of the table construction of the zstd-format entropy stage.
 //
-// These are the small, inherently serial pieces of the encoder that one lane executes per frame
-// region (a few hundred steps over <= 256 symbols): length-limited Huffman code construction,
-// canonical code assignment, and the Huffman tree description (weights, FSE-compressed or direct).
-// They are plain integer functions over caller-provided workspaces so the same code runs on a
-// gfx950 lane (workspace in LDS) and under g++ in the CPU unit tests (tests/test_entropy_host.py).
+// Plain integer functions over caller-provided workspaces, compiled for gfx950 and under g++ (the CPU unit tests:
+// tests/test_entropy_host.py).  The device encoder runs wave-parallel forms of them (zstd_encode.hip: huf_build_wave,
+// huf_write_tree_wave) that must give the same bytes; the rare cases they leave alone fall back to these on one lane.
 //
-// The zstd format is RFC 8878; the construction below follows the published reference encoder's
-// choices (facebook/zstd lib/compress/huf_compress.c and fse_compress.c, the library the reference
-// links as zstd/1.4.8: CMakeLists.txt:92-93) so that, for the same byte histogram, the code lengths
-// and the tree description are the ones libzstd emits ("T4" in SURVEY.md section 7).
+//   huf_build_pm / huf_package_merge   code lengths: optimal under the length limit (package-merge) -- what the device builds
+//   huf_build / huf_set_max_height     libzstd's construction (HUF_buildCTable_wksp): kept as the yardstick of the CPU tests
+//   huf_write_tree, fse_*              Huffman tree description (weights, FSE-compressed or direct): libzstd's HUF_writeCTable
+//                                      byte for byte (facebook/zstd lib/compress/huf_compress.c, fse_compress.c, the
+//                                      library the reference links as zstd/1.4.8: CMakeLists.txt:92-93)
+//   Seq*                               predefined LL / ML encoding tables and value -> code maps of the sequences section
+//
+// The zstd format is RFC 8878.
 #pragma once
 
 #include <stdint.h>
