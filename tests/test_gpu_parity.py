@@ -275,6 +275,66 @@ def test_zstd_encode_cross_decodes_with_libzstd():
         assert _same(g, s)
 
 
+def test_sequences_section_round_and_lane_boundaries():
+    """The encoder's sequences section runs its two FSE state chains on all lanes (four-state warm-up walks; a lane whose
+    walks have not met takes its neighbour's state; rounds of 256 sequences).  Control-byte regions with exactly N runs, N
+    around every boundary of that scheme, with literal-length and match-length codes of one, two, three and four table
+    cells, must decode with libzstd and the restated decoder to the same bytes."""
+    import gpu_util as G
+
+    rng = np.random.default_rng(11)
+    streams, keys = [], []
+    for nruns in [1, 2, 3, 4, 5, 7, 8, 9, 63, 64, 65, 255, 256, 257, 259, 260, 261, 511, 512, 513, 767, 768, 769, 1500, 4000]:
+        for style in range(3):
+            parts = []
+            for _ in range(nruns):
+                if style == 0:      # long literal gaps (many-cell literal-length codes), runs of every length
+                    gap, run = int(rng.integers(1, 40)), int(rng.integers(12, 300))
+                elif style == 1:    # shortest runs (match-length code with two cells), no or one literal between them
+                    gap, run = int(rng.integers(1, 3)), int(rng.integers(12, 15))
+                else:               # literal lengths 0..3 and the match lengths around 12: the codes with several cells
+                    gap, run = int(rng.integers(1, 5)), 12 + int(rng.integers(0, 2)) * int(rng.integers(0, 40))
+                parts.append(rng.integers(1, 256, gap, dtype=np.uint8))
+                parts.append(np.zeros(run, np.uint8))
+            k = np.concatenate(parts)
+            data = rng.integers(0, 256, 3000, dtype=np.uint8) // rng.integers(1, 9)
+            streams.append(np.concatenate([k, data.astype(np.uint8)]))
+            keys.append(len(k))
+    frames = G.zstd_compress(streams, key_bytes=keys)
+    for s, f in zip(streams, frames):
+        assert not isinstance(f, int), f
+        back = O.zstd_decompress(f, len(s))
+        assert back is not None and back.tobytes() == s.tobytes(), len(s)
+        mine = O.zstd_restate_decompress(f, len(s))
+        assert mine is not None and mine.tobytes() == s.tobytes()
+    got = G.zstd_decompress(frames, [len(s) for s in streams])
+    for s, g in zip(streams, got):
+        assert _same(g, s)
+
+
+def test_region_larger_than_the_sort_key_counts():
+    """One wavefront on a 40 MB stream (ordinary path forced): the histogram of the data region exceeds the 24 bits the
+    table construction's sort keys hold and is scaled down; the code stays valid and the frame decodes everywhere."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import gpu_util as G, oracle_lib as O\n"
+        "rng = np.random.default_rng(5)\n"
+        "a = (rng.normal(0, 30, 20_000_000)).astype(np.int16)\n"
+        "o = G.codec().options(True, 2, 1, 1)\n"
+        "f = G.compress([a], o)[0]\n"
+        "assert not isinstance(f, int), f\n"
+        "assert O.decompress(f, a.nbytes, O.options(True, 2, 1, 1)).tobytes() == a.tobytes()\n"
+        "b = G.decompress([f], [a.nbytes], o)[0]\n"
+        "assert b.tobytes() == a.tobytes()\n"
+        "print('ok', len(f))\n" % os.path.dirname(os.path.abspath(__file__))
+    )
+    env = dict(os.environ, VBZ_HIP_SEGMENTED="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), (r.stdout[-400:], r.stderr[-1200:])
+
+
 def test_zstd_ratio_close_to_libzstd_on_signal():
     import gpu_util as G
 
