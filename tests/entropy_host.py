@@ -70,3 +70,116 @@ def parse_first_block_literals(frame):
         tl = 1 + hb if hb < 128 else 1 + (hb - 127 + 1) // 2
         tree = b[q : q + tl]
     return (t, regen, cs, tree, b[q + cs])
+
+
+def weights_from_tree(tree):
+    """Huffman code lengths [256] from a tree description (RFC 8878 4.2.1): direct 4-bit weights or FSE-coded weights."""
+    t = bytes(tree)
+    hb = t[0]
+    if hb >= 128:
+        nw = hb - 127
+        w = []
+        for i in range(nw):
+            b = t[1 + i // 2]
+            w.append(b >> 4 if i % 2 == 0 else b & 15)
+    else:
+        data = t[1 : 1 + hb]
+        val = int.from_bytes(data, "little")
+        pos = 0
+
+        def take(k):
+            nonlocal pos
+            v = (val >> pos) & ((1 << k) - 1)
+            pos += k
+            return v
+
+        log = take(4) + 5
+        remaining, threshold, nbits = (1 << log) + 1, 1 << log, log + 1
+        norm, prev0 = [], False
+        while remaining > 1 and len(norm) <= 255:
+            if prev0:
+                while True:
+                    r = take(2)
+                    norm.extend([0] * r)
+                    if r != 3:
+                        break
+                prev0 = False
+                continue
+            mx = (2 * threshold - 1) - remaining
+            v = (val >> pos) & ((1 << nbits) - 1)
+            if (v & (threshold - 1)) < mx:
+                c = v & (threshold - 1)
+                pos += nbits - 1
+            else:
+                c = v & (2 * threshold - 1)
+                if c >= threshold:
+                    c -= mx
+                pos += nbits
+            c -= 1
+            remaining -= abs(c)
+            norm.append(c)
+            prev0 = c == 0
+            while remaining < threshold:
+                nbits -= 1
+                threshold >>= 1
+        assert remaining == 1
+        hdr = (pos + 7) // 8
+        size = 1 << log
+        sym, high = [0] * size, size - 1
+        for s, c in enumerate(norm):
+            if c == -1:
+                sym[high] = s
+                high -= 1
+        step, p = (size >> 1) + (size >> 3) + 3, 0
+        for s, c in enumerate(norm):
+            for _ in range(max(c, 0)):
+                sym[p] = s
+                p = (p + step) & (size - 1)
+                while p > high:
+                    p = (p + step) & (size - 1)
+        nxt = [1 if c == -1 else c for c in norm]
+        tab = []
+        for u in range(size):
+            s = sym[u]
+            ns = nxt[s]
+            nxt[s] += 1
+            nb = log - (ns.bit_length() - 1)
+            tab.append((s, nb, (ns << nb) - size))
+        stream = int.from_bytes(data[hdr:], "little")
+        top = len(data[hdr:]) * 8 - 1
+        while not (stream >> top) & 1:
+            top -= 1
+        bitpos = top  # unread bits are [0, bitpos)
+        left = [bitpos]
+
+        def rd(k):
+            left[0] -= k
+            if left[0] >= 0:
+                return (stream >> left[0]) & ((1 << k) - 1)
+            have = k + left[0]  # bits that exist; the rest read as zero
+            return ((stream & ((1 << max(have, 0)) - 1)) << (k - max(have, 0))) if have > 0 else 0
+
+        s1, s2 = rd(log), rd(log)
+        w = []
+        while True:
+            e = tab[s1]
+            w.append(e[0])
+            s1 = e[2] + rd(e[1])
+            if left[0] < 0:
+                w.append(tab[s2][0])
+                break
+            e = tab[s2]
+            w.append(e[0])
+            s2 = e[2] + rd(e[1])
+            if left[0] < 0:
+                w.append(tab[s1][0])
+                break
+    total = sum((1 << (x - 1)) for x in w if x)
+    log2 = total.bit_length()
+    rest = (1 << log2) - total
+    assert rest and rest & (rest - 1) == 0
+    w.append(rest.bit_length())
+    nb = np.zeros(256, np.uint8)
+    for s, x in enumerate(w):
+        nb[s] = log2 + 1 - x if x else 0
+    return nb

@@ -777,7 +777,7 @@ def test_full_size_device_round_trip_properties():
 def test_zstd_encoder_tables_match_host_statement():
     """The wave-parallel table construction on the device (bitonic sort, package-merge, FSE-coded weights) must give the
     tree description that its serial host statement gives for the same bytes (zstd_entropy.h: huf_build_pm, checked for
-    optimality on the CPU; huf_write_tree, checked byte-for-byte against libzstd)."""
+    optimality on the CPU; huf_write_tree, checked byte-for-byte against libzstd).  Large regions: see below."""
     import entropy_host as E
     import gpu_util as G
 
@@ -790,16 +790,26 @@ def test_zstd_encoder_tables_match_host_statement():
     regions.append(np.clip(rng.normal(128, 4, 50000), 0, 255).astype(np.uint8))
     regions.append((rng.integers(0, 100, 30000) < 4).astype(np.uint8) * 16)               # two symbols
     frames = G.zstd_compress(regions)
-    checked = 0
+    checked = sampled = 0
     for data, f in zip(regions, frames):
         assert not isinstance(f, int)
         lit = E.parse_first_block_literals(f)
         if lit is None or lit[0] != 2:
             continue   # the encoder stored this region raw (too small to pay for a table)
         log, nb, tree = E.tree_description(data, package_merge=True)
-        assert lit[3] == tree, len(data)
+        if len(data) < (32 << 10):
+            assert lit[3] == tree, len(data)
+        else:
+            # regions of 32 KB and more may be coded from a histogram of a quarter of their bytes (zstd_encode.hip:
+            # region_histogram): the code must still have a word for every byte that occurs and cost at most 0.2 % more
+            mine = E.weights_from_tree(lit[3]).astype(np.int64)
+            cnt = np.bincount(data, minlength=256).astype(np.int64)
+            assert (mine[cnt > 0] > 0).all() and mine.max() <= 11
+            assert sum(2.0 ** -int(x) for x in mine if x) == 1.0
+            assert (cnt * mine).sum() <= 1.002 * (cnt * nb.astype(np.int64)).sum(), len(data)
+            sampled += lit[3] != tree
         checked += 1
-    assert checked >= 8
+    assert checked >= 8 and sampled >= 2
 
 
 def test_hdf5_filter_32020_calling_convention():

@@ -124,56 +124,6 @@ __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
     }
 }
 
-// histogram of in[0..n) into L.hist using all 64 lanes.  LDS atomics on a shared bin serialise, so four lane
-// groups count into four private copies (in the table-construction workspace, idle at this point) that are summed at
-// the end; every byte is one branch-free ds_add.
-__device__ void region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane)
-{
-    static_assert(sizeof(HufPmWksp) >= 4 * 256 * sizeof(uint32_t), "the sub-histograms live in the table-construction workspace");
-    uint32_t* sub = reinterpret_cast<uint32_t*>(&L.pm);
-    for (int i = lane; i < 4 * 256; i += WAVE) sub[i] = 0;
-    wave_lds_sync();
-    uint32_t* mine = sub + 256 * (lane & 3);
-    const uint32_t head = (uint32_t)((16u - ((uintptr_t)in & 15u)) & 15u);
-    const uint32_t h = head < n ? head : n;
-    if ((uint32_t)lane < h) atomicAdd(&mine[in[lane]], 1u);
-    const uint32_t nvec = (n - h) >> 4;
-    const uint4* vp = reinterpret_cast<const uint4*>(in + h);
-    for (uint32_t c0 = 0; c0 < nvec; c0 += 4 * WAVE) {
-        uint4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {  // four independent 16-byte loads in flight per lane
-            const uint32_t c = c0 + (uint32_t)u * WAVE + (uint32_t)lane;
-            q[u] = c < nvec ? vp[c] : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t c = c0 + (uint32_t)u * WAVE + (uint32_t)lane;
-            if (c < nvec) {
-                const uint32_t w[4] = { q[u].x, q[u].y, q[u].z, q[u].w };
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) atomicAdd(&mine[(w[k] >> (8 * j)) & 0xFFu], 1u);
-                }
-            }
-        }
-    }
-    const uint32_t tail0 = h + (nvec << 4);
-    if (tail0 + (uint32_t)lane < n) atomicAdd(&mine[in[tail0 + lane]], 1u);
-    wave_lds_sync();
-    for (int i = lane; i < 256; i += WAVE) L.hist[i] = sub[i] + sub[256 + i] + sub[512 + i] + sub[768 + i];
-    wave_lds_sync();
-}
-
-// ---- table construction, wave-cooperative ---------------------------------------------------------------
-// Code lengths: the present symbols are sorted by a bitonic network over the 64 lanes (four keys per lane), the optimal
-// lengths under the limit come from package-merge with every list of a level merged by the whole wavefront (binary
-// searches of the leaves among the packages and of the packages among the leaves), canonical codes from ballots in symbol
-// order -- the same lengths and codes as huf_build_pm() of zstd_entropy.h, its serial statement, which the CPU suite checks
-// for optimality and the GPU suite against the tree descriptions in the device's frames.  libzstd builds the unlimited
-// Huffman tree and repairs it (HUF_setMaxHeight); package-merge is never longer (0.02 % shorter on signal data) and has no
-// serial chain of 255 merges.  The tree description (huf_write_tree_wave below) is libzstd's for these lengths.
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
 #pragma unroll
@@ -191,6 +141,95 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
+// histogram of in[0..n) into L.hist using all 64 lanes.  LDS atomics on a shared bin serialise, so four lane
+// groups count into four private copies (in the table-construction workspace, idle at this point) that are summed at
+// the end; every byte is one branch-free ds_add.
+//
+// Regions of HIST_SAMPLE_FROM bytes or more are first counted on a quarter of their bytes (one kilobyte out of every four,
+// plus the unaligned ends).  If that sample shows HIST_SAMPLE_SEEN or more of the 256 byte values, the table is built from
+// it, every value it missed counted once: every byte of the region has a word, the code is within 0.03 % of the one the
+// full count would give on signal data, and at worst -- sixteen values that really never occur -- 0.2 % longer.  Otherwise
+// (narrow distributions, where words for absent values would cost more) the other three quarters are added and the
+// histogram is exact, as for the smaller regions.  Returns the number of bytes counted into L.hist.
+constexpr uint32_t HIST_SAMPLE_FROM = 32u << 10, HIST_SAMPLE_SEEN = 240;
+
+__device__ uint32_t region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane)
+{
+    static_assert(sizeof(HufPmWksp) >= 4 * 256 * sizeof(uint32_t), "the sub-histograms live in the table-construction workspace");
+    uint32_t* sub = reinterpret_cast<uint32_t*>(&L.pm);
+    for (int i = lane; i < 4 * 256; i += WAVE) sub[i] = 0;
+    wave_lds_sync();
+    uint32_t* mine = sub + 256 * (lane & 3);
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)in & 15u)) & 15u);
+    const uint32_t h = head < n ? head : n;
+    if ((uint32_t)lane < h) atomicAdd(&mine[in[lane]], 1u);
+    const uint32_t nvec = (n - h) >> 4;
+    const uint4* vp = reinterpret_cast<const uint4*>(in + h);
+    const uint32_t tail0 = h + (nvec << 4);
+    if (tail0 + (uint32_t)lane < n) atomicAdd(&mine[in[tail0 + lane]], 1u);
+    // chunk c (16 bytes) belongs to stripe c / WAVE; LANES stripes, STEP stripes apart, are in flight per trip
+    auto count = [&](uint32_t first_stripe, uint32_t stripe_step, uint32_t trip_stripes, int loads) {
+        for (uint32_t s0 = first_stripe; s0 * WAVE < nvec; s0 += trip_stripes) {
+            uint4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // independent 16-byte loads in flight per lane
+                const uint32_t c = (s0 + (uint32_t)u * stripe_step) * WAVE + (uint32_t)lane;
+                q[u] = (u < loads && c < nvec) ? vp[c] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t c = (s0 + (uint32_t)u * stripe_step) * WAVE + (uint32_t)lane;
+                if (u < loads && c < nvec) {
+                    const uint32_t w[4] = { q[u].x, q[u].y, q[u].z, q[u].w };
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) atomicAdd(&mine[(w[k] >> (8 * j)) & 0xFFu], 1u);
+                    }
+                }
+            }
+        }
+    };
+    auto total = [&]() -> uint32_t {   // sub-histograms -> L.hist; returns the number of byte values seen
+        wave_lds_sync();
+        uint32_t seen = 0;
+        for (int i = lane; i < 256; i += WAVE) {
+            const uint32_t c = sub[i] + sub[256 + i] + sub[512 + i] + sub[768 + i];
+            L.hist[i] = c;
+            seen += c ? 1u : 0u;
+        }
+        seen = wave_sum_u32(seen);
+        wave_lds_sync();
+        return seen;
+    };
+    if (n >= HIST_SAMPLE_FROM) {
+        count(0, 4, 16, 4);                      // stripes 0, 4, 8, 12 of every sixteen
+        const uint32_t seen = total();
+        if (seen >= HIST_SAMPLE_SEEN) {
+            for (int i = lane; i < 256; i += WAVE)
+                if (L.hist[i] == 0) L.hist[i] = 1;   // a value the sample missed may still occur: it gets a (long) word
+            wave_lds_sync();
+            const uint32_t stripes = (nvec + WAVE - 1) / WAVE, groups = stripes >> 2, last = stripes & 3u;
+            uint32_t chunks = groups * WAVE;     // sampled chunks: the first stripe of every group of four ...
+            if (last) chunks += (nvec - groups * 4u * WAVE) < (uint32_t)WAVE ? (nvec - groups * 4u * WAVE) : (uint32_t)WAVE;
+            return h + (n - tail0) + 16u * chunks + (256u - seen);
+        }
+        count(1, 1, 4, 3);                       // the rest: stripes 1, 2, 3 of every four
+    } else {
+        count(0, 1, 4, 4);
+    }
+    (void)total();
+    return n;
+}
+
+// ---- table construction, wave-cooperative ---------------------------------------------------------------
+// Code lengths: the present symbols are sorted by a bitonic network over the 64 lanes (four keys per lane), the optimal
+// lengths under the limit come from package-merge with every list of a level merged by the whole wavefront (binary
+// searches of the leaves among the packages and of the packages among the leaves), canonical codes from ballots in symbol
+// order -- the same lengths and codes as huf_build_pm() of zstd_entropy.h, its serial statement, which the CPU suite checks
+// for optimality and the GPU suite against the tree descriptions in the device's frames.  libzstd builds the unlimited
+// Huffman tree and repairs it (HUF_setMaxHeight); package-merge is never longer (0.02 % shorter on signal data) and has no
+// serial chain of 255 merges.  The tree description (huf_write_tree_wave below) is libzstd's for these lengths.
 // all lanes.  L.hist[0..maxSym] -> L.nbBits / L.ctable; returns the table log (uniform).
 // sub-phase timers of the timed kernel build (tools/phase_timing.py): slots 6.. of the phase counters
 #define SUB(k) do { if (tsub) { unsigned long long tn = __builtin_readcyclecounter(); tsub[k] += tn - *tl; *tl = tn; } } while (0)
@@ -564,7 +603,8 @@ __device__ __forceinline__ int huf_write_tree_wave(EncLds& L, uint32_t maxSym, u
 }
 
 // all lanes: choose the coding mode of a region from its histogram and, for Huffman, build the table
-__device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
+// S: bytes of the region; Sh: bytes its histogram counts (S, or the size of the sample: region_histogram)
+__device__ void region_plan(EncLds& L, uint32_t S, uint32_t Sh, uint32_t nblk, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
 {
     uint32_t mx = 0, msym = 0;
 #pragma unroll
@@ -578,15 +618,15 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane, unsi
     const uint32_t maxSym = wave_max_u32(msym);
     if (lane == 0) {
         L.treeSize = 0;
-        L.mode = maxCount == S ? 1u : 0u;
+        L.mode = maxCount == Sh ? 1u : 0u;     // (a sample is only used when it shows nearly all byte values: never here)
     }
     wave_lds_sync();
-    if (maxCount == S) return;
+    if (maxCount == Sh) return;
     if (S <= 63) return;                       // libzstd stores such literals raw (minLitSize)
-    if (maxCount <= (S >> 7) + 4) return;      // libzstd's "probably not compressible" heuristic
+    if (maxCount <= (Sh >> 7) + 4) return;     // libzstd's "probably not compressible" heuristic
     // the sort keys hold a count in 24 bits: scale the histogram of a larger region down (still a valid code)
     uint32_t shift = 0;
-    while ((S >> shift) >= (1u << 24)) shift++;
+    while ((Sh >> shift) >= (1u << 24)) shift++;
     if (shift) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -624,7 +664,8 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t nblk, int lane, unsi
     if (lane == 0) {
         bool ok = ts >= 0;
         if (ok) {
-            const uint64_t est = ((bits << shift) >> 3) + (uint64_t)ts + 14ull * nblk;
+            const uint64_t counted = (bits << shift) >> 3;   // bytes the counted part of the region would take
+            const uint64_t est = (Sh == S ? counted : counted * S / Sh) + (uint64_t)ts + 14ull * nblk;
             const uint64_t minGain = (S >> 6) + 2;  // ZSTD_minGain
             ok = est + minGain < S;
         }
@@ -1272,9 +1313,9 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             }
         }
         PHASE(0);
-        region_histogram(L, rin, S, lane);
+        const uint32_t Sh = region_histogram(L, rin, S, lane);
         PHASE(1);
-        region_plan(L, S, nblk, lane, TIMED ? tph : nullptr, &tlast);
+        region_plan(L, S, Sh, nblk, lane, TIMED ? tph : nullptr, &tlast);
         wave_lds_sync();
         PHASE(2);
         const uint32_t mode = L.mode;
