@@ -142,6 +142,13 @@ __device__ __forceinline__ int hbit(uint32_t v) { return 31 - __clz((int)v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
 __device__ __forceinline__ uint32_t lane_put(uint32_t reg, uint32_t l, uint32_t v, int lane) { return (uint32_t)lane == l ? v : reg; }
+// the same with wave-uniform l and v in scalar registers: one v_writelane_b32 (the lane select goes through m0: a VOP3
+// instruction of gfx9 reads one scalar register)
+__device__ __forceinline__ uint32_t lane_write(uint32_t reg, uint32_t l, uint32_t v)
+{
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(v), "s"(l) : "m0");
+    return reg;
+}
 
 // FSE table description (RFC 8878 4.1.1) read from LDS bytes; lane 0 only.
 // returns bytes consumed or -1; fills L.u.p.norm[0..nsym)
@@ -511,6 +518,35 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
         };
         uint32_t s1 = rd(log), s2 = rd(log);
         if (left < 0) return -1;
+        // Four weights per trip while neither the bit stream (a weight takes at most 6 bits) nor the weight count can run
+        // out inside a trip: no tests between the steps, one refill per trip, the weights collected across the lanes of a
+        // register (v_writelane) and written 64 at a time.  The last few weights go through the careful loop below.
+        {
+            uint32_t wcur = 0;   // lane j: weight number (nw & ~63) + j
+            while (left >= 24 && nw + 4 <= 252) {
+                if (have <= 32) {
+                    const uint32_t nd = idx >= 0 ? lane_get(dw, (uint32_t)idx) : 0u;
+                    --idx;
+                    buf |= (uint64_t)nd << (32u - have);
+                    have += 32;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t e = lane_get(tab, (g & 1) ? s2 : s1);
+                    wcur = lane_write(wcur, nw & 63u, e);
+                    ++nw;
+                    const uint32_t nb = (e >> 8) & 0xFF;
+                    const uint32_t v = (uint32_t)((buf >> 1) >> (63u - nb));
+                    buf <<= nb;
+                    have -= nb;
+                    left -= (int32_t)nb;
+                    if (g & 1) s2 = (e >> 16) + v;
+                    else s1 = (e >> 16) + v;
+                }
+                if ((nw & 63u) == 0) L.weights[nw - 64u + (uint32_t)lane] = (uint8_t)wcur;
+            }
+            if ((uint32_t)lane < (nw & 63u)) L.weights[(nw & ~63u) + (uint32_t)lane] = (uint8_t)wcur;
+        }
         for (;;) {
             if (nw > 253) return -1;
             uint32_t e = lane_get(tab, s1);
