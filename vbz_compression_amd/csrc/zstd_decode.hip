@@ -454,37 +454,60 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
         if (hdr > hb) return -1;
         // ---- FSE decoding table (4.1.1): lane u of `tab` = cell u (symbol | nbBits << 8 | base << 16)
         const uint32_t size = 1u << log, mask = size - 1;
-        uint32_t tab = 0, snext = 0, high = size - 1;
-        for (uint32_t s2 = 0; s2 < nsym; ++s2) {
-            const int c = (int)lane_get(nrm, s2);
-            if (c == -1) {
-                tab = lane_put(tab, high, s2, lane);
-                --high;
-                snext = lane_put(snext, s2, 1u, lane);
-            } else {
-                snext = lane_put(snext, s2, (uint32_t)c, lane);
-            }
-        }
+        // every lane builds its own cell (lane u = cell u; lane s also holds symbol s's count in nrm):
+        //   "less than one" symbols (count -1) take the cells from the top down, in symbol order;
+        //   the walk k -> (k * step) & mask, k = 0 .. size-1, visits every cell once; the cells it may use (<= high) take the
+        //   symbols' occurrences in order, i.e. the i-th usable cell of the walk holds the symbol whose occurrences include i;
+        //   a cell's state number is its symbol's count plus the cell's rank among that symbol's cells.
+        uint32_t tab;
         {
-            const uint32_t step = (size >> 1) + (size >> 3) + 3;
-            uint32_t pos = 0;
-            for (uint32_t s2 = 0; s2 < nsym; ++s2) {
-                const int c = (int)lane_get(nrm, s2);
-                for (int i = 0; i < c; ++i) {
-                    tab = lane_put(tab, pos, s2, lane);
-                    do {
-                        pos = (pos + step) & mask;
-                    } while (pos > high);
+            const int cnt = (uint32_t)lane < nsym ? (int)nrm : 0;
+            const uint64_t below = (1ull << lane) - 1ull;
+            const uint64_t lowp = __ballot(cnt == -1);
+            const uint32_t nlow = (uint32_t)__popcll(lowp);
+            if (nlow >= size) return -1;
+            const uint32_t high = size - 1 - nlow;
+            const uint32_t pos_cnt = cnt > 0 ? (uint32_t)cnt : 0u;
+            const uint32_t cum_incl = wave_incl_scan_u32(pos_cnt);           // occurrences of symbols 0 .. lane
+            if ((uint32_t)__shfl((int)cum_incl, 63, 64) + nlow != size) return -1;
+            // (1) low-probability symbols: symbol s with count -1 sits in cell size-1 - (its rank among them)
+            uint32_t sym_of_cell = 0xFFFFFFFFu;
+            {
+                const uint32_t my_top = size - 1u - (uint32_t)__popcll(lowp & below);   // for a lane that is such a symbol
+                // hand the symbol number to the lane that is its cell
+                for (uint64_t m = lowp; m; m &= m - 1) {
+                    const uint32_t sl = (uint32_t)__builtin_ctzll(m);
+                    const uint32_t cell = lane_get(my_top, sl);
+                    if ((uint32_t)lane == cell) sym_of_cell = sl;
                 }
             }
-            if (pos != 0) return -1;
-        }
-        for (uint32_t u = 0; u < size; ++u) {
-            const uint32_t s2 = lane_get(tab, u) & 0xFF;
-            const uint32_t ns = lane_get(snext, s2);
-            snext = lane_put(snext, s2, ns + 1, lane);
-            const uint32_t nb = log - (uint32_t)hbit(ns);
-            tab = lane_put(tab, u, s2 | (nb << 8) | ((((ns << nb) - size) & 0xFFFFu) << 16), lane);
+            // (2) the walk: lane k looks at cell (k * step) & mask
+            {
+                const uint32_t step = (size >> 1) + (size >> 3) + 3;
+                const uint32_t cell = ((uint32_t)lane * step) & mask;
+                const bool usable = (uint32_t)lane < size && cell <= high;
+                const uint64_t um = __ballot(usable);
+                const uint32_t occ = (uint32_t)__popcll(um & below);        // which occurrence this cell takes
+                // symbol of occurrence occ: the first symbol whose inclusive occurrence count exceeds occ
+                uint32_t sy = 0;
+                for (uint32_t s2 = 0; s2 + 1 < nsym; ++s2) sy += lane_get(cum_incl, s2) <= occ ? 1u : 0u;
+                // send (cell <- sy): lane `cell` must learn sy; cells are a permutation of the lanes below size
+                uint32_t sent = 0xFFFFFFFFu;
+                if ((uint32_t)lane < size) sent = (uint32_t)__builtin_amdgcn_ds_permute((int)(cell << 2), (int)(usable ? sy : 0xFFFFFFFFu));
+                if ((uint32_t)lane < size && sym_of_cell == 0xFFFFFFFFu) sym_of_cell = sent;
+            }
+            if (__any((uint32_t)lane < size && sym_of_cell >= nsym)) return -1;
+            // (3) state numbers in cell order
+            uint32_t rank = 0;
+            const uint32_t mysym = (uint32_t)lane < size ? sym_of_cell : 0xFFFFFFFFu;
+            for (uint32_t s2 = 0; s2 < nsym; ++s2) {
+                const uint64_t same = __ballot(mysym == s2);
+                if (mysym == s2) rank = (uint32_t)__popcll(same & below);
+            }
+            const int c0 = (int)(uint32_t)__shfl((int)nrm, (int)(mysym & 63u), 64);
+            const uint32_t ns = (c0 == -1 ? 1u : (uint32_t)c0) + rank;
+            const uint32_t nb = log - (uint32_t)hbit(ns ? ns : 1u);
+            tab = (uint32_t)lane < size ? (mysym | (nb << 8) | ((((ns << nb) - size) & 0xFFFFu) << 16)) : 0u;
         }
         // ---- the weights: two interleaved states over the backward bit stream in bytes [1 + hdr, 1 + hb)
         const uint32_t lowbit = 8 * (1 + hdr);
