@@ -369,11 +369,13 @@ __device__ __noinline__ int huf_read_weights(const uint8_t* p, int n, int* out_n
     return used;
 }
 
-// all lanes.  Huffman tree description at g[0..n) -> weights in L.weights, like huf_read_weights, but written as
-// wave-uniform code: the description (at most 129 bytes) sits across the lanes of one register (lane j = bytes
-// 4j..4j+3), so do the probabilities and the FSE table of the weights (at most 64 cells), and the two interleaved
-// state machines run on the scalar unit.  Returns bytes consumed, -1 for a corrupt description, -2 when the
-// description is legal but does not fit this layout (the caller falls back to huf_read_weights).
+// all lanes.  Huffman tree description at g[0..n) -> weights in L.weights, like huf_read_weights, with the description
+// (at most 129 bytes) across the lanes of one register (lane j = bytes 4j..4j+3), and so the probabilities and the FSE table
+// of the weights (at most 64 cells: every lane builds its own cell).  What is serial by nature -- the table description's
+// variable-width fields, the two interleaved state machines over the bit stream -- runs as wave-uniform code on the scalar
+// unit; the weights loop takes four weights per trip with no tests in between while neither bits nor weights can run out.
+// Returns bytes consumed, -1 for a corrupt description, -2 when the description is legal but does not fit this layout (the
+// caller falls back to huf_read_weights).
 __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lane, uint32_t* out_nw, uint32_t* out_log)
 {
     const uint32_t n = uni(n_);

@@ -9,8 +9,9 @@
 //
 //   * the svb stream is cut into two REGIONS, control bytes and data bytes, because their byte
 //     statistics differ completely (control bytes are mostly 0x00); each region gets its own
-//     Huffman table, built exactly the way libzstd builds it (zstd_entropy.h), so the table and
-//     the code lengths are the ones the reference would have produced for those bytes;
+//     Huffman table: code lengths by package-merge (optimal under the 11-bit limit; libzstd's own
+//     construction, a serial merge chain, is never shorter), tree description written the way
+//     libzstd writes it (zstd_entropy.h holds the serial statements of both);
 //   * the data-byte region is cut into near-equal BLOCKS of 4 Huffman streams each; the first block
 //     carries the tree description, the others are "treeless" (reuse the table), which the format
 //     allows.  A frame thus exposes up to 64 independent bit streams: one per lane of the wavefront
@@ -23,9 +24,11 @@
 //     also reproduces the reference's known answers for tiny inputs (vbz/test/vbz_test.cpp:238).
 //
 // One wavefront (64 lanes) per frame, 16 waves per CU.  Per region: histogram (LDS atomics into four
-// private copies) -> table construction (wave-cooperative, the inherently serial parts on one lane or
-// on the scalar unit) -> packing: the wave packs one stream at a time, 1024 symbols per step, with a
-// prefix sum of bit counts; streams are written in frame order and block headers are filled in last.
+// private copies; a quarter of the bytes where that is enough) -> table construction (all lanes: bitonic
+// sort, package-merge, two-lane FSE chains for the tree description) -> packing: the wave packs one
+// stream at a time, 1024 symbols per step, with a prefix sum of bit counts; streams are written in
+// frame order and block headers are filled in last.  The kernel's time follows the number of
+// instructions a wavefront executes, so nothing in it is left to one lane that all lanes can do.
 // Algorithmic HBM bytes per svb byte: 1 read + ~0.67 written.
 #include "vbz_kernels.h"
 #include "zstd_entropy.h"
@@ -689,7 +692,7 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t Sh, uint32_t nblk, i
 // so the offset costs no bits: OF table in RLE mode, code 0), its first zero stays a literal, and the
 // literals (everything outside the run tails) are Huffman coded as before.  Which bytes are run tails is a
 // morphological open of the zero mask, computed with shifts on a 64-bit window per lane; positions come from
-// wave prefix sums.  Only the FSE state chains of the sequences are serial (wave-uniform code on the scalar unit).
+// wave prefix sums; the FSE state chains of the sequences section run on all lanes too (encode_zero_run_sequences).
 #ifndef VBZ_RMIN
 #define VBZ_RMIN 12
 #endif
