@@ -312,6 +312,43 @@ def test_sequences_section_round_and_lane_boundaries():
         assert _same(g, s)
 
 
+def test_sampled_histogram_that_misleads():
+    """Regions of 32 KB and more are coded from a histogram of every fourth kilobyte when that sample shows nearly all byte
+    values (zstd_encode.hip: region_histogram).  Data whose sampled kilobytes look nothing like the rest -- here: almost
+    constant where the sample looks, uniform noise elsewhere -- would be coded 37 % LONGER than it is; the encoder has to
+    notice, start the region over with the exact histogram and end up no larger than the stored form."""
+    import gpu_util as G
+
+    rng = np.random.default_rng(21)
+    streams = []
+    for n in (40000, 131072, 200000, 1 << 20):
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        for s0 in range(0, n, 4096):                       # the sampled stripe of every four: zeros, every value sprinkled in
+            stripe = np.zeros(min(1024, n - s0), np.uint8)
+            k = min(len(stripe), 256)
+            stripe[rng.permutation(len(stripe))[:k]] = np.arange(k, dtype=np.uint8)
+            a[s0 : s0 + len(stripe)] = stripe
+        streams.append(a)
+        b = a.copy()                                        # the other way round: noise where the sample looks, zeros elsewhere
+        b[:] = 0
+        for s0 in range(0, n, 4096):
+            m = min(1024, n - s0)
+            b[s0 : s0 + m] = rng.integers(0, 256, m, dtype=np.uint8)
+        streams.append(b)
+    frames = G.zstd_compress(streams)
+    for s, f in zip(streams, frames):
+        assert not isinstance(f, int), (len(s), f)
+        assert len(f) <= len(s) + (len(s) >> 7) + 64, (len(s), len(f))
+        back = O.zstd_decompress(f, len(s))
+        assert back is not None and back.tobytes() == s.tobytes(), len(s)
+    got = G.zstd_decompress(frames, [len(s) for s in streams])
+    for s, g in zip(streams, got):
+        assert _same(g, s)
+    # the second kind is highly compressible once counted properly (3/4 zeros): the exact histogram must have been used
+    for s, f in zip(streams[1::2], frames[1::2]):
+        assert len(f) < 0.45 * len(s), (len(s), len(f))
+
+
 def test_region_larger_than_the_sort_key_counts():
     """One wavefront on a 40 MB stream (ordinary path forced): the histogram of the data region exceeds the 24 bits the
     table construction's sort keys hold and is scaled down; the code stays valid and the frame decodes everywhere."""

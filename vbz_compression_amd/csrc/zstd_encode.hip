@@ -159,7 +159,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // histogram is exact, as for the smaller regions.  Returns the number of bytes counted into L.hist.
 constexpr uint32_t HIST_SAMPLE_FROM = 32u << 10, HIST_SAMPLE_SEEN = 240;
 
-__device__ uint32_t region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane)
+__device__ uint32_t region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane, bool allow_sample)
 {
     static_assert(sizeof(HufPmWksp) >= 4 * 256 * sizeof(uint32_t), "the sub-histograms live in the table-construction workspace");
     uint32_t* sub = reinterpret_cast<uint32_t*>(&L.pm);
@@ -208,7 +208,7 @@ __device__ uint32_t region_histogram(EncLds& L, const uint8_t* in, uint32_t n, i
         wave_lds_sync();
         return seen;
     };
-    if (n >= HIST_SAMPLE_FROM) {
+    if (allow_sample && n >= HIST_SAMPLE_FROM) {
         count(0, 4, 16, 4);                      // stripes 0, 4, 8, 12 of every sixteen
         const uint32_t seen = total();
         if (seen >= HIST_SAMPLE_SEEN) {
@@ -1260,7 +1260,13 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             }
         }
     }
-    for (int region = 0; region < (span_mode ? 1 : (int)nunit); ++region) {
+    // A table built from a sampled histogram (region_histogram) gives every byte a word, but on data whose sampled kilobytes do
+    // not resemble the rest it can code a region longer than it is, or call compressible data incompressible.  A region
+    // coded from a sample that outgrows its own size (or the destination), or that the sample says does not pay, is done
+    // again from the exact histogram, which knows what it costs (exact_hist; only regions without sequences are sampled,
+    // so nothing that was tokenised is touched twice).
+    bool exact_hist = false;
+    for (int region = 0; region < (span_mode ? 1 : (int)nunit);) {
         const uint32_t cidx = region > 0 ? (uint32_t)region - 1u : 0u;  // chunk of the data region (0 unless long repeats were found)
         const uint32_t r0 = span_mode ? sp.r0 : (region == 0 ? 0 : K + cidx * chunk);
         const uint32_t r1 = span_mode ? sp.r1 : (region == 0 ? (K ? K : N) : ((deepD && N - r0 > chunk) ? r0 + chunk : N));
@@ -1319,11 +1325,27 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             }
         }
         PHASE(0);
-        const uint32_t Sh = region_histogram(L, rin, S, lane);
+        const uint32_t opos_region = opos;
+        bool need_redo = false;
+        {
+        const uint32_t Sh = region_histogram(L, rin, S, lane, !exact_hist && !seqmode);
+#define OVERRUN()                                       \
+    do {                                                \
+        if (Sh != S) {                                  \
+            need_redo = true;                           \
+            goto region_done;                           \
+        }                                               \
+        FINISH(E_ZSTD);                                 \
+        return;                                         \
+    } while (0)
         PHASE(1);
         region_plan(L, S, Sh, nblk, lane, TIMED ? tph : nullptr, &tlast);
         wave_lds_sync();
         PHASE(2);
+        if (Sh != S && L.mode != 2u) {   // "does not pay" is not taken from a sample's word
+            need_redo = true;
+            goto region_done;
+        }
         const uint32_t mode = L.mode;
         if (seqmode && mode != 2) {
             // literals do not pay for a Huffman table: Raw_Literals_Block + sequences in one compressed block
@@ -1340,7 +1362,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             frame_cp = frame_cp || of_dist == 0;
             if (lane == 0) put_le(bp, ((lh + S + sb) << 3) | (2u << 1) | (lastRegion ? 1u : 0u), 3);
             opos += 3 + lh + S + sb;
-            continue;
+            goto region_done;
         }
         if (mode == 1) {
             // RLE blocks (Block_Type 1): Block_Size = run length, one byte of content
@@ -1357,7 +1379,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 }
             }
             opos += 4 * nb;
-            continue;
+            goto region_done;
         }
         if (mode == 0) {
             // raw blocks (Block_Type 0), copied by the whole wave
@@ -1373,7 +1395,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 opos += bs;
                 done += bs;
             }
-            continue;
+            goto region_done;
         }
         // ---- Huffman blocks: passes of up to 16 blocks = 64 streams
         const uint32_t base = S / nblk, extra = S % nblk;
@@ -1493,7 +1515,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         curblk = st >> 2;
                         const uint32_t tsz = (b0 + curblk) == 0 ? treeSize : 0u;
                         const uint32_t hl = 3u + blk_lh(curblk) + tsz + (blk_bs(curblk) < 256u ? 0u : 6u);
-                        if ((uint64_t)ocur + hl > cap) { FINISH(E_ZSTD); return; }
+                        if ((uint64_t)ocur + hl > cap) OVERRUN();
                         for (uint32_t i = lane; i < tsz; i += WAVE) out[ocur + 3u + blk_lh(curblk) + i] = L.tree[i];
                         spos = ocur + hl;
                     }
@@ -1525,7 +1547,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
                     const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
                     const uint32_t fq = allbits >> 7;             // complete 16-byte quads
-                    if ((uint64_t)spos + flushed + 16ull * fq + 24 > cap) { FINISH(E_ZSTD); return; }
+                    if ((uint64_t)spos + flushed + 16ull * fq + 24 > cap) OVERRUN();
                     {
                         const uint32_t pos = base_bits + incl - Tb;
                         uint32_t word = pos >> 5;
@@ -1589,7 +1611,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         if ((nst >> 2) != curblk && !seqmode) {
                             // block finished: a plain block ends with Number_of_Sequences = 0; then the headers
                             wave_lds_sync();
-                            if ((uint64_t)spos + 1 > cap) { FINISH(E_ZSTD); return; }
+                            if ((uint64_t)spos + 1 > cap) OVERRUN();
                             if (lane == 0) out[spos] = 0;
                             block_headers(curblk, ocur, 1u);
                             ocur = spos + 1u;
@@ -1615,8 +1637,20 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 }
                 opos = ocur;
             }
+            if (Sh != S && opos - opos_region > S + (S >> 6) + 256u) need_redo = true;
             wave_lds_sync();
             PHASE(5);
+        }
+#undef OVERRUN
+        }
+    region_done:
+        if (need_redo) {
+            exact_hist = true;
+            opos = opos_region;
+            wave_lds_sync();
+        } else {
+            exact_hist = false;
+            ++region;
         }
     }
     const uint32_t main_bytes = opos;
