@@ -30,26 +30,43 @@ FILES = [BLOB[e["offset"] : e["offset"] + e["size"]] for e in INDEX]
 OPTION_SETS = [(zz, isz, lvl, ver) for zz in (True, False) for isz in (0, 1, 2, 4) for lvl in (0, 1) for ver in (0, 1)]
 
 E_ZSTD, E_INPUT, E_DEST, E_STREAM, E_OOM = 0xFFFFFFFF, 0xFFFFFFFE, 0xFFFFFFFC, 0xFFFFFFFB, 0xFFFFFFF9
+# calls per class of documented divergence (see _allowed), as measured on the MI355X
+PINNED_CLASSES = {"legacy": 11848}
 
 
-def _allowed(want, got, level):
-    """The documented divergences from the reference on MALFORMED input (include/vbz.h):
-    * the reference mallocs whatever content size the frame header claims and reports OUT_OF_MEMORY when that fails
+# zstd's pre-v0.8 frame formats (magic 0xFD2FB522 ... 0xFD2FB527).  They are not RFC 8878 frames; libzstd decodes them only
+# when built with ZSTD_LEGACY_SUPPORT (the distribution's libzstd.so.1.4.8 is: 32 of the 238 corpus files start with the
+# v0.7 magic).  vbz never writes them; the device decoder reports VBZ_ZSTD_ERROR for them (include/vbz.h).
+LEGACY_MAGICS = {0xFD2FB520 | k for k in range(2, 8)}
+
+
+def _legacy_frame(f, sized):
+    o = 4 if sized else 0
+    return len(f) >= o + 4 and int.from_bytes(bytes(f[o : o + 4]), "little") in LEGACY_MAGICS
+
+
+def _allowed(want, got, level, legacy):
+    """The documented divergences from the reference on MALFORMED input (include/vbz.h).  Returns the
+    name of the class, or None.  Apart from the legacy formats -- a predicate on the INPUT BYTES, not on what the device
+    answered -- every class is a rule about calls the ORACLE ITSELF FAILED: a call the oracle decodes must give its bytes.
+    * "legacy": the frame is in a pre-v0.8 zstd format (see LEGACY_MAGICS): VBZ_ZSTD_ERROR, whatever a libzstd with legacy
+      support makes of it;
+    * "oom": the reference mallocs whatever content size the frame header claims and reports OUT_OF_MEMORY when that fails
       (vbz.cpp:252-256); the device path never allocates per read: it reports the error it finds instead;
-    * a frame whose content size exceeds what ANY svb stream of the expected length can be is reported as a stream
-      error without being decoded (the reference decodes it and fails in the svb stage, or runs out of memory);
-    * libzstd 1.4.8 accepts a few malformed bit streams that RFC 8878 forbids; the device decoder is strict, so the
-      reference may get as far as a svb-stage error (or even a result) where the device reports VBZ_ZSTD_ERROR.
+    * "oversize": a frame whose content size exceeds what ANY svb stream of the expected length can be is reported as a
+      stream error without being decoded (the reference decodes it and fails in the zstd or svb stage).
     None of them applies to a valid buffer, and none without the zstd stage (level 0 is exact)."""
     if level == 0:
-        return False
-    if want == E_OOM:
-        return got >= E_OOM
+        return None
+    if legacy and got == E_ZSTD:
+        return "legacy"
+    if want < E_OOM:
+        return None
+    if want == E_OOM and got >= E_OOM:
+        return "oom"
     if got == E_STREAM and want in (E_ZSTD, E_DEST):
-        return True
-    if got == E_ZSTD:
-        return True
-    return False
+        return "oversize"
+    return None
 
 
 def _decompress_batch(files, guesses, opts, sized):
@@ -78,14 +95,18 @@ def _decompress_batch(files, guesses, opts, sized):
 
 def test_fuzz_corpus_decompress_every_guessed_size():
     """vbz_fuzz.cpp:138-161 on the device: 32 option sets x sized/unsized x 238 files x every guessed size."""
-    calls = exact = allowed = successes = 0
+    calls = exact = successes = 0
+    classes = {}
     diverged = {}
     for (zz, isz, lvl, ver) in OPTION_SETS:
         oo = O.options(zz, isz, lvl, ver)
         go = _lib.CompressionOptions(zz, isz, lvl, ver)
         sweeps = [O.fuzz_sweep(f, oo) for f in FILES]
         guesses = [list(range(G + 1)) for G, _ in sweeps]
+        owner = np.repeat(np.arange(len(FILES)), [len(g) for g in guesses])
+        flat_guess = np.concatenate([np.array(g) for g in guesses])
         for sized in (False, True):
+            legacy = np.array([_legacy_frame(f, sized) for f in FILES])
             want = np.concatenate([r[:, 1 if sized else 0] for _, r in sweeps]).astype(np.int64)
             got, doff, dst = _decompress_batch(FILES, guesses, go, sized)
             assert len(got) == len(want)
@@ -97,22 +118,21 @@ def test_fuzz_corpus_decompress_every_guessed_size():
             successes += len(ok)
             if len(ok):
                 host = dst.cpu().numpy()
-                owner = np.repeat(np.arange(len(FILES)), [len(g) for g in guesses])
-                flat_guess = np.concatenate([np.array(g) for g in guesses])
                 for k in ok[:: max(1, len(ok) // 400)]:  # a spread of them (level 0 / size 0 gives tens of thousands)
                     ref = O.decompress(FILES[owner[k]], int(flat_guess[k]), oo, sized=sized)
                     assert not isinstance(ref, int)
                     assert host[doff[k] : doff[k] + int(want[k])].tobytes() == ref.tobytes()
             for k in np.nonzero(~same)[0]:
-                if _allowed(int(want[k]), int(got[k]), lvl):
-                    allowed += 1
+                cls = _allowed(int(want[k]), int(got[k]), lvl, bool(legacy[owner[k]]))
+                if cls:
+                    classes[cls] = classes.get(cls, 0) + 1
                 else:
-                    diverged.setdefault((zz, isz, lvl, ver, sized), []).append((int(k), hex(int(want[k])), hex(int(got[k]))))
+                    diverged.setdefault((zz, isz, lvl, ver, sized), []).append((int(owner[k]), int(flat_guess[k]), hex(int(want[k])), hex(int(got[k]))))
     assert not diverged, {k: v[:5] for k, v in list(diverged.items())[:8]}
     assert calls > 900000 and successes > 1000
-    # the allow-list is for a handful of malformed zstd frames, not a loophole
-    assert allowed < calls * 0.02, (allowed, calls)
-    print("fuzz decompress: %d calls, %d exact verdicts, %d allowed divergences, %d successes" % (calls, exact, allowed, successes))
+    print("fuzz decompress: %d calls, %d exact verdicts, %d successes, documented divergences %s" % (calls, exact, successes, classes))
+    # every class is pinned: a decoder change that moves a verdict shows up here even when it stays inside a class
+    assert classes == PINNED_CLASSES, classes
 
 
 def test_fuzz_corpus_compress_round_trips():

@@ -1753,14 +1753,25 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         if (!err) {
             const uint32_t magic = h[0] | (h[1] << 8) | (h[2] << 16) | ((uint32_t)h[3] << 24);
             const uint32_t fhd = h[4];
-            const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
-            if (magic != 0xFD2FB528u || (fhd & 0x08) || did != 0) err = 1;
+            const int fcs_flag = fhd >> 6, single = (fhd >> 5) & 1, did_flag = fhd & 3;
+            if (magic != 0xFD2FB528u || (fhd & 0x08)) err = 1;
             pos = 5;
             if (!single) {
                 const uint32_t wd = h[pos++];
                 const int wlog = 10 + (int)(wd >> 3);
                 if (wlog > 31) err = 1;
                 window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
+            }
+            // Dictionary_ID field (0, 1, 2 or 4 bytes): the value 0 means "no dictionary" and is accepted like libzstd does;
+            // any other dictionary is one this decoder does not have (libzstd: dictionary_wrong), reported behind the
+            // content-size check like ZSTD_getFrameContentSize + ZSTD_decompress would (vbz.cpp:236-273)
+            bool foreign_dict = false;
+            {
+                const uint32_t dsz = did_flag == 3 ? 4u : (uint32_t)did_flag;
+                if (pos + dsz > n) err = 1;
+                else
+                    for (uint32_t i = 0; i < dsz; ++i) foreign_dict |= h[pos + i] != 0;
+                pos += dsz;
             }
             const int fsz = fcs_flag == 0 ? (single ? 1 : 0) : (fcs_flag == 1 ? 2 : (fcs_flag == 2 ? 4 : 8));
             if (fsz == 0) err = 1;  // unknown content size: the reference rejects it too (vbz.cpp:236-240)
@@ -1771,6 +1782,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 pos += fsz;
                 if (single) window = fcs;
                 if (!err && fcs > cap) err = 2;  // dstSize_tooSmall
+                if (!err && foreign_dict) err = 1;
             }
             L.ctl[C_A] = pos;
             L.ctl[C_B] = (uint32_t)fcs;
