@@ -24,6 +24,10 @@
  *     with any libzstd / the reference's vbz_decompress, but are not byte-identical to libzstd's.
  *     A compressed buffer may end in one zstd skippable frame (magic 0x184D2A5B, <= 272 bytes) with
  *     checkpoints for this library's parallel decoder; libzstd skips it (RFC 8878 3.1.2).
+ *   - the decoder reads RFC 8878 frames only.  zstd's legacy frame formats (v0.2 ... v0.7, magic 0xFD2FB522 ... 27), which
+ *     a libzstd built with ZSTD_LEGACY_SUPPORT also decodes, are VBZ_ZSTD_ERROR here (no vbz writer ever produced them;
+ *     32 files of the reference's fuzz corpus start with the v0.7 magic).  A frame may carry a Dictionary_ID field of 0
+ *     ("no dictionary"); any other dictionary is VBZ_ZSTD_ERROR, as with libzstd when it has not got that dictionary.
  */
 #ifndef VBZ_H_MI355X
 #define VBZ_H_MI355X
@@ -68,10 +72,11 @@ struct CompressionOptions
     /* 0 (no streamvbyte stage), 1, 2 or 4 */
     unsigned int integer_size;
     /* 0 = no zstd stage; any other value selects this library's zstd-format entropy stage.  The reference hands the level to
-     * libzstd (vbz/vbz.cpp:194-207); here it picks how hard the encoder looks for matches: 1-3 = Huffman-coded literals plus
-     * run sequences (what libzstd levels 1-3 get out of nanopore signal); >= 4 additionally searches the data bytes for ONE
-     * long repeat distance (a read that repeats a template: the reference's own perf generator) and codes the repeats as
-     * matches at that distance.  Decoding does not depend on the level. */
+     * libzstd (vbz/vbz.cpp:194-207); this encoder does the same work at every level: Huffman-coded literals, run sequences
+     * for the control bytes (what libzstd gets out of nanopore signal), and -- for a read that repeats a template, like the
+     * reads of the reference's own perf generator -- ONE long repeat distance in the data bytes, coded as matches at that
+     * distance (what libzstd's match finder makes of such reads at any level).  Reads of half a megabyte and more (the
+     * large-read path) are coded without the repeat distance.  Decoding does not depend on the level. */
     unsigned int zstd_compression_level;
     /* 0 or 1 (identical for integer_size 2 and 4, reference vbz/v1/vbz_streamvbyte.cpp:46-61) */
     unsigned int vbz_version;

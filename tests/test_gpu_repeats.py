@@ -1,9 +1,10 @@
-"""GPU tests (-m gpu) of the long-repeat matcher (zstd_compression_level >= 4).
+"""GPU tests (-m gpu) of the long-repeat matcher.
 
-The reference hands any level to libzstd (vbz/vbz.cpp:194-207) and its own perf generator fills reads by cycling a
-15 643-sample template (vbz/perf/test_data_generator.h:61-67), on which libzstd reaches ratios of 15-30.  Levels 1-3 of
-this library find runs only (distance 1); from level 4 the encoder also looks for ONE repeat distance in the data bytes and
-codes every period after the first as matches with that explicit offset."""
+The reference hands any level to libzstd (vbz/vbz.cpp:194-207), whose match finder is on at every level, and its own perf
+generator fills reads by cycling a 15 643-sample template (vbz/perf/test_data_generator.h:61-67), on which libzstd level 1
+reaches ratios of 15-30.  The encoder here looks for ONE repeat distance in the data bytes of every read, at every level
+(a cheap probe in the ordinary kernel; reads that have one are coded by a second launch with the matcher), and codes every
+period after the first as matches with that explicit offset: same options, same input -> about the same ratio."""
 import os
 
 import numpy as np
@@ -34,26 +35,29 @@ def test_template_cycling_reads_compress_like_libzstd():
     oo1, oo4 = O.options(True, 2, 1, 1), O.options(True, 2, 4, 1)
     g1 = G.compress(reads, _lib.CompressionOptions(True, 2, 1, 1))
     g4 = G.compress(reads, _lib.CompressionOptions(True, 2, 4, 1))
-    back = G.decompress(g4, [a.nbytes for a in reads], _lib.CompressionOptions(True, 2, 4, 1))
-    for i, (a, f1, f4, b) in enumerate(zip(reads, g1, g4, back)):
-        assert not isinstance(f4, int) and not isinstance(b, int)
-        assert b.tobytes() == a.tobytes()                                           # device decodes its own frame
-        assert O.decompress(f4, a.nbytes, oo4).tobytes() == a.tobytes()              # ... and so does the reference's decoder
-        ref = O.compress(a, oo1)                                                     # libzstd level 1
-        r4, r1, rr = a.nbytes / len(f4), a.nbytes / len(f1), a.nbytes / len(ref)
-        if i < len(lengths):
-            assert r1 < 3.0                              # runs alone do not see the period
-            assert r4 > 0.8 * rr and r4 > 1.7 * r1, (i, r4, rr, r1)   # the matcher does: about what libzstd gets
-            print("cycled read of %d samples: level 1 %.2f, level 4 %.2f, libzstd %.2f" % (len(a), r1, r4, rr))
-        elif i == len(lengths):
-            assert abs(len(f4) - len(f1)) <= 16, (len(f4), len(f1))
-        else:
-            assert r4 > 0.5 * rr, (r4, rr)
+    for level, frames, oo in ((1, g1, oo1), (4, g4, oo4)):
+        back = G.decompress(frames, [a.nbytes for a in reads], _lib.CompressionOptions(True, 2, level, 1))
+        for i, (a, f, b) in enumerate(zip(reads, frames, back)):
+            assert not isinstance(f, int) and not isinstance(b, int)
+            assert b.tobytes() == a.tobytes()                                           # device decodes its own frame
+            assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes()                # ... and so does the reference's decoder
+            ref = O.compress(a, oo)                                                      # libzstd at the SAME level
+            r, rr = a.nbytes / len(f), a.nbytes / len(ref)
+            if i < len(lengths):
+                # same options, same input: about what libzstd gets (T2; round 2 asserted r < 3 here at level 1)
+                assert r > 0.8 * rr, (level, i, r, rr)
+                print("cycled read of %d samples, level %d: %.2f, libzstd %.2f" % (len(a), level, r, rr))
+            elif i == len(lengths):
+                assert abs(r / rr - 1) < (0.01 if level == 1 else 0.02), (level, r, rr)  # plain signal: the +-1 % contract (level 1)
+            else:
+                assert r > 0.5 * rr, (level, r, rr)
+    for f1, f4 in zip(g1, g4):   # the matcher does not depend on the level
+        assert len(f1) == len(f4)
 
 
-def test_level_four_on_every_dtype_and_shape():
+def test_matcher_on_every_dtype_and_shape():
     """The matcher must never cost correctness: every integer size, zig-zag or not, periodic or not, sizes around the tile
-    and block boundaries, sized and unsized -- decoded by the device and by the reference's decoder."""
+    and block boundaries, sized and unsized, levels 1 and 4 -- decoded by the device and by the reference's decoder."""
     rng = np.random.default_rng(13)
     cases = []
     for dt, size in ((np.int16, 2), (np.int32, 4), (np.int8, 1), (np.uint32, 4), (np.uint16, 2)):
@@ -68,9 +72,9 @@ def test_level_four_on_every_dtype_and_shape():
     for zz in (True, False):
         for sized in (False, True):
             bufs = [a for a, _ in cases]
-            for size in (1, 2, 4):
+            for size, level in ((1, 4), (2, 1), (2, 4), (4, 1)):
                 sel = [a for a, sz in cases if sz == size]
-                go, oo = _lib.CompressionOptions(zz, size, 4, 0), O.options(zz, size, 4, 0)
+                go, oo = _lib.CompressionOptions(zz, size, level, 0), O.options(zz, size, level, 0)
                 frames = G.compress(sel, go, sized=sized)
                 back = G.decompress(frames, [a.nbytes for a in sel], go, sized=sized)
                 for a, f, b in zip(sel, frames, back):
@@ -78,5 +82,5 @@ def test_level_four_on_every_dtype_and_shape():
                     assert b.tobytes() == a.tobytes()
                     assert O.decompress(f, a.nbytes, oo, sized=sized).tobytes() == a.tobytes()
                     if len(a) >= 32768 and len(a) <= 150000:
-                        ref = O.compress(a, oo, sized=sized)      # libzstd level 4
+                        ref = O.compress(a, oo, sized=sized)      # libzstd at the same level
                         assert len(f) <= 1.6 * len(ref) + 64 or len(f) <= 0.45 * a.nbytes, (len(a), size, zz, len(f), len(ref))

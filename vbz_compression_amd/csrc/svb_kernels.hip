@@ -68,13 +68,35 @@ __device__ __forceinline__ uint32_t svb_encode_check(uint32_t size, uint32_t cap
     return 0;
 }
 
+// ---- probe for a long repeat distance in the data bytes (consumed by zstd_encode.hip's long-repeat coder) -------------
+// libzstd's match finder (on at every level of the reference: vbz/vbz.cpp:194-207) turns signal that cycles a template --
+// the reference's own perf generator does, vbz/perf/test_data_generator.h:61-67 -- into a few long matches: the data bytes
+// of such a read repeat at ONE distance D.  Finding D must cost a read without one next to nothing, and this kernel has
+// every data byte in LDS once anyway.  The sixteen dwords that start at data bytes p0 .. p0 + 15 are the probes; whatever D
+// is, exactly one of them comes to lie, D bytes further down, on the first dword of a 16-byte chunk of the flush loop.  So
+// the flush looks up the first dword of every chunk it writes in a small hash table (value -> probe number; an empty cell
+// holds a value that does not hash to it, so nothing matches it): a multiply, a shift, one LDS read and a compare per 16
+// data bytes.  A hit whose 16 bytes equal the 16 bytes behind the probe proposes D = position - (p0 + probe number); the
+// smallest proposal is left in hint[r] (0: none), and the entropy stage checks it before it relies on it.
+constexpr uint32_t PROBE_TABLE = 512, PROBE_P0 = 256, PROBE_MIN_D = 64, PROBE_TRIES = 4, PROBE_SHIFT = 80;
+struct PeriodProbe
+{
+    uint32_t val[PROBE_TABLE];
+    uint8_t idx[PROBE_TABLE];
+    uint32_t ctx[12];   // the 32 + 16 data bytes from p0 on (dword k = bytes p0 + 4k ...)
+    uint32_t best;      // smallest distance proposed so far
+    uint32_t lost;      // table construction: a probe collided
+};
+__device__ __forceinline__ uint32_t probe_hash(uint32_t w) { return (w * 0x9E3779B1u) >> 23; }
+
 // Values [first, end) of a read of n values (first a multiple of the tile size): control bytes to keys[first/4 ...),
 // data bytes to data[0 ...) -- `data` is where this range's data bytes start, any alignment; only bytes of the range
 // are touched.  COUNT_ONLY: nothing is written, the data byte count is all that is wanted.  Returns the data bytes
 // (workgroup-uniform).  All 256 threads.
-template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY>
+// PROBE (one-workgroup-per-read kernel only, data starts at first == 0): see PeriodProbe; *hint_out gets the distance.
+template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY, bool PROBE = false>
 __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t first, uint32_t end, uint8_t* keys, uint8_t* data,
-                                                     uint8_t* stage, uint32_t* wsum)
+                                                     uint8_t* stage, uint32_t* wsum, PeriodProbe* pp = nullptr, uint32_t* hint_out = nullptr)
 {
     constexpr int VPL = Vpl<ELEM>::value;
     constexpr int TILE = WG * VPL;
@@ -86,6 +108,15 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
 
     uint64_t F = 0;  // bytes of the aligned space already flushed (multiple of 16)
     uint64_t P = A;  // next byte position in the aligned space; stage[] holds [F, P)
+    uint32_t probe_p0 = 0;   // != 0: the probe table stands, with its probes at data bytes probe_p0 ...
+    if (PROBE) {
+        for (uint32_t i = tid; i < PROBE_TABLE; i += WG) pp->val[i] = i == 0 ? 1u : 0u;   // hash(0) = 0, hash(1) != 0
+        if (tid == 0) {
+            pp->best = 0xFFFFFFFFu;
+            pp->lost = 0;
+        }
+        // (the scan of the first tile holds the barrier that orders these writes)
+    }
 
     // the next tile's 16 bytes per lane are requested before this tile is processed (one load always in flight)
     uint4 qnext = make_uint4(0u, 0u, 0u, 0u);
@@ -225,12 +256,55 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
         wg_lds_barrier();
         const uint32_t endidx = (uint32_t)(P - F) + tot;
         const uint32_t nch = endidx >> 4;
+        if (PROBE && t0 == 0 && endidx >= A + PROBE_P0 + PROBE_TRIES * PROBE_SHIFT + 48u) {
+            // the first tile holds the probes: sixteen distinct dwords in sixteen different cells, else another place
+            uint32_t p0 = PROBE_P0;
+            for (uint32_t attempt = 0; attempt < PROBE_TRIES; ++attempt, p0 += PROBE_SHIFT) {
+                uint32_t pw = 0, h = 0;
+                if (tid < 16) {
+                    const uint8_t* q = stage + A + p0 + tid;
+                    pw = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+                    h = probe_hash(pw);
+                    pp->val[h] = pw;
+                    pp->idx[h] = (uint8_t)tid;
+                }
+                wg_lds_barrier();
+                if (tid < 16 && (pp->val[h] != pw || pp->idx[h] != (uint8_t)tid)) pp->lost = 1;   // two probes in one cell (or equal)
+                wg_lds_barrier();
+                const bool lost = pp->lost != 0;
+                wg_lds_barrier();
+                if (!lost) {
+                    probe_p0 = p0;
+                    break;
+                }
+                if (tid < 16) pp->val[h] = h == 0 ? 1u : 0u;
+                if (tid == 0) pp->lost = 0;
+                wg_lds_barrier();
+            }
+            if (probe_p0 && tid < 12) {
+                const uint8_t* q = stage + A + probe_p0 + 4 * tid;
+                pp->ctx[tid] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+            }
+            wg_lds_barrier();
+        }
         for (uint32_t c = tid; c < nch; c += WG) {
             uint8_t* g = gal + F + 16ull * c;
             if (F == 0 && c == 0 && A != 0) {
                 for (uint32_t j = A; j < 16; ++j) g[j] = stage[j];
             } else {
-                *reinterpret_cast<uint4*>(g) = *reinterpret_cast<const uint4*>(stage + 16u * c);
+                const uint4 v = *reinterpret_cast<const uint4*>(stage + 16u * c);
+                *reinterpret_cast<uint4*>(g) = v;
+                if (PROBE && probe_p0) {
+                    const uint32_t h = probe_hash(v.x);
+                    if (pp->val[h] == v.x) {   // rare: compare the chunk with the 16 bytes behind that probe
+                        const uint64_t rel = F + 16ull * c - A;   // data byte of the chunk's first byte
+                        const uint32_t j = pp->idx[h], k = j >> 2, sh = j & 3u;
+                        const uint32_t c0 = __builtin_amdgcn_alignbyte(pp->ctx[k + 1], pp->ctx[k], sh), c1 = __builtin_amdgcn_alignbyte(pp->ctx[k + 2], pp->ctx[k + 1], sh);
+                        const uint32_t c2 = __builtin_amdgcn_alignbyte(pp->ctx[k + 3], pp->ctx[k + 2], sh), c3 = __builtin_amdgcn_alignbyte(pp->ctx[k + 4], pp->ctx[k + 3], sh);
+                        if (rel >= (uint64_t)probe_p0 + j + PROBE_MIN_D && rel < 0xFFFFFFFFull && c0 == v.x && c1 == v.y && c2 == v.z && c3 == v.w)
+                            atomicMin(&pp->best, (uint32_t)rel - (probe_p0 + j));
+                    }
+                }
             }
         }
         const uint32_t rem = endidx & 15u;
@@ -244,6 +318,7 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
     }
     if (COUNT_ONLY) return P - A;
     wg_lds_barrier();
+    if (PROBE && tid == 0) *hint_out = pp->best == 0xFFFFFFFFu ? 0u : pp->best;
     {   // tail: bytes [F, P) still in LDS
         const uint32_t rem = (uint32_t)(P - F);
         const uint32_t lo = (F == 0) ? A : 0u;
@@ -258,14 +333,16 @@ struct EncStage
     static constexpr int value = WG * Vpl<ELEM>::value * (I16ZZ ? 2 : 4) + 32;
 };
 
-template <int ELEM, bool ZZ, bool I16ZZ>
-__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap)
+template <int ELEM, bool ZZ, bool I16ZZ, bool PROBE>
+__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, uint32_t* period_hint)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[EncStage<ELEM, I16ZZ>::value];
     __shared__ uint32_t wsum[4];
+    __shared__ PeriodProbe probe;   // (only the PROBE instantiations refer to it)
 
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
+    if (PROBE && tid == 0) period_hint[r] = 0;
     if (b.gate && b.gate[r] >= E_FIRST) {
         if (tid == 0) b.result[r] = b.gate[r];
         return;
@@ -284,7 +361,8 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         if (tid < 4) out[tid] = (uint8_t)(size >> (8 * tid));
         out += 4;
     }
-    const uint64_t bytes = svb_encode_range<ELEM, ZZ, I16ZZ, false>(in, 0, n, out, out + keyLen, stage, wsum);
+    const uint64_t bytes = svb_encode_range<ELEM, ZZ, I16ZZ, false, PROBE>(in, 0, n, out, out + keyLen, stage, wsum, PROBE ? &probe : nullptr,
+                                                                           PROBE ? period_hint + r : nullptr);
     if (tid == 0) b.result[r] = hdr + keyLen + (uint32_t)bytes;
 }
 
@@ -876,23 +954,30 @@ hipError_t launch1(K kernel, const ReadBatch& b, hipStream_t s)
 
 }  // namespace
 
-hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, hipStream_t s)
+hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, uint32_t* period_hint,
+                             hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     dim3 g(b.n_reads), t(WG);
     if (half) {  // v1, 1-byte integers: the nibble codec
         if (integer_size != 1) return hipErrorInvalidValue;
+        if (period_hint) (void)hipMemsetAsync(period_hint, 0, 4ull * b.n_reads, s);   // (the nibble stream is not probed)
         if (zigzag) hipLaunchKernelGGL((svb_half_encode_kernel<true>), g, t, 0, s, b, hdr);
         else hipLaunchKernelGGL((svb_half_encode_kernel<false>), g, t, 0, s, b, hdr);
         return hipGetLastError();
     }
-    if (integer_size == 2 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<2, true, true>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
-    else if (integer_size == 2) hipLaunchKernelGGL((svb_encode_kernel<2, false, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
-    else if (integer_size == 4 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<4, true, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
-    else if (integer_size == 4) hipLaunchKernelGGL((svb_encode_kernel<4, false, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
-    else if (integer_size == 1 && zigzag) hipLaunchKernelGGL((svb_encode_kernel<1, true, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
-    else if (integer_size == 1) hipLaunchKernelGGL((svb_encode_kernel<1, false, false>), g, t, 0, s, b, hdr, strict_cap ? 1u : 0u);
+    const uint32_t sc = strict_cap ? 1u : 0u;
+#define X(E, Z, I)                                                                                                    \
+    if (period_hint) hipLaunchKernelGGL((svb_encode_kernel<E, Z, I, true>), g, t, 0, s, b, hdr, sc, period_hint);     \
+    else hipLaunchKernelGGL((svb_encode_kernel<E, Z, I, false>), g, t, 0, s, b, hdr, sc, period_hint)
+    if (integer_size == 2 && zigzag) { X(2, true, true); }
+    else if (integer_size == 2) { X(2, false, false); }
+    else if (integer_size == 4 && zigzag) { X(4, true, false); }
+    else if (integer_size == 4) { X(4, false, false); }
+    else if (integer_size == 1 && zigzag) { X(1, true, false); }
+    else if (integer_size == 1) { X(1, false, false); }
     else return hipErrorInvalidValue;
+#undef X
     return hipGetLastError();
 }
 

@@ -60,6 +60,7 @@ struct vbz_gpu_ctx
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
+    int long_repeats = 1;  // VBZ_HIP_LONG_REPEATS=0: no search for a repeat distance (experiments: 2 = probe only, 3 = second launch only)
     bool phase_timing = false;
     bool trace = false;        // VBZ_HIP_TRACE=1: synchronise after every launch group and name it on stderr (to find a faulting kernel)
     void* pinned = nullptr;
@@ -321,27 +322,29 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
             HIPCHK(c, launch_svb_encode_seg(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, seg.first, seg.max_segs, seg.val, seg.off, s),
                    "svb_encode (segmented) launch");
         else
-            HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, half_codec(o), s), "svb_encode launch");
+            HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, half_codec(o), nullptr, s), "svb_encode launch");
         return 0;
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, false, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
     uint32_t num, den;
     svb_factor(o->integer_size, o->perform_delta_zig_zag, &num, &den);
-    // level >= 4 (long-repeat matcher): room behind every stream for one record per 16 data bytes and a mask bit per byte
-    if (o->zstd_compression_level >= 4 && !segmented) num *= 2;
+    // the long-repeat matcher (every level: the reference's libzstd matches at every level; its workspace is the top of the
+    // destination slots)
+    const bool matcher = !segmented && c->zero_run_sequences && c->long_repeats;
     const size_t scratch_need = (size_t)(((unsigned __int128)bt->src_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
     if (!ensure(c, c->scratch, scratch_need)) return -1;
-    if (!ensure(c, c->meta, (size_t)n * 32 + 256)) return -1;
+    if (!ensure(c, c->meta, (size_t)n * 40 + 256)) return -1;
     MetaCarver mc(c->meta.p);
     uint64_t* svb_off = mc.take<uint64_t>(n);
     uint32_t* svb_cap = mc.take<uint32_t>(n);
     uint32_t* svb_size = mc.take<uint32_t>(n);
     uint32_t* gate = mc.take<uint32_t>(n);
+    uint32_t* deep_d = mc.take<uint32_t>(n);
     {
         Timed t(c, "plan_scratch");
         HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, false, s), "plan launch");
@@ -358,7 +361,8 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
             HIPCHK(c, launch_svb_encode_seg(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, seg.first, seg.max_segs, seg.val, seg.off, s),
                    "svb_encode (segmented) launch");
         else
-            HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, half_codec(o), s), "svb_encode launch");
+            HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, half_codec(o), (matcher && c->long_repeats != 3) ? deep_d : nullptr, s), "svb_encode launch");
+        if (matcher && c->long_repeats == 3) (void)hipMemsetAsync(deep_d, 0, 4ull * n, s);
     }
     ReadBatch z = rb;
     z.src = (const uint8_t*)c->scratch.p;
@@ -392,7 +396,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     {
         Timed t(c, "zstd_encode");
         HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, c->zero_run_sequences ? svb_cap : nullptr,
-                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, o->zstd_compression_level >= 4, s),
+                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, s),
                "zstd_encode launch");
     }
     dbg_end(c, n, "zstd_encode: setup hist plan size hdr encode", dbg);
@@ -551,6 +555,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRACE")) c->trace = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
     {
@@ -660,7 +665,7 @@ int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int inte
     DeviceGuard dg(c->device);
     if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || version > 1 || version < 0) return -2;
     Timed t(c, "svb_encode");
-    HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, version == 1 && integer_size == 1, c->stream), "svb_encode launch");
+    HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, version == 1 && integer_size == 1, nullptr, c->stream), "svb_encode launch");
     return 0;
 }
 
@@ -679,7 +684,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, false, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, nullptr, c->stream), "zstd_encode launch");
     return 0;
 }
 

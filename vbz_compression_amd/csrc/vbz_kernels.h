@@ -40,7 +40,10 @@ struct ReadBatch
 // hdr: 0, or 4 to prepend / skip the sized header (u32 LE original size) in front of the svb stream.
 // strict_cap: apply the reference's worst-case capacity rule (keys + 4 bytes per value) to dst_cap.
 // half: the v1 nibble codec for 1-byte integers (vbz/v1/vbz_streamvbyte_impl.h)
-hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, hipStream_t s);
+// period_hint (nullable, n_reads words): the encoder also looks for ONE long repeat distance in the data bytes it writes
+// (svb_kernels.hip: PeriodProbe) and leaves it there (0: none) for the entropy stage's long-repeat coder.
+hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, uint32_t* period_hint,
+                             hipStream_t s);
 hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, bool half, hipStream_t s);
 // The same stage with one read spread over many workgroups ("segments" of svb_seg_unit_bytes raw bytes), for batches of few,
 // large reads (one 10 M-element buffer, one 400 k-sample read): seg_first[n_reads + 1] from launch_seg_plan; max_segs
@@ -60,10 +63,13 @@ hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigz
 // src_cap + seq_tables (both nullable): the source streams live in library-owned scratch slots of that
 // capacity, which lets the encoder rewrite the control-byte region as literals + zero-run sequences.
 // trailers: append the decoder-checkpoint skippable frame when a sequences section was written (see zstd_encode.hip)
-// deep: also look for one long repeat distance in the data bytes (zstd_compression_level >= 4)
+// deep_d (nullable, n_reads words): the repeat distance launch_svb_encode's probe proposes for every read (0: none).  Reads
+// whose proposal holds are coded by a second launch with the long-repeat matcher (what libzstd's match finder gets out of
+// template-cycling signal, at every level); deep_d[r] is rewritten with the verdict.  The matcher's workspace is the top of
+// the destination slot (reads whose slot is too small for frame and workspace are coded without it).
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              bool deep, hipStream_t s);
+                              uint32_t* deep_d, hipStream_t s);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);
 // The same stage for batches of few, large reads: one wavefront per SPAN of a read's stream (see zstd_encode.hip).

@@ -725,7 +725,8 @@ __device__ __forceinline__ uint64_t dilate_left(uint64_t w, uint32_t r)  // bit 
 // PERIOD: the mask "byte p equals byte p - D" was computed beforehand (period_mask) and is read from `mask16` (one 16-bit
 // word per 16 positions); a run of RPER or more such positions is one match, none of its bytes stays a literal.
 constexpr uint32_t RPER = 16;
-template <bool PERIOD>
+// COUNT_ONLY: nothing is written or moved; nrec is all that is wanted.
+template <bool PERIOD, bool COUNT_ONLY = false>
 __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit, uint32_t& nrec, const uint16_t* mask16, int lane)
 {
     uint32_t lit_total = 0, rec_total = 0;
@@ -788,7 +789,7 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
         // with RMIN <= 8 two qualifying runs can end inside one lane's 16 positions (never three)
         const uint32_t second = end16 & (end16 - 1);
         const uint64_t endmask1 = __ballot(end16 != 0), endmask2 = __ballot(second != 0);
-        if (end16) {
+        if (!COUNT_ONLY && end16) {
             const uint32_t idx = rec_total + (uint32_t)__popcll(endmask1 & below) + (uint32_t)__popcll(endmask2 & below);
             const uint32_t i = (uint32_t)__ffs((int)end16) - 1u;
             rec[idx] = make_uint2((uint32_t)lo + i + 1u, lit_total + excl + (uint32_t)__popc(kept16 & ((2u << i) - 1u)));
@@ -797,10 +798,12 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
                 rec[idx + 1] = make_uint2((uint32_t)lo + i2 + 1u, lit_total + excl + (uint32_t)__popc(kept16 & ((2u << i2) - 1u)));
             }
         }
-        uint32_t off = lit_total + excl;
+        if (!COUNT_ONLY) {
+            uint32_t off = lit_total + excl;
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if ((kept16 >> i) & 1u) k[off++] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+            for (int i = 0; i < 16; ++i)
+                if ((kept16 >> i) & 1u) k[off++] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+        }
         rec_total += (uint32_t)__popcll(endmask1) + (uint32_t)__popcll(endmask2);
         lit_total += tot;
         carry60 = (uint32_t)__shfl((int)zm, 60, 64);
@@ -811,63 +814,71 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
     nrec = rec_total;
 }
 
-// ---- long repeats at ONE distance (zstd_compression_level >= 4) ---------------------------------------------------------
+// ---- long repeats at ONE distance ---------------------------------------------------------------------------------------
 // Signal that repeats a template (the reference's own perf generator cycles a 15 643-sample read: vbz/perf/
-// test_data_generator.h:61-67) makes the data bytes of the svb stream periodic; libzstd's match finder turns every period
-// after the first into one long match.  The device equivalent looks for ONE distance D per region: an 8-byte probe from the
-// front of the region is searched for further down (all lanes, 16 positions each per trip), the first hit gives D, two
-// more places confirm it; then every position is marked "equals the byte D before" and runs of RPER or more marked
-// positions become sequences with the explicit offset D (OF table in RLE mode with code floor(log2(D + 3))).
-// Returns 0 when the region shows no such distance.
-__device__ uint32_t detect_period(const uint8_t* in, uint32_t S, int lane)
+// test_data_generator.h:61-67) makes the data bytes of the svb stream periodic; libzstd's match finder -- at every level,
+// vbz/vbz.cpp:194-207 hands the caller's level through -- turns every period after the first into one long match.  The
+// device equivalent uses ONE distance D per read: the svb encoder proposes it (svb_kernels.hip: PeriodProbe -- it has every
+// data byte in LDS once and looks the first dword of every 16-byte chunk up in a table of sixteen probes, which costs a read
+// without a period next to nothing), period_holds() checks the proposal, every position is then marked "equals the byte D
+// before" (period_mask) and runs of RPER or more marked positions become sequences with the explicit offset D (OF table in
+// RLE mode with code floor(log2(D + 3))).
+constexpr uint32_t PERIOD_MIN_D = 64;   // (short distances: the d = 1 tokeniser and the Huffman code do better)
+
+// all lanes: eight places spread over the region are asked (one lane each); most of them must repeat what stands D bytes
+// before -- a template repeated with a few changed samples still qualifies, a chance hit of the probe does not.
+__device__ bool period_holds(const uint8_t* in, uint32_t S, uint32_t D, int lane)
 {
-    if (S < 8192) return 0;
-    const uint32_t p0 = 256;
-    uint32_t pr[2];
-    __builtin_memcpy(pr, in + p0, 8);
-    // a probe of one repeated byte would find runs, not periods
-    if (pr[0] == pr[1] && pr[0] == ((pr[0] & 0xFFu) * 0x01010101u)) return 0;
-    uint32_t D = 0;
-    for (uint32_t q0 = p0 + 8; q0 + 24 <= S; q0 += 16 * WAVE) {
-        const uint32_t q = q0 + 16u * (uint32_t)lane;
-        uint32_t w[6] = { 0, 0, 0, 0, 0, 0 };
-        uint32_t hit = 0;
-        if (q + 24 <= S) {
-            uint4 a;
-            uint2 c;
-            __builtin_memcpy(&a, in + q, 16);
-            __builtin_memcpy(&c, in + q + 16, 8);
-            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = c.x; w[5] = c.y;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const uint32_t lo = __builtin_amdgcn_alignbyte(w[(i >> 2) + 1], w[i >> 2], i & 3);
-                const uint32_t hi = __builtin_amdgcn_alignbyte(w[(i >> 2) + 2], w[(i >> 2) + 1], i & 3);
-                hit |= (lo == pr[0] && hi == pr[1]) ? (1u << i) : 0u;
-            }
-        }
-        const uint64_t any = __ballot(hit != 0);
-        if (any) {
-            const int fl = __ffsll((long long)any) - 1;
-            const uint32_t fh = (uint32_t)__shfl((int)hit, fl, 64);
-            D = q0 + 16u * (uint32_t)fl + ((uint32_t)__ffs((int)fh) - 1u) - p0;
-            break;
-        }
-    }
-    if (D == 0 || D < 64) return 0;  // (short distances: the d = 1 tokeniser and the Huffman code do better)
-    // eight more places are asked (one lane each); most of them must agree (a template repeated with a few changed samples
-    // still matches nearly everywhere)
+    if (D < PERIOD_MIN_D || S < 8192 || (uint64_t)D + 32u > S) return false;
     bool agree = false;
     if (lane < 8) {
         const uint32_t t = D + 8u + (uint32_t)(((uint64_t)(S - D - 16u) * (uint32_t)lane) / 8u);  // spread over what has a predecessor
-        if (S >= D + 32u && t >= D + 8 && t + 8 <= S) {
+        if (t + 8 <= S) {
             uint32_t x[2], y[2];
             __builtin_memcpy(x, in + t, 8);
             __builtin_memcpy(y, in + t - D, 8);
             agree = x[0] == y[0] && x[1] == y[1];
         }
     }
-    const bool ok = __popcll(__ballot(agree)) >= 5;
-    return ok ? D : 0u;
+    return __popcll(__ballot(agree)) >= 5;
+}
+
+// Where the long-repeat coder keeps its workspace -- one mask bit per data byte and one 8-byte record per match.  The mask
+// goes to the spare room of the library's scratch slot behind the stream (below the control-byte region's run records) if
+// it fits there, the records to the top of the read's DESTINATION slot, which the caller sizes for the worst case
+// (vbz_max_compressed_size: 4 bytes per value and more) while a frame is never longer than its stream plus a little; the
+// frame may then use the slot up to `cap` only.  Room for every match the data could possibly hold (one per RPER + 1 bytes)
+// is not asked for: real repeats are few and long, so the records get what room there is (rec_cap) and the matches are
+// counted before anything is moved.  false: no room at all (a stream near its worst case): no matcher for this read.
+struct DeepLayout { uint8_t* recs; uint16_t* mask; uint32_t cap, rec_cap, nch; };
+__device__ __forceinline__ bool deep_layout(uint32_t N, uint32_t K, const uint8_t* in, uint32_t slot, uint8_t* out, uint32_t dst_cap, uint32_t hdr,
+                                            DeepLayout& d)
+{
+    const uint32_t SD = N - K;
+    d.nch = (SD + (BLOCK_MAX - 16u) - 1u) / (BLOCK_MAX - 16u);
+    const uint32_t mask_bytes = 2u * ((SD + 15u) >> 4) + 16u;
+    const uint64_t frame_worst = (uint64_t)hdr + N + (N >> 6) + 1024u;   // (raw blocks are the worst a region can do)
+    if (frame_worst + 64 > dst_cap) return false;
+    uint64_t room = dst_cap - frame_worst - 48;                           // of the destination slot, above the frame
+    const uintptr_t top = (uintptr_t)(out + dst_cap) & ~(uintptr_t)15;
+    const uint64_t keyrecs = 8ull * (K / RMIN + 4u) + 8;                  // the control-byte region's records, at the top of the scratch slot
+    uintptr_t mask;
+    if ((uint64_t)N + 32 + mask_bytes + 16 + keyrecs <= slot) {
+        mask = ((uintptr_t)(in + slot) - keyrecs - mask_bytes) & ~(uintptr_t)15;
+    } else {
+        if (room < mask_bytes + 16u) return false;
+        room -= mask_bytes + 16u;
+        mask = top - mask_bytes - 16u;
+    }
+    const uint32_t worst = SD / (RPER + 1u) + 2u * d.nch + 2u;            // more matches than this the data cannot hold
+    const uint64_t fit = room / 8u;
+    d.rec_cap = fit < worst ? (uint32_t)fit : worst;
+    if (d.rec_cap < 16u) return false;
+    const uintptr_t recs = ((mask < top && mask >= (uintptr_t)out ? mask : top) - 8ull * d.rec_cap) & ~(uintptr_t)15;
+    d.recs = reinterpret_cast<uint8_t*>(recs);
+    d.mask = reinterpret_cast<uint16_t*>(mask);
+    d.cap = (uint32_t)(recs - (uintptr_t)out);
+    return true;
 }
 
 // all lanes: mask16[p >> 4] bit (p & 15) = byte p equals byte p - D (0 for p < D)
@@ -1156,7 +1167,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab, const EncSpan* spans,
                                                            const uint32_t* span_count, uint8_t* span_tmp, uint32_t* span_size,
-                                                           uint32_t* span_trail, uint32_t trailers)
+                                                           uint32_t* span_trail, uint32_t trailers, uint32_t* deep_d)
 {
     __shared__ __attribute__((aligned(16))) EncLds L;
     unsigned long long tph[PHASE_SLOTS] = {};
@@ -1185,7 +1196,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         FINISH(N);
         return;
     }
-    const uint32_t cap = span_mode ? sp.tmp_cap : b.dst_cap[r];
+    uint32_t cap = span_mode ? sp.tmp_cap : b.dst_cap[r];
     const uint8_t* in = b.src + b.src_off[r];
     uint8_t* out = span_mode ? span_tmp + sp.tmp_off : b.dst + b.dst_off[r];
     uint32_t K = 0;
@@ -1201,6 +1212,26 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             return;                                              \
         }                                                        \
     } while (0)
+    // Long repeats are used in every read that has them, at every level (the reference hands its level to libzstd, whose
+    // match finder is on at all of them), in two launches: this kernel without the matcher looks at the distance the svb
+    // encoder proposed (deep_d[r]) before it touches anything; a read whose distance holds is left to the second launch, the
+    // DEEP instantiation, which runs for those reads only (deep_d[r] stays the distance; 0 = coded here).
+    if (deep_d && !span_mode) {
+        if (DEEP) {
+            if (deep_d[r] == 0) return;
+        } else {
+            const uint32_t hint = deep_d[r];
+            if (hint) {
+                bool ok = false;
+                if (K != 0 && src_cap && seqtab && N - K >= 8192) {
+                    DeepLayout dl;
+                    ok = deep_layout(N, K, in, src_cap[r], out, cap, hdr, dl) && period_holds(in + K, N - K, hint, lane);
+                }
+                if (ok) return;
+                if (lane == 0) deep_d[r] = 0;
+            }
+        }
+    }
     if (seqtab) {  // 968 bytes of encoding tables, copied once per frame
         const uint32_t* g = reinterpret_cast<const uint32_t*>(seqtab);
         uint32_t* l = reinterpret_cast<uint32_t*>(&L.seq);
@@ -1236,27 +1267,28 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     uint32_t deepD = 0, nunit = 2, chunk = 0;
     uint16_t* mask16 = nullptr;
     uint8_t* deep_recs = nullptr;
-    if (DEEP && !span_mode && K != 0 && src_cap && seqtab && N - K >= 8192) {
-        const uint32_t SD = N - K, slot = src_cap[r];
-        const uint32_t nch = (SD + (BLOCK_MAX - 16u) - 1u) / (BLOCK_MAX - 16u);
-        const uint32_t recs_keys = K / RMIN + 4u;
-        const uint32_t recs_data = SD / RPER + 2u * nch + 2u;
-        const uint32_t mask_bytes = 2u * ((SD + 15u) >> 4) + 16u;
-        const uint64_t need = (uint64_t)N + 16 + 8ull * (recs_keys + recs_data) + mask_bytes + 16;
-        if (need <= slot) {
-            const uint32_t keybase = (slot - 8u * recs_keys) & ~7u;
-            const uint32_t recbase = keybase - 8u * recs_data;
-            const uint32_t maskbase = (recbase - mask_bytes) & ~1u;
-            const uint32_t D = detect_period(in + K, SD, lane);
-            if (D) {
-                uint8_t* base = const_cast<uint8_t*>(in);
-                mask16 = reinterpret_cast<uint16_t*>(base + maskbase);
-                deep_recs = base + recbase;
-                period_mask(in + K, SD, D, mask16, lane);
-                __syncthreads();
+    uint32_t deep_used = 0;   // records of the chunks coded so far
+    if (DEEP && !span_mode && deep_d && K != 0 && src_cap && seqtab && N - K >= 8192) {
+        const uint32_t SD = N - K, D = deep_d[r];   // the first launch has checked the distance
+        DeepLayout dl;
+        if (D >= PERIOD_MIN_D && (uint64_t)D + 32u <= SD && deep_layout(N, K, in, src_cap[r], out, cap, hdr, dl)) {
+            period_mask(in + K, SD, D, dl.mask, lane);
+            __syncthreads();
+            // the matches are counted before anything is moved: they must fit the room their records have
+            const uint32_t ch = ((SD + dl.nch - 1u) / dl.nch + 15u) & ~15u;
+            uint32_t total = 0;
+            for (uint32_t c0 = 0; c0 < SD; c0 += ch) {
+                uint32_t lit = 0, n1 = 0;
+                tokenise_runs<true, true>(const_cast<uint8_t*>(in + K + c0), (SD - c0) < ch ? (SD - c0) : ch, nullptr, lit, n1, dl.mask + (c0 >> 4), lane);
+                total += n1;
+            }
+            if (total != 0 && total <= dl.rec_cap) {
+                mask16 = dl.mask;
+                deep_recs = dl.recs;
+                cap = dl.cap;   // the frame stays below the workspace
                 deepD = D;
-                chunk = ((SD + nch - 1u) / nch + 15u) & ~15u;
-                nunit = 1u + nch;
+                chunk = ch;
+                nunit = 1u + dl.nch;
             }
         }
     }
@@ -1313,8 +1345,9 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         uint32_t of_dist = 0;  // != 0: this region's sequences carry this explicit distance (long repeats)
         if (DEEP && deepD && region >= 1) {
             uint32_t Lit = 0;
-            uint2* recs = reinterpret_cast<uint2*>(deep_recs + 8u * ((r0 - K) / RPER + 2u * cidx));
+            uint2* recs = reinterpret_cast<uint2*>(deep_recs + 8u * deep_used);
             tokenise_runs<true>(const_cast<uint8_t*>(rin), S, recs, Lit, nrec, mask16 + ((r0 - K) >> 4), lane);
+            deep_used += nrec;
             __syncthreads();
             if (nrec) {  // (without a single match nothing was moved)
                 seqmode = true;
@@ -1911,19 +1944,21 @@ __global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, con
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              bool deep, hipStream_t s)
+                              uint32_t* deep_d, hipStream_t s)
 {
     const uint32_t tr = trailers ? 1u : 0u;
     if (b.n_reads == 0) return hipSuccess;
-    if (dbg)
+    const SeqCTables* st = reinterpret_cast<const SeqCTables*>(seq_tables);
+    if (dbg) {
         hipLaunchKernelGGL((zstd_encode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
-    else if (deep)
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, nullptr);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+                       src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d);
+    if (deep_d)  // the reads in which the first launch found a repeat distance (it wrote deep_d[] for every read)
         hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
-    else
-        hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, reinterpret_cast<const SeqCTables*>(seq_tables), nullptr, nullptr, nullptr, nullptr, nullptr, tr);
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d);
     return hipGetLastError();
 }
 
@@ -1952,7 +1987,8 @@ hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_siz
     hipLaunchKernelGGL(zstd_span_plan_kernel, dim3(1), dim3(1024), 0, s, b.n_reads, b.src_size, orig_size, key_elem, b.gate,
                        (src_cap && seq_tables) ? 1u : 0u, max_spans, span_tmp_bytes, spans, span_first, span_count);
     hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
-                       reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u);
+                       reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u,
+                       nullptr);
     hipLaunchKernelGGL(zstd_span_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, hdr, spans, span_first, max_spans, span_size, span_trail,
                        span_dst, index_trailer ? 1u : 0u);
     hipLaunchKernelGGL(zstd_span_compact_kernel, dim3(max_spans), dim3(256), 0, s, b, spans, span_count, span_tmp, span_size, span_trail, span_dst,
