@@ -166,6 +166,57 @@ def test_svb_int16_decoder_body_tail_split():
         assert _same(got, want), n
 
 
+def test_wave_svb_decoder_behind_the_entropy_stage():
+    """The int16 zig-zag stream behind the entropy stage has two decoders: svb_decode_kernel with its block path (lanes own
+    32 consecutive values, packed 16-bit arithmetic), and -- VBZ_HIP_FUSE_SVB=1 -- the wavefront that decoded the frame
+    (svb_wave.h).  Same verdicts from both: foreign and malformed svb streams (codes 2 / 3, wrong lengths, short and long
+    streams, every length class of the block paths) packed into frames by libzstd -- what a foreign writer could store --
+    must give the oracle's samples or the oracle's error."""
+    import gpu_util as G
+    from vbz_compression_amd import _lib, batch
+
+    rng = np.random.default_rng(77)
+    cases = []   # (svb stream, claimed output bytes)
+    for n in (0, 1, 7, 8, 511, 512, 513, 4095, 4096, 4097, 8191, 8192 + 512, 12288, 40000, 100003):
+        a = O.synth_signal(5, n, n)
+        st = O.svb_compress(a, 2, True, 0)
+        cases.append((st, a.nbytes))
+        if n:
+            cases += [(st[:-1], a.nbytes), (np.concatenate([st, np.zeros(1, np.uint8)]), a.nbytes), (st, a.nbytes - 2), (st, a.nbytes + 2), (st, a.nbytes + 1)]
+    for n in (64, 8, 40, 333, 5000, 4096, 9000, 30000):   # random control bytes: codes 2 / 3, the reference's body / tail split
+        keys = rng.integers(0, 256, (n + 3) // 4, dtype=np.uint8)
+        if n % 4:
+            keys[-1] &= (1 << (2 * (n % 4))) - 1
+        codes = np.array([(keys[i >> 2] >> (2 * (i & 3))) & 3 for i in range(n)])
+        data = rng.integers(0, 256, int((codes + 1).sum()), dtype=np.uint8)
+        cases.append((np.concatenate([keys, data]), 2 * n))
+    a = O.synth_signal(5, 99, 30000)   # wide codes in the middle of an ordinary stream: the pipeline hands over to the tile loop
+    st = O.svb_compress(a, 2, True, 0).copy()
+    K = (len(a) + 3) // 4
+    wide = st.copy()
+    wide[5000] |= 0x80      # value 20003 gets code 2 or 3: the stream is then one or two bytes short
+    cases.append((wide, a.nbytes))
+    cases.append((np.concatenate([wide, np.zeros(2, np.uint8)]), a.nbytes))
+    cases.append((np.concatenate([wide, np.zeros(1, np.uint8)]), a.nbytes))
+    oo = O.options(True, 2, 1, 1)
+    frames = [O.zstd_compress(st, 1) for st, _ in cases]
+    want = [O.decompress(f, nb, oo) for f, (_, nb) in zip(frames, cases)]
+    assert sum(1 for w in want if isinstance(w, int)) >= 40 and sum(1 for w in want if not isinstance(w, int)) >= 20
+    keep = G._codec
+    try:
+        for fuse in ("0", "1"):   # the separate svb_decode launch, and the frame's own wavefront (a context of its own each)
+            os.environ["VBZ_HIP_FUSE_SVB"] = fuse
+            try:
+                G._codec = batch.GpuCodec(0)
+            finally:
+                del os.environ["VBZ_HIP_FUSE_SVB"]
+            got = G.decompress(frames, [nb for _, nb in cases], _lib.CompressionOptions(True, 2, 1, 1))
+            for i, (w, g) in enumerate(zip(want, got)):
+                assert _same(g, w), (fuse, i, len(cases[i][0]), cases[i][1], g if isinstance(g, int) else "samples", w if isinstance(w, int) else "samples")
+    finally:
+        G._codec = keep
+
+
 # ------------------------------------------------------------------------------------------------
 # stage 2: zstd-format entropy stage
 # ------------------------------------------------------------------------------------------------

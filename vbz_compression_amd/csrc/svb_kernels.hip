@@ -16,6 +16,7 @@
 //     scan primitives; the previous sample comes from the neighbouring lane by a shuffle.
 // Algorithmic HBM bytes per int16 sample: encode 2 read + ~1.26 written; decode the reverse.
 #include "vbz_kernels.h"
+#include "svb_wave.h"
 
 namespace vbzhip {
 
@@ -454,39 +455,7 @@ __global__ __launch_bounds__(WG) void svb_seg_encode_scan_kernel(ReadBatch b, ui
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
-// Per-read validation of the decoder (both kernels): returns true when the read is finished with `res`.
-template <int ELEM, bool I16ZZ>
-__device__ __forceinline__ bool svb_decode_check(uint32_t in_size, uint32_t out_size, uint32_t& res)
-{
-    if (out_size % ELEM != 0) {  // vbz/v0/vbz_streamvbyte.cpp:75-78
-        res = E_DESTINATION_SIZE;
-        return true;
-    }
-    const uint32_t count = out_size / ELEM;
-    const uint32_t keyLen = (count + 3u) >> 2;
-    if (I16ZZ) {
-        if (count == 0) {  // sse3.h:472-476
-            res = 0;
-            return true;
-        }
-        if (in_size < keyLen) {  // sse3.h:478-482
-            res = E_INPUT_SIZE;
-            return true;
-        }
-    } else {
-        // streamvbyte_validate_stream (vbz/v0/vbz_streamvbyte_impl.h:49-51)
-        if (in_size == 0 || count == 0) {
-            res = (in_size == count) ? 0u : E_STREAM;
-            return true;
-        }
-        if (keyLen > in_size) {
-            res = E_STREAM;
-            return true;
-        }
-    }
-    return false;
-}
-
+// (per-read validation of the decoders: svb_decode_check in svb_wave.h, shared with the wave decoder)
 // MODE 0: decode values [first, end) of a stream of `count` values whose data bytes start at data[pos] and whose delta
 //         chain stands at `run`; store them.  MODE 1: only add up the data bytes the control bytes announce.
 //         MODE 2: decode without storing (the total of the deltas is wanted).  pos / run are updated; returns false when

@@ -60,6 +60,7 @@ struct vbz_gpu_ctx
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
+    bool fuse_svb = false;     // VBZ_HIP_FUSE_SVB=1: the frame's wavefront decodes the svb stream too (measured slower: DESIGN.md 4.4)
     int long_repeats = 1;  // VBZ_HIP_LONG_REPEATS=0: no search for a repeat distance (experiments: 2 = probe only, 3 = second launch only)
     bool phase_timing = false;
     bool trace = false;        // VBZ_HIP_TRACE=1: synchronise after every launch group and name it on stderr (to find a faulting kernel)
@@ -475,6 +476,14 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     z.result = svb_size;
     z.gate = gate;
     unsigned long long* dbg = segmented ? nullptr : dbg_begin(c, n);
+    // the hot path -- int16 zig-zag samples, one wavefront per frame: the wavefront decodes the svb stream it has just
+    // written while it is still in the caches, straight into the destination; there is no svb_decode launch
+    if (!segmented && !dbg && c->fuse_svb && o->integer_size == 2 && o->perform_delta_zig_zag) {
+        z.result = rb.result;
+        Timed t(c, "zstd_decode");  // (zstd_decode_kernel<false, true>: the frame and its svb stream)
+        HIPCHK(c, launch_zstd_decode_svb_i16zz(z, E_STREAM, c->seqdtab.p, rb.dst, rb.dst_off, rb.dst_cap, s), "zstd_decode + svb_decode launch");
+        return 0;
+    }
     if (segmented) {  // few, large reads: frames with a span index are decoded one span per wavefront
         const uint32_t max_spans = zstd_dspan_max_spans(scratch_need, n);
         if (!max_spans) {
@@ -556,6 +565,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_TRACE")) c->trace = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);
+    if (const char* e = getenv("VBZ_HIP_FUSE_SVB")) c->fuse_svb = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
     {

@@ -87,6 +87,11 @@ hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_siz
 // seq_dtables (device, from seq_dtables_build): decoding tables of the predefined LL / ML distributions.
 hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsigned long long* dbg, const void* seq_dtables,
                               hipStream_t s);
+// The same, and the frame's content -- the svb stream of int16 zig-zag samples, b.dst = its slot in the library's scratch --
+// is decoded by the same wavefront straight away (svb_wave.h) into out + out_off[i] (out_size[i] bytes exactly): result[i]
+// gets what launch_svb_decode(2, zigzag) would have reported after launch_zstd_decode, and no svb_decode launch follows.
+hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, uint8_t* out, const uint64_t* out_off,
+                                        const uint32_t* out_size, hipStream_t s);
 size_t seq_dtables_bytes();
 void seq_dtables_build(void* host_buffer);
 // The same for batches of few, large reads: frames that carry the encoder's span index are decoded one span per wavefront

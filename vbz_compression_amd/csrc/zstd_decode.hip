@@ -20,6 +20,7 @@
 // copies literals and matches cooperatively.
 // Algorithmic HBM bytes per svb byte: ~0.67 read + 1 written.
 #include "vbz_kernels.h"
+#include "svb_wave.h"
 
 namespace vbzhip {
 
@@ -1690,10 +1691,20 @@ constexpr uint32_t DSPAN_MIN_CONTENT = 8u << 10;    // an honest index has at mo
 constexpr uint32_t DSPAN_WS_STRIDE = 64u << 10;
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
-template <bool TIMED>
+// FUSED: the frame's content is the svb stream of int16 zig-zag samples and b.dst its slot in the library's scratch: once the
+// frame is decoded the same wave decodes the stream (svb_wave.h) into the read's final destination (fuse.out) and
+// b.result[] gets the FINAL verdict -- the stream is read back while it is still in the caches, and no svb_decode launch
+// follows.
+struct SvbFuse
+{
+    uint8_t* out;
+    const uint64_t* out_off;
+    const uint32_t* out_size;   // exact decoded byte count of every read
+};
+template <bool TIMED, bool FUSED>
 __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs,
                                                                       const DecSpan* dspans, const uint32_t* dspan_count, uint32_t* dspan_status,
-                                                                      const uint32_t* only)
+                                                                      const uint32_t* only, SvbFuse fuse)
 {
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
@@ -2568,7 +2579,14 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         }
         return;
     }
-    if (lane == 0) b.result[r] = fcs;
+    if (FUSED) {
+        static_assert(sizeof(DecLds) >= svbwave::LDS_TOTAL, "the wave's svb decoder works in the frame decoder's LDS");
+        __syncthreads();  // every byte of the stream is in memory (raw / RLE blocks store without a drain)
+        const uint32_t res = svbwave::svb_decode_wave_i16zz(dst, fcs, fuse.out + fuse.out_off[r], fuse.out_size[r], reinterpret_cast<uint8_t*>(&L), lane);
+        if (lane == 0) b.result[r] = res;
+    } else if (lane == 0) {
+        b.result[r] = fcs;
+    }
     if (TIMED && lane == 0 && !dspans)
         for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
 #undef SQB
@@ -2744,12 +2762,23 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
                               hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
+    const SvbFuse none = { nullptr, nullptr, nullptr };
     if (dbg)
-        hipLaunchKernelGGL(zstd_decode_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((zstd_decode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none);
     else
-        hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr);
+        hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none);
+    return hipGetLastError();
+}
+
+hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, uint8_t* out, const uint64_t* out_off,
+                                        const uint32_t* out_size, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    const SvbFuse fuse = { out, out_off, out_size };
+    hipLaunchKernelGGL((zstd_decode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
+                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, fuse);
     return hipGetLastError();
 }
 
@@ -2769,10 +2798,11 @@ hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, 
     DecSpan* spans = reinterpret_cast<DecSpan*>(dspan_desc);
     const SeqDTables* dt = reinterpret_cast<const SeqDTables*>(seq_dtables);
     hipLaunchKernelGGL(zstd_dspan_plan_kernel, dim3(1), dim3(1024), 0, s, b, max_spans, spans, dspan_first, dspan_count, dspan_status);
-    hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(max_spans), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, spans, dspan_count, dspan_status,
-                       nullptr);
+    const SvbFuse none = { nullptr, nullptr, nullptr };
+    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, spans, dspan_count, dspan_status,
+                       nullptr, none);
     hipLaunchKernelGGL(zstd_dspan_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, spans, dspan_first, max_spans, dspan_status, redo);
-    hipLaunchKernelGGL(zstd_decode_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, nullptr, nullptr, nullptr, redo);
+    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, nullptr, nullptr, nullptr, redo, none);
     return hipGetLastError();
 }
 
