@@ -251,3 +251,52 @@ def test_last_block_flag_inside_a_large_frame():
     for v, gq in zip(variants, got):
         assert isinstance(O.decompress(v, a.nbytes, oo), int)
         assert isinstance(gq, int), "the device decoded a frame that ends in the middle"
+
+
+def test_aliased_sources_cannot_overflow_the_segment_tables():
+    """vbz_gpu.h only asks that src_bytes covers every read: reads may ALIAS their source bytes, and then the sizes add up to
+    more than the arena -- which is what the host sizes the segment tables (and grids) of the large-read path by.  Three
+    reads over the same 2 MB buffer: every read either comes out right or is refused with OUT_OF_MEMORY (the first one must
+    come out right); nothing is written behind the tables (round 2 did that)."""
+    c = G.codec()
+    dev = c.device
+    a = O.synth_signal(5, 11, 1_048_576)                # 2 MB of int16
+    raw = torch.from_numpy(np.frombuffer(a.tobytes(), np.uint8).copy()).to(dev)
+    src = torch.zeros(raw.numel() + 64, dtype=torch.uint8, device=dev)
+    src[: raw.numel()] = raw
+    n = 3
+    for level in (0, 1):
+        go, oo = _lib.CompressionOptions(True, 2, level, 1), O.options(True, 2, level, 1)
+        cap = _lib.load().vbz_max_compressed_size(a.nbytes, ctypes.byref(go))
+        doff, dtotal = batch.layout([cap + 32] * n, 64)
+        dst = torch.zeros(dtotal + 64, dtype=torch.uint8, device=dev)
+        res = torch.full((n,), -8, dtype=torch.int32, device=dev)
+        c.compress(src[: raw.numel()], torch.zeros(n, dtype=torch.int64, device=dev), torch.full((n,), a.nbytes, dtype=torch.int32, device=dev), dst,
+                   doff.to(dev), torch.full((n,), cap, dtype=torch.int32, device=dev), res, go)
+        torch.cuda.synchronize()
+        r = [int(x) & 0xFFFFFFFF for x in res.cpu().tolist()]
+        host = dst.cpu().numpy()
+        good = 0
+        for i in range(n):
+            if r[i] == 0xFFFFFFF9:
+                continue
+            assert r[i] < 0xFFFFFFF0, hex(r[i])
+            f = host[int(doff[i]) : int(doff[i]) + r[i]]
+            assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes(), (level, i)
+            good += 1
+        assert good >= 1 and r[0] < 0xFFFFFFF0, [hex(x) for x in r]
+        # the other direction: three reads over ONE compressed buffer decode into three slots (the destination arena covers
+        # them, so nothing is refused there)
+        f = O.compress(a, oo)
+        fsrc = torch.zeros(len(f) + 64, dtype=torch.uint8, device=dev)
+        fsrc[: len(f)] = torch.from_numpy(f.copy()).to(dev)
+        ooff, ototal = batch.layout([a.nbytes + 32] * n, 64)
+        out = torch.zeros(ototal + 64, dtype=torch.uint8, device=dev)
+        res = torch.full((n,), -8, dtype=torch.int32, device=dev)
+        c.decompress(fsrc[: len(f)], torch.zeros(n, dtype=torch.int64, device=dev), torch.full((n,), len(f), dtype=torch.int32, device=dev), out,
+                     ooff.to(dev), torch.full((n,), a.nbytes, dtype=torch.int32, device=dev), res, go)
+        torch.cuda.synchronize()
+        host = out.cpu().numpy()
+        for i in range(n):
+            assert int(res[i]) == a.nbytes
+            assert host[int(ooff[i]) : int(ooff[i]) + a.nbytes].tobytes() == a.tobytes()

@@ -50,8 +50,12 @@ __global__ __launch_bounds__(1024) void plan_scratch_kernel(uint32_t n, const ui
     }
 }
 
-// segment counts of a batch of few, large reads: exclusive scan by one 1024-thread workgroup
-__global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32_t* size, uint32_t unit, const uint32_t* gate, uint32_t* seg_first)
+// segment counts of a batch of few, large reads: exclusive scan by one 1024-thread workgroup.  max_segs is what the host sized
+// the segment tables (and the grids) for -- the arena's extent; reads may alias their source bytes, so the sizes can add up to
+// more: a read whose segments would not fit keeps ONE segment and gets gate_out[i] = E_OOM (a per-read error instead of
+// writes behind the tables); gate_out[i] is the input gate otherwise (0 without one).
+__global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32_t* size, uint32_t unit, const uint32_t* gate, uint32_t max_segs,
+                                                        uint32_t* seg_first, uint32_t* gate_out)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
@@ -60,19 +64,37 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + tid;
-        uint32_t c = 0;
+        uint32_t c = 0, g = 0;
         if (i < n) {
-            const uint32_t sz = (gate && gate[i] >= E_FIRST) || size[i] >= E_FIRST ? 0u : size[i];
+            g = gate ? gate[i] : 0u;
+            const uint32_t sz = g >= E_FIRST || size[i] >= E_FIRST ? 0u : size[i];
             c = sz ? (uint32_t)(((uint64_t)sz + unit - 1) / unit) : 1u;
         }
-        const uint32_t inc = wave_incl_scan_u32(c);
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        uint32_t pre = carry_s;
-        for (int k = 0; k < w; ++k) pre += wsum[k];
-        if (i < n) seg_first[i] = pre + inc - c;
-        __syncthreads();
-        if (tid == 1023) carry_s = pre + inc;
+        // a read fits if its segments end inside the tables with one segment left for every read behind it; the scan is
+        // redone with the misfits' counts at one (they are rare: one retry settles it, the check is repeated to be sure)
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const uint32_t inc = wave_incl_scan_u32(c);
+            if (lane == 63) wsum[w] = inc;
+            __syncthreads();
+            uint32_t pre = carry_s;
+            for (int k = 0; k < w; ++k) pre += wsum[k];
+            const uint32_t first = pre + inc - c;
+            const bool fits = i >= n || (uint64_t)first + c + (n - 1 - i) <= max_segs;
+            __syncthreads();
+            if (attempt == 1 || !__syncthreads_or(!fits)) {
+                if (i < n) {
+                    seg_first[i] = first;
+                    if (!fits) g = E_OOM;   // (second attempt only: cannot happen with c == 1 unless max_segs < n)
+                    gate_out[i] = g;
+                }
+                if (tid == 1023) carry_s = pre + inc;
+                break;
+            }
+            if (!fits) {
+                c = 1;
+                g = E_OOM;
+            }
+        }
         __syncthreads();
     }
     if (tid == 0) seg_first[n] = carry_s;
@@ -184,9 +206,10 @@ hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mu
     return hipGetLastError();
 }
 
-hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t* seg_first, hipStream_t s)
+hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t max_segs, uint32_t* seg_first,
+                           uint32_t* gate_out, hipStream_t s)
 {
-    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, s, n, size, unit_bytes, gate, seg_first);
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, s, n, size, unit_bytes, gate, max_segs, seg_first, gate_out);
     return hipGetLastError();
 }
 

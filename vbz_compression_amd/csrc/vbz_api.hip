@@ -270,6 +270,7 @@ struct SegTables
     uint32_t* val = nullptr;    // [max_segs]
     uint64_t* off = nullptr;    // [max_segs]
     uint32_t* run = nullptr;    // [max_segs]
+    uint32_t* gate = nullptr;   // [n]: the input gate, plus E_OOM for reads whose segments do not fit the tables
     uint32_t max_segs = 0;
 };
 
@@ -282,14 +283,15 @@ int plan_segments(vbz_gpu_ctx* c, uint32_t n, const uint32_t* raw_size, const ui
         return -1;
     }
     t->max_segs = (uint32_t)segs;
-    if (!ensure(c, c->segmeta, ((size_t)n + 1) * 4 + (size_t)segs * 16 + 256)) return -1;
+    if (!ensure(c, c->segmeta, ((size_t)n + 1) * 8 + (size_t)segs * 16 + 256)) return -1;
     MetaCarver mc(c->segmeta.p);
     t->first = mc.take<uint32_t>((size_t)n + 1);
+    t->gate = mc.take<uint32_t>(n);
     t->val = mc.take<uint32_t>(segs);
     t->off = mc.take<uint64_t>(segs);
     t->run = mc.take<uint32_t>(segs);
     Timed tm(c, "seg_plan");
-    HIPCHK(c, launch_seg_plan(n, raw_size, unit, gate, t->first, c->stream), "seg_plan launch");
+    HIPCHK(c, launch_seg_plan(n, raw_size, unit, gate, t->max_segs, t->first, t->gate, c->stream), "seg_plan launch");
     return 0;
 }
 
@@ -317,6 +319,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     const bool segmented = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n);
     SegTables seg;
     if (segmented && plan_segments(c, n, bt->src_size, nullptr, bt->src_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
+    if (segmented) rb.gate = seg.gate;   // (E_OOM for a read whose segments do not fit the tables)
     if (o->integer_size != 0 && o->zstd_compression_level == 0) {  // vbz.cpp:171-192: svb straight into dst
         Timed t(c, "svb_encode");
         if (segmented)
@@ -346,9 +349,10 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     uint32_t* svb_size = mc.take<uint32_t>(n);
     uint32_t* gate = mc.take<uint32_t>(n);
     uint32_t* deep_d = mc.take<uint32_t>(n);
+    if (segmented) HIPCHK(c, hipMemcpyAsync(gate, seg.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
     {
         Timed t(c, "plan_scratch");
-        HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, false, s), "plan launch");
+        HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, segmented, s), "plan launch");
     }
     ReadBatch a = rb;
     a.dst = (uint8_t*)c->scratch.p;
@@ -445,6 +449,10 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     const bool segmented = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n);
     SegTables seg;
     if (segmented && plan_segments(c, n, rb.dst_cap, rb.gate, bt->dst_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
+    if (segmented) {   // (E_OOM for a read whose segments do not fit the tables)
+        HIPCHK(c, hipMemcpyAsync(gate, seg.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
+        rb.gate = gate;
+    }
     if (o->zstd_compression_level == 0) {
         Timed t(c, "svb_decode");
         if (segmented)
@@ -467,7 +475,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     if (!ensure(c, c->scratch, scratch_need)) return -1;
     {
         Timed t(c, "plan_scratch");
-        HIPCHK(c, launch_plan_scratch(n, rb.dst_cap, num, den, c->scratch.cap, svb_off, svb_cap, gate, sized != 0, s), "plan launch");
+        HIPCHK(c, launch_plan_scratch(n, rb.dst_cap, num, den, c->scratch.cap, svb_off, svb_cap, gate, sized != 0 || segmented, s), "plan launch");
     }
     ReadBatch z = rb;
     z.dst = (uint8_t*)c->scratch.p;

@@ -110,8 +110,11 @@ hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, 
 hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mul_num, uint32_t mul_den, uint64_t limit,
                                uint64_t* off, uint32_t* cap, uint32_t* gate, bool gate_is_input, hipStream_t s);
 // seg_first[i] = number of segments of reads 0..i-1, a read of `size` bytes having max(1, ceil(size / unit_bytes)) of them
-// (seg_first[n] = total); reads whose gate is an error get one segment.
-hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t* seg_first, hipStream_t s);
+// (seg_first[n] = total); reads whose gate is an error get one segment.  max_segs = the size of the caller's segment tables
+// (and grids): reads whose segments would not fit them (sources that alias each other can add up to more than the arena)
+// keep one segment and get gate_out[i] = E_OOM; gate_out[i] = gate[i] (or 0) otherwise.  gate_out may be gate.
+hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t max_segs, uint32_t* seg_first,
+                           uint32_t* gate_out, hipStream_t s);
 // sized decode: read the 4-byte headers -> payload offsets/sizes, original sizes, gate errors
 hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
                               const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
