@@ -610,7 +610,8 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier):
     dom_dir = "encode" if "encode" in dom else "decode"
     t_dom = t_enc if dom_dir == "encode" else t_dec
     out = {
-        "metric": METRIC, "value": round(total_raw / elapsed / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": METRIC if kind != "u32" else "MB/s encode+decode, uint32 buffers (BASELINE configs[3]: UD=32020,5,0,0,4,0,3), 1 MI355X vs CPU; ratio preserved",
+        "value": round(total_raw / elapsed / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "uint32" if kind == "u32" else "int16", "data": "synthetic",
         "config": {"workload": name + ", encode then decode through the batched entry points, inputs resident in HBM",
@@ -637,17 +638,29 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier):
         f = vbz.compress_raw(h, o2)
         b2 = vbz.decompress_raw(f, nbytes, o2)
         assert b2.tobytes() == h.tobytes()
+        # the C entry points themselves, on buffers the caller owns and reuses (what a C caller does; the numpy wrappers above
+        # allocate a fresh 40 MB array per call, whose page faults would be most of the time measured)
+        import numpy as np
+        bound = L.vbz_max_compressed_size(nbytes, ctypes.byref(o2))
+        cbuf = np.zeros(bound + 16, np.uint8)
+        dbuf = np.zeros(nbytes, np.uint8)
         k = 10
-        t0 = time.perf_counter()
-        for _ in range(k):
-            f = vbz.compress_raw(h, o2)
+        n = 0
+        for it in range(k + 2):
+            if it == 2:
+                t0 = time.perf_counter()
+            n = L.vbz_compress(h.ctypes.data, nbytes, cbuf.ctypes.data, bound, ctypes.byref(o2))
         t1 = time.perf_counter()
-        for _ in range(k):
-            b2 = vbz.decompress_raw(f, nbytes, o2)
+        assert not _lib.is_error(n) and n == len(f)
+        for it in range(k + 2):
+            if it == 2:
+                t1 = time.perf_counter()
+            m = L.vbz_decompress(cbuf.ctypes.data, n, dbuf.ctypes.data, nbytes, ctypes.byref(o2))
         t2 = time.perf_counter()
+        assert m == nbytes and dbuf.tobytes() == h.tobytes()
         out["host_api"] = {"vbz_compress_ms": round((t1 - t0) / k * 1e3, 3), "vbz_decompress_ms": round((t2 - t1) / k * 1e3, 3),
                            "encode_decode_MBps": round(nbytes / ((t2 - t0) / k) / 1e6, 1),
-                           "note": "one buffer per call through include/vbz.h, host memory in and out"}
+                           "note": "one buffer per call through include/vbz.h, pageable host memory in and out, buffers reused by the caller"}
     if world == 1 and not args.no_cpu:
         if kind == "u32":
             out["cpu_baseline"] = cpu_baseline_u32(max(nbuf, usable_cpus()[0]), count)

@@ -2,7 +2,7 @@
 # Per-kernel durations of any command on the GPU box (rocprofv3 kernel trace), library kernels only:
 #   bash tools/kernel_times.sh <tag> python3 tools/time_large.py
 set -u
-tag=$1; shift
+tag=${1:?usage: kernel_times.sh <tag> <command...>}; shift
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
