@@ -38,6 +38,26 @@ SVB_BYTES_PER_SAMPLE = 1.261  # svb stream bytes per int16 sample of this worklo
 # ---------------------------------------------------------------------------------------------------------------------
 # launcher (no GPU call may happen before or inside it)
 # ---------------------------------------------------------------------------------------------------------------------
+def kfd_gpu_count():
+    """GPUs the kernel driver knows (topology nodes with SIMDs; CPUs are nodes without), or None if sysfs does not say."""
+    import glob
+
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    count = 0
+    for path in nodes:
+        try:
+            with open(path) as f:
+                for ln in f:
+                    k, _, v = ln.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        count += 1
+        except (OSError, ValueError):
+            return None
+    return count
+
+
 def launch_ranks(args, argv):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -253,12 +273,16 @@ def run_rank(args):
 
     if args.dry_run:
         # the same work queue as the real run, on the generator's length formula restated in torch
+        fixed_job = args.workload == "config5"
         R = args.resident or 2
-        total_reads = world * R * n
+        total_reads = args.total_reads if fixed_job else world * R * n
         g = torch.Generator().manual_seed(5)
         lengths = 90000 + torch.randint(0, 20001, (total_reads,), generator=g)
         lengths = shard.share_read_table(lengths if rank == 0 else torch.zeros(total_reads, dtype=torch.int64))
         a, b = shard.partition_reads(lengths, world)[rank]
+        if fixed_job:  # the rank's share of the fixed job, in batches of at most n reads, each coded once
+            R = max(1, -(-(b - a) // n))
+            args.steps = R
         batches = shard.cut_batches(a, b, lengths, R)
         barrier()
         t0 = time.perf_counter()
@@ -267,9 +291,11 @@ def run_rank(args):
         table, off = shard.exchange_tallies(sum(y - x for x, y in batches), raw, raw // 2)
         if rank == 0:
             print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "dtype": "int16", "data": "dry-run (no codec: launcher and work-queue plumbing only)",
-                              "config": {"workload": "dry-run", "reads_per_step": n},
+                              "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "strong" if fixed_job else "weak",
+                              "vs_baseline": None, "dtype": "int16", "data": "dry-run (no codec: launcher and work-queue plumbing only)",
+                              "config": {"workload": "dry-run" + (" of configs[4]: %d reads over %d rank(s)" % (total_reads, world) if fixed_job else ""),
+                                         "reads_per_step": n},
+                              "rank_imbalance": round(float(table[:, 1].max()) * world / max(float(table[:, 1].sum()), 1.0), 4),
                               "tallies": table.tolist(), "ranges": [list(p) for p in shard.partition_reads(lengths, world)]}), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -279,7 +305,7 @@ def run_rank(args):
 
     codec = batch.GpuCodec(local_rank)
     torch.cuda.set_stream(codec.stream)  # everything below (generation, events, kernels) runs on the codec's stream
-    if args.workload != "reads":
+    if args.workload in ("config4", "config1"):
         run_large(args, codec, dev, rank, world, coll_dev, barrier)
         if world > 1:
             barrier()
@@ -297,16 +323,27 @@ def run_rank(args):
         while n > 8192 and free < fixed(n) + n * per_read:
             n //= 2
     R = args.resident or max(1, min(args.steps, 16, int((free - fixed(n)) // (n * per_read * 1.02))))
+    fixed_job = args.workload == "config5"
 
     # ---- the work queue: rank 0 owns the read table (lengths of world x R x n reads), every rank takes the contiguous,
-    # sample-balanced range the partition gives it and cuts it into R batches (weak scaling: per-GPU work is fixed)
-    total_reads = world * R * n
+    # sample-balanced range the partition gives it and cuts it into R batches (weak scaling: per-GPU work is fixed).
+    # configs[4] (--workload config5) is a FIXED job instead: --total-reads reads for all ranks together (strong scaling);
+    # a rank's share is cut into batches of at most n reads, all resident, each coded once in the timed region.
+    total_reads = args.total_reads if fixed_job else world * R * n
     if rank == 0:
         lengths = torch.cat([codec.synth_lengths(5, f, min(1 << 20, total_reads - f)).to(torch.int64) for f in range(0, total_reads, 1 << 20)])
     else:
         lengths = torch.zeros(total_reads, dtype=torch.int64, device=dev)
     lengths = shard.share_read_table(lengths, coll_dev)
     my_first, my_last = shard.partition_reads(lengths, world)[rank]
+    if fixed_job:
+        R = max(1, -(-(my_last - my_first) // n))
+        need = R * n * per_read * 1.02 + fixed(n)
+        if need > free:
+            raise SystemExit("bench.py --workload config5: this rank's share (%d reads, %.0f GB resident) does not fit %.0f GB of free HBM; "
+                             "use more GPUs or fewer --total-reads" % (my_last - my_first, need / 1e9, free / 1e9))
+        args.steps = R          # one pass over the rank's share
+        args.warmup = min(args.warmup, 1)
     ranges = shard.cut_batches(my_first, my_last, lengths, R)
 
     max_total = max_ctotal = 0
@@ -477,12 +514,14 @@ def run_rank(args):
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if fixed_job else "weak",
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: synthetic int16 reads of ~100k samples (SURVEY 8d generator, seed 5), "
+                "workload": ("configs[4]: a FIXED job of %d reads (%.1f GB raw over all ranks) sharded over %d GPU(s) by cumulative samples, every rank's share "
+                             "resident and coded once; per batch: " % (total_reads, total_raw / 1e9, world) if fixed_job else "") +
+                            "configs[1]: synthetic int16 reads of ~100k samples (SURVEY 8d generator, seed 5), "
                             "~%d reads (%.2f GB raw) per step per GPU (batches are cut by cumulative samples), %d distinct batches resident per GPU (%d distinct reads over %d GPU(s), each "
                             "round-trip verified before the timed region), zig-zag + svb + zstd-format stage, encode then decode, inputs resident in HBM"
                             % (batches[0]["n"], batches[0]["raw_bytes"] / 1e9, R, total_reads, world),
@@ -493,6 +532,7 @@ def run_rank(args):
                 "parallelism": "read table partitioned by cumulative samples across %d GPU(s) (rank 0 broadcasts the table, "
                                "all-gather of tallies); no data-path collective" % world,
             },
+            "rank_imbalance": round(float(table[:, 1].max()) * world / max(float(table[:, 1].sum()), 1.0), 4),   # slowest rank's raw bytes over the mean
             "ratio": round(ratio, 4),
             "encode_MBps": round(raw_bytes / (enc_ms * 1e-3) / 1e6, 1),
             "decode_MBps": round(raw_bytes / (dec_ms * 1e-3) / 1e6, 1),
@@ -677,8 +717,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=DEFAULT_READS, help="reads per batch (one batch per step)")
     ap.add_argument("--resident", type=int, default=0, help="distinct batches kept in HBM and cycled (0: as many as fit, at most 16)")
-    ap.add_argument("--workload", default="reads", choices=["reads", "config4", "config1"],
-                    help="reads: BASELINE configs[1] (the headline); config4: uint32 10M-element buffers; config1: one 400k-sample read")
+    ap.add_argument("--workload", default="reads", choices=["reads", "config4", "config1", "config5"],
+                    help="reads: BASELINE configs[1] (the headline); config4: uint32 10M-element buffers; config1: one 400k-sample read; "
+                         "config5: BASELINE configs[4], a FIXED job of --total-reads reads (~100 GB) sharded over the ranks (strong scaling)")
+    ap.add_argument("--total-reads", type=int, default=500000, help="config5: reads of the whole job (500 000 x ~100 k samples = 100 GB raw)")
     ap.add_argument("--buffers", type=int, default=8, help="config4: buffers per step")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the work queue (nccl = RCCL)")
     ap.add_argument("--dry-run", action="store_true", help="launcher and work-queue plumbing only: no codec, no GPU (CPU test of the N > 1 path)")
@@ -688,11 +730,11 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if not args.dry_run:
-            import torch  # device_count() does not initialise the GPU on this image
-
-            have = torch.cuda.device_count()
-            if have < args.gpus:
-                raise SystemExit("bench.py: --gpus %d but %d GPU(s) visible" % (args.gpus, have))
+            # the parent must not touch the HIP runtime (its children would be forks of an initialised process): the GPUs are
+            # counted from the kernel driver's topology; when that cannot be read the ranks find out for themselves
+            have = kfd_gpu_count()
+            if have is not None and have < args.gpus:
+                raise SystemExit("bench.py: --gpus %d but %d GPU(s) in /sys/class/kfd" % (args.gpus, have))
         return launch_ranks(args, sys.argv[1:])
     return run_rank(args)
 

@@ -103,6 +103,52 @@ def test_bench_launcher_starts_one_process_per_rank():
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
+def test_fixed_job_is_sharded_over_the_ranks():
+    """BASELINE configs[4] (`--workload config5`): a FIXED number of reads for the whole job, cut over the ranks by cumulative
+    samples (strong scaling), every rank coding its share in batches of at most --reads reads.  Dry run, two ranks, gloo."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    outs = {}
+    for gpus in (1, 2):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--workload", "config5", "--dry-run", "--total-reads",
+                            "3001", "--reads", "500"], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        outs[gpus] = json.loads(lines[0])
+    one, two = outs[1], outs[2]
+    assert one["scaling"] == two["scaling"] == "strong" and two["n_gpus"] == 2
+    assert one["ranges"] == [[0, 3001]] and one["steps"] == 7                 # 3001 reads in batches of at most 500
+    (a0, b0), (a1, b1) = two["ranges"]
+    assert a0 == 0 and b0 == a1 and b1 == 3001                                # the same job, not a bigger one
+    assert two["steps"] in (3, 4)                                             # rank 0: ~1500 reads in batches of at most 500
+    t = two["tallies"]
+    assert t[0][0] + t[1][0] == 3001 and t[0][1] + t[1][1] == one["tallies"][0][1]
+    assert 1.0 <= two["rank_imbalance"] < 1.01
+
+
+def test_launcher_counts_gpus_without_the_hip_runtime():
+    """The launcher parent must not initialise HIP (its children would be forks of an initialised process): it counts the
+    GPUs from /sys/class/kfd, or not at all.  Here (no GPU, usually no kfd) the function answers None or a number and
+    bench.py's parent path imports no torch.cuda call."""
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.kfd_gpu_count()
+    assert n is None or (isinstance(n, int) and n >= 0)
+    src = open(os.path.join(root, "bench.py")).read()
+    launcher = src[src.index("def main():"):]
+    assert "device_count" not in launcher and "is_available" not in launcher
+
+
 def test_single_rank_identity():
     table, off = shard.exchange_tallies(5, 100, 40)
     assert table.tolist() == [[5, 100, 40]] and off == 0
