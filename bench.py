@@ -111,10 +111,11 @@ def cpu_baseline_u32(n_buffers, count, min_seconds=6.0):
 
 
 def cpu_baseline(min_seconds=8.0, n_reads=16384):
-    """The oracle (port of the reference CPU path: scalar svb + the pinned libzstd, dlopen'd) timed on this box's
-    host cores on a bounded sample of the same workload: reads [0, n_reads) of the same generator, encode+decode,
-    persistent pthreads claiming reads from a queue (reads are independent; the reference has no internal
-    threading), verification in an untimed pass.  The oracle is checker code: here it is only the reported baseline."""
+    """The oracle (port of the reference CPU path: the int16 zig-zag stage in SSSE3 form like the reference's hot path --
+    oracle/vbz_oracle_simd.c, own code, byte-identical to the scalar restatement -- plus the pinned libzstd, dlopen'd) timed on
+    this box's host cores on a bounded sample of the same workload: reads [0, n_reads) of the same generator, encode+decode,
+    persistent pthreads claiming reads from a queue (reads are independent; the reference has no internal threading),
+    verification in an untimed pass.  The oracle is checker code: here it is only the reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
 
@@ -123,23 +124,44 @@ def cpu_baseline(min_seconds=8.0, n_reads=16384):
     if cores < 32:  # a small host (or a small CPU quota): keep the leg at ~10-30 s of CPU work
         n_reads = min(n_reads, 256 * cores)
     opts = O.options(True, 2, 1, 1)
-    one = O.bench_roundtrip(min(n_reads, 64), 1, 1.0, opts)
-    allc = O.bench_roundtrip(n_reads, cores, min_seconds, opts)
+    simd = O.simd_available()
+    one_scalar = O.bench_roundtrip(min(n_reads, 64), 1, 1.0, opts)
+    one = O.bench_roundtrip(min(n_reads, 64), 1, 1.0, opts, simd=simd)
+    allc = O.bench_roundtrip(n_reads, cores, min_seconds, opts, simd=simd)
+    one_MBps = one["raw_bytes"] / one["best_s"] / 1e6
     out = {
         "value": round(allc["raw_bytes"] / allc["best_s"] / 1e6, 1),
         "unit": "MB/s",
         "cores": cores,
         "kind": "port",
         "sample": "reads 0..%d of the same generator (%.1f MB raw), encode+decode, %d persistent threads (%s) claiming reads from a "
-                  "queue, scalar svb (not the SSSE3 worker) + libzstd %s level 1, verification in an untimed pass, best of %d timed "
-                  "passes; one thread: %.1f MB/s"
-        % (n_reads - 1, allc["raw_bytes"] / 1e6, cores, quota_note, (O.lib().vbo_zstd_version() or b"?").decode(), allc["passes"],
-           one["raw_bytes"] / one["best_s"] / 1e6),
-        "one_thread": round(one["raw_bytes"] / one["best_s"] / 1e6, 1),
+                  "queue, %s svb + libzstd %s level 1, verification in an untimed pass, best of %d timed passes; one thread: %.1f MB/s "
+                  "(%.1f with the scalar svb)"
+        % (n_reads - 1, allc["raw_bytes"] / 1e6, cores, quota_note, "SSSE3 (own code, the reference's class of path)" if simd else "scalar",
+           (O.lib().vbo_zstd_version() or b"?").decode(), allc["passes"], one_MBps, one_scalar["raw_bytes"] / one_scalar["best_s"] / 1e6),
+        "one_thread": round(one_MBps, 1),
+        "one_thread_scalar_svb": round(one_scalar["raw_bytes"] / one_scalar["best_s"] / 1e6, 1),
         "host_hw_threads": hw,
         "ratio": round(allc["raw_bytes"] / allc["comp_bytes"], 4),
         "encode_share": round(allc["enc_thread_s"] / (allc["enc_thread_s"] + allc["dec_thread_s"]), 3),
     }
+    # BASELINE.json's target is stated against a single socket.  When the process cannot use one (a CPU quota, an affinity
+    # mask) it is EXTRAPOLATED: one thread's rate x the physical cores of socket 0 (an upper bound: perfect scaling)
+    try:
+        cores0 = set()
+        import glob as _glob
+
+        for path in _glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/physical_package_id"):
+            with open(path) as f:
+                if int(f.read()) != 0:
+                    continue
+            with open(os.path.join(os.path.dirname(path), "core_id")) as f:
+                cores0.add(int(f.read()))
+        if cores0 and cores < len(cores0):
+            out["single_socket"] = {"value": round(one_MBps * len(cores0), 1), "unit": "MB/s", "cores": len(cores0),
+                                    "how": "extrapolated = one_thread x physical cores of socket 0 (the process may use %d CPUs' worth of time)" % cores}
+    except (OSError, ValueError):
+        pass
     # BASELINE.json's target is stated against a single socket: time one socket's hardware threads as well
     # (the worker pthreads inherit the affinity set here)
     try:
@@ -152,10 +174,10 @@ def cpu_baseline(min_seconds=8.0, n_reads=16384):
             saved = os.sched_getaffinity(0)
             os.sched_setaffinity(0, socket0)
             try:
-                s0 = O.bench_roundtrip(n_reads, len(socket0), min_seconds / 2, opts)
+                s0 = O.bench_roundtrip(n_reads, len(socket0), min_seconds / 2, opts, simd=simd)
             finally:
                 os.sched_setaffinity(0, saved)
-            out["single_socket"] = {"value": round(s0["raw_bytes"] / s0["best_s"] / 1e6, 1), "unit": "MB/s", "cores": len(socket0)}
+            out["single_socket"] = {"value": round(s0["raw_bytes"] / s0["best_s"] / 1e6, 1), "unit": "MB/s", "cores": len(socket0), "how": "measured"}
     except OSError:
         pass
     return out

@@ -338,6 +338,10 @@ vbo_size_t vbo_max_streamvbyte_size(size_t integer_size, vbo_size_t source_size)
     return (vbo_size_t)svb_max_bytes((uint32_t)(source_size / integer_size));
 }
 
+/* the CPU baseline leg of bench.py switches the SSSE3 form of the int16 zig-zag stage on (vbz_oracle_simd.c) */
+static int g_simd_svb = 0;
+void vbo_use_simd_svb(int on) { g_simd_svb = on && vbo_simd_available(); }
+
 vbo_size_t vbo_streamvbyte_compress(const void* src, vbo_size_t src_size, void* dst, vbo_size_t dst_cap, int integer_size,
                                     bool zigzag, unsigned version)
 {
@@ -345,7 +349,10 @@ vbo_size_t vbo_streamvbyte_compress(const void* src, vbo_size_t src_size, void* 
     /* vbz/v0/vbz_streamvbyte.cpp:20-65, vbz/v1/vbz_streamvbyte.cpp:22-65 */
     if (integer_size != 1 && integer_size != 2 && integer_size != 4) return VBO_INTEGER_SIZE_ERROR;
     if (src_size % (uint32_t)integer_size != 0) return VBO_INPUT_SIZE_ERROR;
-    if (integer_size == 2 && zigzag) return i16zz_compress((const uint8_t*)src, src_size, (uint8_t*)dst);
+    if (integer_size == 2 && zigzag) {
+        if (g_simd_svb) return vbo_i16zz_compress_simd((const uint8_t*)src, src_size, (uint8_t*)dst);
+        return i16zz_compress((const uint8_t*)src, src_size, (uint8_t*)dst);
+    }
     return generic_compress((const uint8_t*)src, src_size, (uint8_t*)dst, integer_size, zigzag,
                             version == 1 && integer_size == 1);
 }
@@ -356,8 +363,13 @@ vbo_size_t vbo_streamvbyte_decompress(const void* src, vbo_size_t src_size, void
     /* vbz/v0/vbz_streamvbyte.cpp:67-108, vbz/v1/vbz_streamvbyte.cpp:67-113 */
     if (integer_size != 1 && integer_size != 2 && integer_size != 4) return VBO_INTEGER_SIZE_ERROR;
     if (dst_size % (uint32_t)integer_size != 0) return VBO_DESTINATION_SIZE_ERROR;
-    if (integer_size == 2 && zigzag)
+    if (integer_size == 2 && zigzag) {
+        if (g_simd_svb) {
+            const vbo_size_t r = vbo_i16zz_decompress_simd((const uint8_t*)src, src_size, (uint8_t*)dst, dst_size);
+            if (r != VBO_SIMD_DECLINED) return r;
+        }
         return i16zz_decompress((const uint8_t*)src, src_size, (uint8_t*)dst, dst_size);
+    }
     return generic_decompress((const uint8_t*)src, src_size, (uint8_t*)dst, dst_size, integer_size, zigzag,
                               version == 1 && integer_size == 1);
 }

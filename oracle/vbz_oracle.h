@@ -52,6 +52,14 @@ typedef struct VboOptions {
 } VboOptions;
 
 /* ---- L1: integer codec (reference vbz/v0/vbz_streamvbyte.cpp, vbz/v1/vbz_streamvbyte.cpp) */
+/* vbz_oracle_simd.c: an SSSE3 form of the int16 zig-zag stage, byte-identical to the scalar one, for the CPU baseline leg
+ * only.  vbo_use_simd_svb(1) makes vbo_streamvbyte_compress / _decompress (hence vbo_compress / vbo_decompress) take it
+ * for integer_size 2 with zig-zag; the default is the scalar restatement. */
+#define VBO_SIMD_DECLINED ((vbo_size_t)-100)
+int vbo_simd_available(void);
+void vbo_use_simd_svb(int on);
+vbo_size_t vbo_i16zz_compress_simd(const uint8_t* src, vbo_size_t src_size, uint8_t* dst);
+vbo_size_t vbo_i16zz_decompress_simd(const uint8_t* src, vbo_size_t src_size, uint8_t* dst, vbo_size_t dst_size);
 vbo_size_t vbo_max_streamvbyte_size(size_t integer_size, vbo_size_t source_size);
 vbo_size_t vbo_streamvbyte_compress(const void* src, vbo_size_t src_size, void* dst, vbo_size_t dst_cap,
                                     int integer_size, bool zigzag, unsigned version);

@@ -31,7 +31,7 @@ class Options(ctypes.Structure):
 
 def build_oracle():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vbz_oracle.c", "zstd_restate.c", "vbz_oracle_bench.c", "vbz_oracle_fuzz.c", "vbz_oracle.h", "Makefile")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("vbz_oracle.c", "zstd_restate.c", "vbz_oracle_bench.c", "vbz_oracle_fuzz.c", "vbz_oracle_simd.c", "vbz_oracle.h", "Makefile")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return so
@@ -89,6 +89,14 @@ def lib():
         L.vbo_bench_roundtrip.argtypes = [u32, ctypes.c_int, ctypes.c_double, op, ctypes.POINTER(ctypes.c_double)]
         L.vbo_bench_roundtrip_u32.restype = ctypes.c_int
         L.vbo_bench_roundtrip_u32.argtypes = [u32, u32, ctypes.c_int, ctypes.c_double, op, ctypes.POINTER(ctypes.c_double)]
+        L.vbo_simd_available.restype = ctypes.c_int
+        L.vbo_use_simd_svb.restype = None
+        L.vbo_use_simd_svb.argtypes = [ctypes.c_int]
+        for name in ("vbo_i16zz_compress_simd",):
+            getattr(L, name).restype = u32
+            getattr(L, name).argtypes = [vp, u32, vp]
+        L.vbo_i16zz_decompress_simd.restype = u32
+        L.vbo_i16zz_decompress_simd.argtypes = [vp, u32, vp, u32]
         L.vbo_fuzz_max_destination.restype = u32
         L.vbo_fuzz_max_destination.argtypes = [u32, op]
         L.vbo_fuzz_decompress_sweep.restype = ctypes.c_int
@@ -137,6 +145,32 @@ def svb_decompress(buf, nbytes, size, zigzag, version=0):
     out = np.zeros(max(nbytes, 1), np.uint8)
     r = lib().vbo_streamvbyte_decompress(p, n, out.ctypes.data, nbytes, size, zigzag, version)
     if is_error(r):
+        return r
+    return out[:r].copy()
+
+
+SIMD_DECLINED = 0xFFFFFF9C   # (vbo_size_t)-100: not a stream the SSSE3 decoder takes
+
+
+def simd_available():
+    return bool(lib().vbo_simd_available())
+
+
+def i16zz_compress_simd(arr):
+    """The SSSE3 form of the int16 zig-zag stage (oracle/vbz_oracle_simd.c: CPU baseline leg only)."""
+    a, p, n = _buf(arr)
+    out = np.zeros(n // 2 // 4 + n + 64, np.uint8)
+    r = lib().vbo_i16zz_compress_simd(p, n, out.ctypes.data)
+    return out[:r].copy()
+
+
+def i16zz_decompress_simd(buf, nbytes):
+    a, p, n = _buf(np.frombuffer(bytes(buf), np.uint8) if not isinstance(buf, np.ndarray) else buf)
+    src = np.zeros(n + 64, np.uint8)   # (the vector loads stay inside the stream by the 32-byte rule; slack for safety)
+    src[:n] = a.view(np.uint8).reshape(-1)[:n]
+    out = np.zeros(max(nbytes, 1) + 16, np.uint8)
+    r = lib().vbo_i16zz_decompress_simd(src.ctypes.data, n, out.ctypes.data, nbytes)
+    if r >= FIRST_ERROR or r == SIMD_DECLINED:
         return r
     return out[:r].copy()
 
@@ -223,14 +257,18 @@ def fnv1a64(data):
     return "%016x" % h
 
 
-def bench_roundtrip(n_reads, threads, min_seconds, opts, u32_count=0):
+def bench_roundtrip(n_reads, threads, min_seconds, opts, u32_count=0, simd=False):
     """Threaded CPU timing of encode+decode over reads [0, n_reads) of the synthetic workload (u32_count: buffers of that
-    many uint32 values of the config-4 generator instead of int16 reads)."""
+    many uint32 values of the config-4 generator instead of int16 reads).  simd: the int16 zig-zag stage in its SSSE3 form."""
     out = (ctypes.c_double * 6)()
-    if u32_count:
-        rc = lib().vbo_bench_roundtrip_u32(n_reads, u32_count, threads, min_seconds, ctypes.byref(opts), out)
-    else:
-        rc = lib().vbo_bench_roundtrip(n_reads, threads, min_seconds, ctypes.byref(opts), out)
+    lib().vbo_use_simd_svb(1 if simd else 0)
+    try:
+        if u32_count:
+            rc = lib().vbo_bench_roundtrip_u32(n_reads, u32_count, threads, min_seconds, ctypes.byref(opts), out)
+        else:
+            rc = lib().vbo_bench_roundtrip(n_reads, threads, min_seconds, ctypes.byref(opts), out)
+    finally:
+        lib().vbo_use_simd_svb(0)
     if rc != 0:
         raise RuntimeError("oracle bench failed (%d)" % rc)
     return dict(raw_bytes=out[0], comp_bytes=out[1], best_s=out[2], enc_thread_s=out[3], dec_thread_s=out[4], passes=int(out[5]))

@@ -249,3 +249,43 @@ def test_fuzz_corpus_replay_on_the_oracle():
     assert calls == 949216
     assert dict(tally) == {"ok": 87750, "VBZ_DESTINATION_SIZE_ERROR": 539540, "VBZ_INPUT_SIZE_ERROR": 512, "VBZ_ZSTD_ERROR": 252044,
                            "VBZ_STREAMVBYTE_STREAM_ERROR": 69322, "VBZ_OUT_OF_MEMORY_ERROR": 48}, dict(tally)
+
+
+def test_ssse3_svb_of_the_baseline_leg_is_the_scalar_restatement():
+    """oracle/vbz_oracle_simd.c (own SSSE3 code, used by bench.py's CPU baseline so that the baseline is the reference's class
+    of CPU path) against the scalar restatement the known answers pin: byte-identical streams, identical samples and errors."""
+    if not O.simd_available():
+        pytest.skip("no SSSE3 on this host")
+    rng = np.random.default_rng(31)
+    reads = [O.synth_signal(5, i, n) for i, n in enumerate([1, 2, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 1000, 4097, 100003])]
+    reads.append(rng.integers(-32768, 32767, 30001, endpoint=True).astype(np.int16))   # full range, wraps: mostly two-byte codes
+    reads.append(np.array([32767, -32768] * 500, np.int16))
+    reads.append(np.zeros(5000, np.int16))
+    reads.append(np.fromfile(os.path.join(GOLDEN, "test_data_read.i16"), dtype="<i2"))
+    for a in reads:
+        want = O.svb_compress(a, 2, True, 0)
+        got = O.i16zz_compress_simd(a)
+        assert got.tobytes() == want.tobytes(), len(a)
+        back = O.i16zz_decompress_simd(want, a.nbytes)
+        assert not isinstance(back, int) and back.tobytes() == a.tobytes(), len(a)
+        for bad, nb in ((want[:-1], a.nbytes), (np.concatenate([want, np.zeros(1, np.uint8)]), a.nbytes), (want, a.nbytes + 2)):
+            w = O.svb_decompress(bad, nb, 2, True, 0)
+            g = O.i16zz_decompress_simd(bad, nb)
+            if g == O.SIMD_DECLINED:
+                continue   # (a code above 1 appeared where the stream was cut: the scalar function decides)
+            assert (isinstance(w, int) and g == w) or (not isinstance(w, int) and g.tobytes() == w.tobytes()), (len(a), nb)
+    # a stream with a code above 1 is declined, not decoded
+    st = O.svb_compress(reads[15], 2, True, 0).copy()
+    st[3] |= 0x80
+    assert O.i16zz_decompress_simd(st, reads[15].nbytes) in (O.SIMD_DECLINED, 0xFFFFFFFB)
+    # and the whole path through vbo_compress / vbo_decompress with the switch on gives the same frames
+    a = reads[17]
+    oo = O.options(True, 2, 1, 1)
+    f0 = O.compress(a, oo)
+    O.lib().vbo_use_simd_svb(1)
+    try:
+        f1 = O.compress(a, oo)
+        b1 = O.decompress(f0, a.nbytes, oo)
+    finally:
+        O.lib().vbo_use_simd_svb(0)
+    assert f1.tobytes() == f0.tobytes() and b1.tobytes() == a.tobytes()
