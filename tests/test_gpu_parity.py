@@ -400,6 +400,43 @@ def test_sampled_histogram_that_misleads():
         assert len(f) < 0.45 * len(s), (len(s), len(f))
 
 
+def test_huffman_blocks_stay_below_the_block_maximum():
+    """A compressed block above Block_Maximum_Size (128 KB) is one no decoder accepts.  On the one-wavefront path blocks of a
+    long stream used to be cut at 128 KB of CONTENT, and a Huffman block can come out longer than its content (11-bit codes
+    from a region-wide or sampled table on a block that looks nothing like the rest): content is now cut at 92 KB.  A 1.5 M-sample
+    read next to small ones (the batch stays on the one-wavefront path) whose data bytes change character block by block."""
+    import gpu_util as G
+    from vbz_compression_amd import _lib
+
+    rng = np.random.default_rng(41)
+    parts = []
+    for k in range(12):   # quiet stretches (one byte value dominates) next to noise (all byte values): one table serves neither well
+        if k % 2:
+            parts.append(rng.integers(-127, 128, 125000).astype(np.int16))
+        else:
+            parts.append((rng.integers(0, 2, 125000) * 3).astype(np.int16))
+    big = np.cumsum(np.concatenate(parts)).astype(np.int16)
+    reads = [big] + [O.synth_signal(5, i, 20000) for i in range(7)]
+    go, oo = _lib.CompressionOptions(True, 2, 1, 1), O.options(True, 2, 1, 1)
+    frames = G.compress(reads, go)
+    back = G.decompress(frames, [a.nbytes for a in reads], go)
+    for a, f, b in zip(reads, frames, back):
+        assert not isinstance(f, int) and not isinstance(b, int)
+        assert b.tobytes() == a.tobytes()
+        assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes()          # libzstd refuses oversized blocks
+    # every block header of the big frame announces at most 128 KB
+    f = frames[0]
+    p = 4 + 1 + 4   # magic, frame header descriptor (0xA0), 4-byte content size
+    assert f[4] == 0xA0
+    while True:
+        bh = int(f[p]) | (int(f[p + 1]) << 8) | (int(f[p + 2]) << 16)
+        last, bt, bs = bh & 1, (bh >> 1) & 3, bh >> 3
+        assert bs <= 128 * 1024
+        p += 3 + (1 if bt == 1 else bs)
+        if last:
+            break
+
+
 def test_region_larger_than_the_sort_key_counts():
     """One wavefront on a 40 MB stream (ordinary path forced): the histogram of the data region exceeds the 24 bits the
     table construction's sort keys hold and is scaled down; the code stays valid and the frame decodes everywhere."""

@@ -2058,9 +2058,12 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         const uint32_t modes = SQB(used0);
                         const uint32_t llm = modes >> 6, ofm = (modes >> 4) & 3;
                         const uint32_t ofsym_at = used0 + 1 + (llm == 1 ? 1u : 0u);
-                        ws_lit = ((fcs + 15u) & ~15u) + (partial ? sp.ord * DSPAN_WS_STRIDE : 0u);
+                        // (64-bit: a crafted index on a frame of half a gigabyte could make the stripe offset wrap)
+                        const uint64_t ws_lit64 = (((uint64_t)fcs + 15u) & ~15ull) + (partial ? (uint64_t)sp.ord * DSPAN_WS_STRIDE : 0ull);
+                        const bool ws_ok = ws_lit64 + BLOCK_MAX + 16 < 0xFFFFFFF0ull;
+                        ws_lit = ws_ok ? (uint32_t)ws_lit64 : 0u;
                         ws_pairs = ws_lit + (ltype >= 2 ? ((regen + 7u) & ~7u) : 0u);
-                        go = (ofm == 1 && llm != 2 && ofsym_at < sqn && SQB(ofsym_at) == 0 && rep0 == 1 &&
+                        go = (ws_ok && ofm == 1 && llm != 2 && ofsym_at < sqn && SQB(ofsym_at) == 0 && rep0 == 1 &&
                               (uint64_t)ws_pairs + 8ull * ns0 + 8 <= cap &&
                               (!partial || (uint64_t)ws_pairs + 8ull * ns0 + 8 <= (uint64_t)ws_lit + DSPAN_WS_STRIDE)) ? 1u : 0u;
                         // predefined LL and ML tables (what zstd_encode.hip writes): nothing to build
@@ -2601,10 +2604,13 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                                                                uint32_t* dspan_count, uint32_t* dspan_status)
 {
     __shared__ uint32_t wcnt[16];
-    __shared__ uint32_t carry_c;
+    __shared__ uint32_t carry_c, limit_s;
     __shared__ uint32_t q_ns[1024], q_tb[1024], q_ok[1024], q_first[1024], q_hl[1024], q_fcs[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (tid == 0) carry_c = 0;
+    if (tid == 0) {
+        carry_c = 0;
+        limit_s = max_spans;   // the first span that has no descriptor (a read whose spans do not fit the arrays)
+    }
     __syncthreads();
     for (uint32_t base = 0; base < b.n_reads; base += 1024) {
         const uint32_t i = base + tid;
@@ -2678,7 +2684,10 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
             const uint32_t si = pc + ci - cnt;
             dspan_first[i] = si;
             q_first[tid] = si;
-            if (si + cnt > max_spans) q_ok[tid] = 2;  // cannot happen with the host's bound: the read is left to the second launch
+            if (si + cnt > max_spans) {  // cannot happen with the host's bound: the read is left to the second launch, and the
+                q_ok[tid] = 2;           // span launch stops in front of its (unwritten) descriptors
+                atomicMin(&limit_s, si);
+            }
         }
         __syncthreads();
         // (4) all threads: the descriptors
@@ -2718,7 +2727,7 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
     }
     if (tid == 0) {
         dspan_first[b.n_reads] = carry_c;
-        *dspan_count = carry_c < max_spans ? carry_c : max_spans;
+        *dspan_count = carry_c < limit_s ? carry_c : limit_s;
     }
 }
 

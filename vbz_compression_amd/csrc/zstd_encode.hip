@@ -40,6 +40,7 @@ namespace {
 constexpr int WAVE = 64;
 constexpr uint32_t BLOCK_MAX = 128u << 10;
 constexpr uint32_t MIN_BLOCK = 4096;      // target block size is at least this
+constexpr uint32_t HUF_BLOCK_MAX = 92u << 10;   // content of a Huffman-coded block: 11/8 of it + tree + headers < BLOCK_MAX
 constexpr uint32_t SPLIT_MIN = 2048;      // frames smaller than this are one region
 constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams = 64 lanes)
 // Large reads (span mode, see EncSpan): blocks of at most SPAN_BLOCK bytes, SPAN_BLOCKS of them per span.  A span is what ONE
@@ -1256,8 +1257,11 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         FINISH(opos + 3);
         return;
     }
+    // (a Huffman block may come out LONGER than its content -- 11-bit codes from a sampled or region-wide table on a block
+    // that does not look like the rest -- and a compressed block above Block_Maximum_Size is one no decoder accepts: blocks
+    // are cut so that even 11 bits per byte stay below it)
     uint32_t T = (N + 13) / 14;
-    T = T < MIN_BLOCK ? MIN_BLOCK : (T > BLOCK_MAX ? BLOCK_MAX : T);
+    T = T < MIN_BLOCK ? MIN_BLOCK : (T > HUF_BLOCK_MAX ? HUF_BLOCK_MAX : T);
     if (span_mode) T = SPAN_BLOCK;
 
     bool keys_one_block = false;
@@ -1310,7 +1314,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         if (region >= 1 && keys_one_block) {
             // the control bytes took one block (4 streams): the data bytes get the other 15 x 4 lanes of the decoder
             uint32_t Td = (S + DATA_BLOCKS - 1) / DATA_BLOCKS;
-            Td = Td < MIN_BLOCK ? MIN_BLOCK : (Td > BLOCK_MAX ? BLOCK_MAX : Td);
+            Td = Td < MIN_BLOCK ? MIN_BLOCK : (Td > HUF_BLOCK_MAX ? HUF_BLOCK_MAX : Td);
             nblk = (S + Td - 1) / Td;
         }
         // control-byte region of a library-owned svb stream: turn long zero runs into sequences.  The
