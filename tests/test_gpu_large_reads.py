@@ -300,3 +300,78 @@ def test_aliased_sources_cannot_overflow_the_segment_tables():
         for i in range(n):
             assert int(res[i]) == a.nbytes
             assert host[int(ooff[i]) : int(ooff[i]) + a.nbytes].tobytes() == a.tobytes()
+
+
+def test_long_reads_among_many_short_ones_are_routed():
+    """The reference treats every buffer alike (vbz/vbz.cpp:116-208); ultra-long nanopore reads exist (the shipped file already
+    spans 9 885 ... 505 057 samples).  A batch of 4096 reads of ~100 k samples with three reads of 5 M samples among them: the
+    batch's AVERAGE says "one workgroup / one wavefront per read", which for a 5 M-sample read means tens of milliseconds on
+    one wavefront -- the library routes such reads to the large-read path on the device.  Bit-exact both ways (the frames of
+    the long reads carry a span index and decode through the reference's decoder), the other reads' frames are byte for byte
+    what they are without the long reads, and the batch takes < 1.3 x the time of the same batch without them."""
+    import time
+
+    c = G.codec()
+    dev = c.device
+    L = _lib.load()
+    go, oo = _lib.CompressionOptions(True, 2, 1, 1), O.options(True, 2, 1, 1)
+    n_short, long_at = 4096, (7, 2000, 4098)
+    short = [O.synth_signal(5, i % 64, 90000 + 311 * (i % 64)) for i in range(64)]
+    longs = [O.synth_signal(5, 100 + k, 5_000_000) for k in range(3)]
+
+    def build(with_long):
+        reads = [short[i % 64] for i in range(n_short)]
+        if with_long:
+            for pos, a in zip(long_at, longs):
+                reads.insert(pos, a)
+        sizes = [a.nbytes for a in reads]
+        off, total = batch.layout(sizes, 64)
+        raw = torch.zeros(total, dtype=torch.uint8, device=dev)
+        uniq = {}
+        for a, o_ in zip(reads, off.tolist()):
+            if id(a) not in uniq:
+                uniq[id(a)] = torch.from_numpy(np.frombuffer(a.tobytes(), np.uint8).copy()).to(dev)
+            raw[o_ : o_ + a.nbytes] = uniq[id(a)]
+        caps = [L.vbz_max_compressed_size(sz, ctypes.byref(go)) for sz in sizes]
+        coff, ctotal = batch.layout(caps, 64)
+        return dict(reads=reads, raw=raw, off=off.to(dev), size=torch.tensor(sizes, dtype=torch.int32, device=dev), coff=coff.to(dev), coff_h=coff,
+                    cap=torch.tensor(caps, dtype=torch.int32, device=dev), comp=torch.zeros(ctotal, dtype=torch.uint8, device=dev),
+                    csize=torch.zeros(len(reads), dtype=torch.int32, device=dev), back=torch.zeros(total, dtype=torch.uint8, device=dev),
+                    res=torch.zeros(len(reads), dtype=torch.int32, device=dev))
+
+    def run(B, reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c.compress(B["raw"], B["off"], B["size"], B["comp"], B["coff"], B["cap"], B["csize"], go)
+            c.decompress(B["comp"], B["coff"], B["csize"], B["back"], B["off"], B["size"], B["res"], go)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    A, B = build(False), build(True)
+    run(A, 1)
+    run(B, 1)
+    assert bool((B["res"] == B["size"]).all()) and torch.equal(B["raw"], B["back"])
+    assert bool((A["res"] == A["size"]).all()) and torch.equal(A["raw"], A["back"])
+    comp = B["comp"].cpu().numpy()
+    cs = B["csize"].cpu().numpy()
+    compA, csA = A["comp"].cpu().numpy(), A["csize"].cpu().numpy()
+    for pos in long_at:   # the reference's decoder reads the long reads' frames; they came down the large-read path (span index)
+        f = comp[int(B["coff_h"][pos]) : int(B["coff_h"][pos]) + int(cs[pos])]
+        assert O.decompress(f, longs[0].nbytes, oo).tobytes() == B["reads"][pos].tobytes()
+        body, trailers = _trailers(f)
+        assert any(int(t[:4].view("<u4")[0]) == IDX_MAGIC for t in trailers)
+    ia = 0
+    for ib in range(len(B["reads"])):   # everybody else: the same bytes as without the long reads
+        if ib in long_at:
+            continue
+        if ia % 97 == 0:
+            fa = compA[int(A["coff_h"][ia]) : int(A["coff_h"][ia]) + int(csA[ia])]
+            fb = comp[int(B["coff_h"][ib]) : int(B["coff_h"][ib]) + int(cs[ib])]
+            assert fa.tobytes() == fb.tobytes(), (ia, ib)
+        ia += 1
+    tA = min(run(A, 3) for _ in range(2))
+    tB = min(run(B, 3) for _ in range(2))
+    raw_ratio = float(B["size"].to(torch.int64).sum()) / float(A["size"].to(torch.int64).sum())
+    print("4096 short reads: %.2f ms; with three 5 M-sample reads (%.3f x the bytes): %.2f ms = %.2f x" % (tA * 1e3, raw_ratio, tB * 1e3, tB / tA))
+    assert tB < 1.3 * tA, (tA, tB)

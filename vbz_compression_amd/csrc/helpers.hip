@@ -23,7 +23,7 @@ __global__ __launch_bounds__(1024) void plan_scratch_kernel(uint32_t n, const ui
         uint64_t slot = 0;
         bool gated = false;
         if (i < n) {
-            gated = gate_is_input && gate[i] >= E_FIRST;  // already failed: give it an empty slot
+            gated = gate_is_input && gate[i] >= GATE_SKIP;  // already failed (or not in this launch group): an empty slot
             const uint64_t bound = gated ? 0 : ((uint64_t)raw_size[i] * mul_num + mul_den - 1) / mul_den + 8;
             slot = ((bound + 15) & ~15ull) + 48;
         }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32
         uint32_t c = 0, g = 0;
         if (i < n) {
             g = gate ? gate[i] : 0u;
-            const uint32_t sz = g >= E_FIRST || size[i] >= E_FIRST ? 0u : size[i];
+            const uint32_t sz = g >= GATE_SKIP || size[i] >= E_FIRST ? 0u : size[i];
             c = sz ? (uint32_t)(((uint64_t)sz + unit - 1) / unit) : 1u;
         }
         // a read fits if its segments end inside the tables with one segment left for every read behind it; the scan is
@@ -100,6 +100,91 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32
     if (tid == 0) seg_first[n] = carry_s;
 }
 
+// ---- per-read routing (vbz_api.hip): the reads of `min_bytes` raw bytes and more, in batch order, at most max_reads of them and
+// max_bytes in all, become the compact second launch group (descriptors l_*[max_reads], l_map = their batch indices, *l_count;
+// l_gate = the read's input gate, GATE_SKIP behind the last routed one); gate_small[i] = GATE_SKIP for them, the input gate
+// (or 0) for everybody else.  Two launches: every thread looks at one read and long reads put their index on a candidate
+// list (they are rare); one workgroup sorts the list and takes from its front.
+constexpr uint32_t ROUTE_CAND_MAX = 1024;
+
+__global__ __launch_bounds__(256) void route_flag_kernel(ReadBatch b, const uint32_t* raw_size, uint32_t min_bytes, uint32_t* gate_small, uint32_t* cand,
+                                                         uint32_t* cand_count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b.n_reads) return;
+    const uint32_t g = b.gate ? b.gate[i] : 0u;
+    const uint32_t sz = raw_size[i];
+    bool big = g < GATE_SKIP && sz >= min_bytes && sz < E_FIRST;
+    if (big) {
+        const uint32_t at = atomicAdd(cand_count, 1u);
+        if (at < ROUTE_CAND_MAX) cand[at] = i;
+        else big = false;   // (more long reads than the list holds: this one stays in the first group)
+    }
+    gate_small[i] = big ? GATE_SKIP : g;
+}
+
+__global__ __launch_bounds__(1024) void route_pick_kernel(ReadBatch b, const uint32_t* raw_size, uint32_t max_reads, uint64_t max_bytes, uint32_t* gate_small,
+                                                          const uint32_t* cand, const uint32_t* cand_count, uint64_t* l_src_off, uint32_t* l_src_size,
+                                                          uint64_t* l_dst_off, uint32_t* l_dst_cap, uint32_t* l_gate, uint32_t* l_map, uint32_t* l_count)
+{
+    __shared__ uint32_t key[ROUTE_CAND_MAX];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n = *cand_count < ROUTE_CAND_MAX ? *cand_count : ROUTE_CAND_MAX;
+    for (uint32_t j = tid; j < max_reads; j += 1024) {
+        l_gate[j] = GATE_SKIP;
+        l_src_off[j] = 0;
+        l_dst_off[j] = 0;
+        l_src_size[j] = 0;
+        l_dst_cap[j] = 0;
+        l_map[j] = 0;
+    }
+    if (tid == 0) *l_count = 0;
+    if (n == 0) return;
+    key[tid] = tid < n ? cand[tid] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t k = 2; k <= ROUTE_CAND_MAX; k <<= 1)   // bitonic sort, ascending (the list came in any order)
+        for (uint32_t d = k >> 1; d > 0; d >>= 1) {
+            const uint32_t o = tid ^ d;
+            if (o > tid) {
+                const uint32_t x = key[tid], y = key[o];
+                const bool up = (tid & k) == 0;
+                if ((x > y) == up) {
+                    key[tid] = y;
+                    key[o] = x;
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {   // (a handful of entries: one thread walks them)
+        uint64_t bytes = 0;
+        uint32_t taken = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t i = key[j];
+            const uint32_t g = b.gate ? b.gate[i] : 0u;
+            if (taken < max_reads && bytes + raw_size[i] <= max_bytes) {
+                bytes += raw_size[i];
+                l_src_off[taken] = b.src_off[i];
+                l_src_size[taken] = b.src_size[i];
+                l_dst_off[taken] = b.dst_off[i];
+                l_dst_cap[taken] = b.dst_cap[i];
+                l_gate[taken] = g;
+                l_map[taken] = i;
+                ++taken;
+            } else {
+                gate_small[i] = g;   // not routed after all
+            }
+        }
+        *l_count = taken;
+    }
+}
+
+// results of the second launch group back to the reads they belong to
+__global__ void route_results_kernel(const uint32_t* l_result, const uint32_t* l_map, const uint32_t* l_count, uint32_t max_reads, uint32_t* result)
+{
+    const uint32_t j = threadIdx.x;
+    if (j < max_reads && j < *l_count) result[l_map[j]] = l_result[j];
+}
+
 __global__ void parse_sized_kernel(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
                                    const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
                                    uint32_t* gate)
@@ -125,8 +210,8 @@ __global__ void parse_sized_kernel(uint32_t n, const uint8_t* src, const uint64_
 __global__ __launch_bounds__(256) void copy_bytes_kernel(ReadBatch b, uint32_t hdr)
 {
     const uint32_t r = blockIdx.x;
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (threadIdx.x == 0) b.result[r] = b.gate[r];
+    if (b.gate && b.gate[r] >= GATE_SKIP) {
+        if (threadIdx.x == 0 && b.gate[r] != GATE_SKIP) b.result[r] = b.gate[r];
         return;
     }
     const uint32_t n = b.src_size[r];
@@ -210,6 +295,28 @@ hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes
                            uint32_t* gate_out, hipStream_t s)
 {
     hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, s, n, size, unit_bytes, gate, max_segs, seg_first, gate_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_route_reads(const ReadBatch& b, const uint32_t* raw_size, uint32_t min_bytes, uint32_t max_reads, uint64_t max_bytes, uint32_t* gate_small,
+                              uint64_t* l_src_off, uint32_t* l_src_size, uint64_t* l_dst_off, uint32_t* l_dst_cap, uint32_t* l_gate, uint32_t* l_map,
+                              uint32_t* l_count, uint32_t* cand, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    uint32_t* cand_count = cand + ROUTE_CAND_MAX;
+    hipError_t e = hipMemsetAsync(cand_count, 0, 4, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(route_flag_kernel, dim3((b.n_reads + 255) / 256), dim3(256), 0, s, b, raw_size, min_bytes, gate_small, cand, cand_count);
+    hipLaunchKernelGGL(route_pick_kernel, dim3(1), dim3(1024), 0, s, b, raw_size, max_reads, max_bytes, gate_small, cand, cand_count, l_src_off, l_src_size,
+                       l_dst_off, l_dst_cap, l_gate, l_map, l_count);
+    return hipGetLastError();
+}
+
+size_t route_cand_words() { return ROUTE_CAND_MAX + 4; }
+
+hipError_t launch_route_results(const uint32_t* l_result, const uint32_t* l_map, const uint32_t* l_count, uint32_t max_reads, uint32_t* result, hipStream_t s)
+{
+    hipLaunchKernelGGL(route_results_kernel, dim3(1), dim3(64), 0, s, l_result, l_map, l_count, max_reads, result);
     return hipGetLastError();
 }
 

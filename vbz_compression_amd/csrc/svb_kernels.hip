@@ -344,8 +344,8 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
     if (PROBE && tid == 0) period_hint[r] = 0;
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (tid == 0) b.result[r] = b.gate[r];
+    if (b.gate && b.gate[r] >= GATE_SKIP) {
+        if (tid == 0 && b.gate[r] != GATE_SKIP) b.result[r] = b.gate[r];
         return;
     }
     const uint32_t size = b.src_size[r];
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(WG) void svb_seg_encode_kernel(ReadBatch b, uint32_
     if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
     const int tid = threadIdx.x;
     if (COUNT_ONLY && tid == 0) seg_bytes[blockIdx.x] = 0;
-    if (b.gate && b.gate[r] >= E_FIRST) return;
+    if (b.gate && b.gate[r] >= GATE_SKIP) return;
     const uint32_t size = b.src_size[r];
     if (svb_encode_check<ELEM, I16ZZ>(size, b.dst_cap[r], hdr, strict_cap)) return;
     const uint32_t n = size / ELEM;
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(WG) void svb_seg_encode_scan_kernel(ReadBatch b, ui
         if (i < s1) seg_off[i] = carry + ex;
         carry += tot;
     }
-    if (tid == 0) {
+    if (tid == 0 && !(b.gate && b.gate[r] == GATE_SKIP)) {
         uint32_t res;
         if (b.gate && b.gate[r] >= E_FIRST) res = b.gate[r];
         else {
@@ -597,8 +597,8 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
 
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (tid == 0) b.result[r] = b.gate[r];
+    if (b.gate && b.gate[r] >= GATE_SKIP) {
+        if (tid == 0 && b.gate[r] != GATE_SKIP) b.result[r] = b.gate[r];
         return;
     }
     const uint32_t in_size = b.src_size[r];
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(WG) void svb_seg_decode_kernel(ReadBatch b, const u
     if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
     const int tid = threadIdx.x;
     if (MODE != 0 && tid == 0) seg_val[blockIdx.x] = 0;
-    if (b.gate && b.gate[r] >= E_FIRST) return;
+    if (b.gate && b.gate[r] >= GATE_SKIP) return;
     const uint32_t in_size = b.src_size[r];
     if (in_size >= E_FIRST) return;
     const uint32_t out_size = b.dst_cap[r];
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(WG) void svb_seg_decode_scan_kernel(ReadBatch b, co
         }
         carry += tot;
     }
-    if (VERDICT && tid == 0) {
+    if (VERDICT && tid == 0 && !(b.gate && b.gate[r] == GATE_SKIP)) {
         uint32_t res;
         if (b.gate && b.gate[r] >= E_FIRST) res = b.gate[r];
         else if (b.src_size[r] >= E_FIRST) res = b.src_size[r];
@@ -712,8 +712,8 @@ __global__ __launch_bounds__(WG) void svb_half_encode_kernel(ReadBatch b, uint32
 
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (tid == 0) b.result[r] = b.gate[r];
+    if (b.gate && b.gate[r] >= GATE_SKIP) {
+        if (tid == 0 && b.gate[r] != GATE_SKIP) b.result[r] = b.gate[r];
         return;
     }
     const uint32_t n = b.src_size[r];  // one byte per value
@@ -816,8 +816,8 @@ __global__ __launch_bounds__(WG) void svb_half_decode_kernel(ReadBatch b)
 
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (tid == 0) b.result[r] = b.gate[r];
+    if (b.gate && b.gate[r] >= GATE_SKIP) {
+        if (tid == 0 && b.gate[r] != GATE_SKIP) b.result[r] = b.gate[r];
         return;
     }
     const uint32_t in_size = b.src_size[r];

@@ -50,6 +50,11 @@ struct vbz_gpu_ctx
     std::string error;
     DevBuf scratch;   // intermediate svb streams of a batch
     DevBuf meta;      // per-read bookkeeping arrays
+    DevBuf gmeta;     // ... of one launch group of a decompress call
+    DevBuf route;     // per-read routing: the first group's gates, the second group's compact descriptors
+    int routing = 1;       // VBZ_HIP_ROUTING=0: by batch shape only (2: experiment, the second group is not launched)
+    vbz_gpu_ctx* large = nullptr;   // per-read routing: the second group's own stream and buffers (it runs beside the first group)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // single-buffer API staging
     DevBuf one_in, one_out, one_meta;
     DevBuf dbg;       // per-read phase timers (VBZ_HIP_PHASE_TIMING=1)
@@ -295,14 +300,10 @@ int plan_segments(vbz_gpu_ctx* c, uint32_t n, const uint32_t* raw_size, const ui
     return 0;
 }
 
-int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+ReadBatch to_rb(const vbz_gpu_batch* bt)
 {
-    const uint32_t n = bt->n_reads;
-    if (n == 0) return 0;
-    const uint32_t hdr = sized ? 4u : 0u;
-    hipStream_t s = c->stream;
     ReadBatch rb;
-    rb.n_reads = n;
+    rb.n_reads = bt->n_reads;
     rb.src = (const uint8_t*)bt->src;
     rb.src_off = bt->src_off;
     rb.src_size = bt->src_size;
@@ -311,14 +312,27 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     rb.dst_cap = bt->dst_cap;
     rb.result = bt->result;
     rb.gate = nullptr;
+    return rb;
+}
+
+// One launch group of a compress call: the reads of rb_in (those whose gate is closed left alone), on the one-workgroup path or
+// on the large-read path.  src_bytes: extent of the raw bytes of the group's reads.
+int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, const CompressionOptions* o, int sized, bool segmented)
+{
+    const uint32_t n = rb_in.n_reads;
+    if (n == 0) return 0;
+    const uint32_t hdr = sized ? 4u : 0u;
+    hipStream_t s = c->stream;
+    ReadBatch rb = rb_in;
+    struct { const uint32_t* src_size; uint64_t src_bytes; } view = { rb_in.src_size, src_bytes };
+    const auto* bt = &view;   // (the body below was written against the batch descriptor)
     if (o->integer_size == 0 && o->zstd_compression_level == 0) {  // vbz.cpp:130-133
         Timed t(c, "copy_bytes");
         HIPCHK(c, launch_copy_bytes(rb, hdr, s), "copy launch");
         return 0;
     }
-    const bool segmented = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n);
     SegTables seg;
-    if (segmented && plan_segments(c, n, bt->src_size, nullptr, bt->src_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
+    if (segmented && plan_segments(c, n, bt->src_size, rb_in.gate, bt->src_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
     if (segmented) rb.gate = seg.gate;   // (E_OOM for a read whose segments do not fit the tables)
     if (o->integer_size != 0 && o->zstd_compression_level == 0) {  // vbz.cpp:171-192: svb straight into dst
         Timed t(c, "svb_encode");
@@ -349,10 +363,10 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     uint32_t* svb_size = mc.take<uint32_t>(n);
     uint32_t* gate = mc.take<uint32_t>(n);
     uint32_t* deep_d = mc.take<uint32_t>(n);
-    if (segmented) HIPCHK(c, hipMemcpyAsync(gate, seg.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
+    if (rb.gate) HIPCHK(c, hipMemcpyAsync(gate, rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
     {
         Timed t(c, "plan_scratch");
-        HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, segmented, s), "plan launch");
+        HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, rb.gate != nullptr, s), "plan launch");
     }
     ReadBatch a = rb;
     a.dst = (uint8_t*)c->scratch.p;
@@ -408,49 +422,30 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     return 0;
 }
 
-int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+// One launch group of a decompress call: the reads of rb_in (dst_cap = the exact decoded byte counts; those whose gate is closed
+// left alone), on the one-workgroup path or on the large-read path.  dst_bytes: extent of the decoded bytes of the group.
+int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes, const CompressionOptions* o, bool segmented)
 {
-    const uint32_t n = bt->n_reads;
+    const uint32_t n = rb_in.n_reads;
     if (n == 0) return 0;
     hipStream_t s = c->stream;
-    if (!ensure(c, c->meta, (size_t)n * 64 + 512)) return -1;
-    MetaCarver mc(c->meta.p);
-    uint64_t* pay_off = mc.take<uint64_t>(n);
+    if (!ensure(c, c->gmeta, (size_t)n * 24 + 512)) return -1;
+    MetaCarver mc(c->gmeta.p);
     uint64_t* svb_off = mc.take<uint64_t>(n);
-    uint32_t* pay_size = mc.take<uint32_t>(n);
-    uint32_t* orig_size = mc.take<uint32_t>(n);
     uint32_t* gate = mc.take<uint32_t>(n);
     uint32_t* svb_cap = mc.take<uint32_t>(n);
     uint32_t* svb_size = mc.take<uint32_t>(n);
-    ReadBatch rb;
-    rb.n_reads = n;
-    rb.src = (const uint8_t*)bt->src;
-    rb.src_off = bt->src_off;
-    rb.src_size = bt->src_size;
-    rb.dst = (uint8_t*)bt->dst;
-    rb.dst_off = bt->dst_off;
-    rb.dst_cap = bt->dst_cap;
-    rb.result = bt->result;
-    rb.gate = nullptr;
-    if (sized) {  // vbz.cpp:332-366: strip the header, the original size becomes the exact destination size
-        Timed t(c, "parse_sized");
-        HIPCHK(c, launch_parse_sized(n, rb.src, bt->src_off, bt->src_size, bt->dst_cap, pay_off, pay_size, orig_size, gate, s),
-               "parse_sized launch");
-        rb.src_off = pay_off;
-        rb.src_size = pay_size;
-        rb.dst_cap = orig_size;
-        rb.gate = gate;
-    }
+    ReadBatch rb = rb_in;
     if (o->integer_size == 0 && o->zstd_compression_level == 0) {
         Timed t(c, "copy_bytes");
         HIPCHK(c, launch_copy_bytes(rb, 0, s), "copy launch");
         return 0;
     }
-    const bool segmented = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n);
     SegTables seg;
-    if (segmented && plan_segments(c, n, rb.dst_cap, rb.gate, bt->dst_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
-    if (segmented) {   // (E_OOM for a read whose segments do not fit the tables)
-        HIPCHK(c, hipMemcpyAsync(gate, seg.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
+    if (segmented && plan_segments(c, n, rb.dst_cap, rb.gate, dst_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
+    const bool gate_in = segmented || rb.gate != nullptr;
+    if (gate_in) {   // (the caller's gate; E_OOM for a read whose segments do not fit the tables)
+        HIPCHK(c, hipMemcpyAsync(gate, segmented ? seg.gate : rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
         rb.gate = gate;
     }
     if (o->zstd_compression_level == 0) {
@@ -471,11 +466,11 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     // then svb decode into dst (vbz.cpp:234-299)
     uint32_t num, den;
     svb_factor(o->integer_size, false, &num, &den);  // any code length may appear in a foreign stream
-    const size_t scratch_need = (size_t)(((unsigned __int128)bt->dst_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
+    const size_t scratch_need = (size_t)(((unsigned __int128)dst_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
     if (!ensure(c, c->scratch, scratch_need)) return -1;
     {
         Timed t(c, "plan_scratch");
-        HIPCHK(c, launch_plan_scratch(n, rb.dst_cap, num, den, c->scratch.cap, svb_off, svb_cap, gate, sized != 0 || segmented, s), "plan launch");
+        HIPCHK(c, launch_plan_scratch(n, rb.dst_cap, num, den, c->scratch.cap, svb_off, svb_cap, gate, gate_in, s), "plan launch");
     }
     ReadBatch z = rb;
     z.dst = (uint8_t*)c->scratch.p;
@@ -484,8 +479,9 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     z.result = svb_size;
     z.gate = gate;
     unsigned long long* dbg = segmented ? nullptr : dbg_begin(c, n);
-    // the hot path -- int16 zig-zag samples, one wavefront per frame: the wavefront decodes the svb stream it has just
-    // written while it is still in the caches, straight into the destination; there is no svb_decode launch
+    // the hot path -- int16 zig-zag samples, one wavefront per frame: optionally (VBZ_HIP_FUSE_SVB=1) the wavefront decodes the
+    // svb stream it has just written while it is still in the caches, straight into the destination, and there is no
+    // svb_decode launch (measured slower than the separate launch: profiles/r03_fused_svb_decode.md)
     if (!segmented && !dbg && c->fuse_svb && o->integer_size == 2 && o->perform_delta_zig_zag) {
         z.result = rb.result;
         Timed t(c, "zstd_decode");  // (zstd_decode_kernel<false, true>: the frame and its svb stream)
@@ -531,6 +527,133 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     return 0;
 }
 
+// ---- per-read routing ----------------------------------------------------------------------------------------------------
+// The one-workgroup / one-wavefront kernels fill the GPU with thousands of reads, but ONE very long read among them (ultra-long
+// nanopore reads exist: millions of samples) would run on one wavefront of 1024 for tens of milliseconds -- the reference
+// treats every buffer alike (vbz/vbz.cpp:116-208), a batch must too.  The host does not know the sizes (they live on the
+// device), so every call whose arena could hold a long read routes on the device: route_reads picks the reads of
+// ROUTE_MIN_BYTES and more (at most ROUTE_MAX_READS of them, ROUTE_MAX_BYTES in all: more than that and the batch shape rule
+// above has already sent the whole batch down the large-read path) into a compact second group that takes the large-read
+// path with small grids; in the first group their gate says GATE_SKIP.  Without long reads the second group's launches
+// find nothing to do (a few empty grids per call).
+constexpr uint32_t ROUTE_MIN_BYTES = (uint32_t)SEGMENTED_MIN_AVG, ROUTE_MAX_READS = 16;
+constexpr uint64_t ROUTE_MAX_BYTES = 64ull << 20;
+
+struct Routed
+{
+    uint32_t* gate_small = nullptr;   // [n]
+    ReadBatch large;                  // ROUTE_MAX_READS compact entries (gate: GATE_SKIP behind the routed ones)
+    uint32_t* large_orig = nullptr;   // compress: raw sizes of the routed reads (= large.src_size); decompress: unused
+    uint32_t* map = nullptr;          // [ROUTE_MAX_READS] index of each routed read in the batch
+    uint32_t* count = nullptr;        // [1]
+};
+
+bool routing_applies(const vbz_gpu_ctx* c, const CompressionOptions* o, uint64_t raw_arena_bytes, uint32_t n)
+{
+    return c->routing && c->segmented < 0 && n > 1 && o->integer_size != 0 && !half_codec(o) && raw_arena_bytes >= ROUTE_MIN_BYTES;
+}
+
+int route(vbz_gpu_ctx* c, const ReadBatch& rb, const uint32_t* raw_size, Routed* r)
+{
+    const uint32_t n = rb.n_reads;
+    if (!c->large) {   // the second group's context: its launches are small and run beside the first group's on a stream of their own
+        c->large = vbz_gpu_create(c->device, nullptr);
+        if (!c->large || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+            set_error(c, "could not create the context of the routed reads");
+            return -1;
+        }
+        c->large->routing = 0;
+    }
+    c->large->trailers = c->trailers;
+    c->large->zero_run_sequences = c->zero_run_sequences;
+    c->large->segmented = 1;
+    if (!ensure(c, c->route, (size_t)n * 4 + (size_t)ROUTE_MAX_READS * 48 + route_cand_words() * 4 + 512)) return -1;
+    MetaCarver mc(c->route.p);
+    r->gate_small = mc.take<uint32_t>(n);
+    uint64_t* l_src_off = mc.take<uint64_t>(ROUTE_MAX_READS);
+    uint64_t* l_dst_off = mc.take<uint64_t>(ROUTE_MAX_READS);
+    uint32_t* l_src_size = mc.take<uint32_t>(ROUTE_MAX_READS);
+    uint32_t* l_dst_cap = mc.take<uint32_t>(ROUTE_MAX_READS);
+    uint32_t* l_gate = mc.take<uint32_t>(ROUTE_MAX_READS);
+    uint32_t* l_result = mc.take<uint32_t>(ROUTE_MAX_READS);
+    r->map = mc.take<uint32_t>(ROUTE_MAX_READS);
+    r->count = mc.take<uint32_t>(4);
+    uint32_t* cand = mc.take<uint32_t>(route_cand_words());
+    r->large = rb;
+    r->large.n_reads = ROUTE_MAX_READS;
+    r->large.src_off = l_src_off;
+    r->large.src_size = l_src_size;
+    r->large.dst_off = l_dst_off;
+    r->large.dst_cap = l_dst_cap;
+    r->large.gate = l_gate;
+    r->large.result = l_result;
+    Timed t(c, "route");
+    HIPCHK(c, launch_route_reads(rb, raw_size, ROUTE_MIN_BYTES, ROUTE_MAX_READS, ROUTE_MAX_BYTES, r->gate_small, l_src_off, l_src_size, l_dst_off, l_dst_cap,
+                                 l_gate, r->map, r->count, cand, c->stream),
+           "route launch");
+    HIPCHK(c, hipEventRecord(c->ev_fork, c->stream), "event record");
+    HIPCHK(c, hipStreamWaitEvent(c->large->stream, c->ev_fork, 0), "stream wait");
+    return 0;
+}
+
+// the second group is done before anything enqueued behind the call runs
+int route_join(vbz_gpu_ctx* c, const Routed& r, uint32_t* result)
+{
+    HIPCHK(c, launch_route_results(r.large.result, r.map, r.count, ROUTE_MAX_READS, result, c->large->stream), "route results launch");
+    HIPCHK(c, hipEventRecord(c->ev_join, c->large->stream), "event record");
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0), "stream wait");
+    return 0;
+}
+
+int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+{
+    const uint32_t n = bt->n_reads;
+    if (n == 0) return 0;
+    ReadBatch rb = to_rb(bt);
+    const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n);
+    if (by_shape || !routing_applies(c, o, bt->src_bytes, n)) return compress_group(c, rb, bt->src_bytes, o, sized, by_shape);
+    Routed r;
+    if (route(c, rb, bt->src_size, &r) != 0) return -1;
+    ReadBatch small = rb;
+    small.gate = r.gate_small;
+    if (c->routing != 2 && compress_group(c->large, r.large, ROUTE_MAX_BYTES, o, sized, true) != 0) return -1;   // (first: its launches are short)
+    if (compress_group(c, small, bt->src_bytes, o, sized, false) != 0) return -1;
+    return route_join(c, r, bt->result);
+}
+
+int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+{
+    const uint32_t n = bt->n_reads;
+    if (n == 0) return 0;
+    hipStream_t s = c->stream;
+    ReadBatch rb = to_rb(bt);
+    if (sized) {  // vbz.cpp:332-366: strip the header, the original size becomes the exact destination size
+        if (!ensure(c, c->meta, (size_t)n * 24 + 512)) return -1;
+        MetaCarver mc(c->meta.p);
+        uint64_t* pay_off = mc.take<uint64_t>(n);
+        uint32_t* pay_size = mc.take<uint32_t>(n);
+        uint32_t* orig_size = mc.take<uint32_t>(n);
+        uint32_t* gate = mc.take<uint32_t>(n);
+        Timed t(c, "parse_sized");
+        HIPCHK(c, launch_parse_sized(n, rb.src, bt->src_off, bt->src_size, bt->dst_cap, pay_off, pay_size, orig_size, gate, s),
+               "parse_sized launch");
+        rb.src_off = pay_off;
+        rb.src_size = pay_size;
+        rb.dst_cap = orig_size;
+        rb.gate = gate;
+    }
+    const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n);
+    if (by_shape || !routing_applies(c, o, bt->dst_bytes, n)) return decompress_group(c, rb, bt->dst_bytes, o, by_shape);
+    Routed r;
+    if (route(c, rb, rb.dst_cap, &r) != 0) return -1;   // by the decoded size
+    ReadBatch small = rb;
+    small.gate = r.gate_small;
+    if (c->routing != 2 && decompress_group(c->large, r.large, ROUTE_MAX_BYTES, o, true) != 0) return -1;
+    if (decompress_group(c, small, bt->dst_bytes, o, false) != 0) return -1;
+    return route_join(c, r, bt->result);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -574,6 +697,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);
     if (const char* e = getenv("VBZ_HIP_FUSE_SVB")) c->fuse_svb = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e);
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
     {
@@ -618,8 +742,11 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp })
         if (b->p) (void)hipFree(b->p);
+    if (c->large) vbz_gpu_destroy(c->large);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -660,21 +787,6 @@ int vbz_gpu_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Comp
         return -2;
     }
     return decompress_batch_impl(c, bt, o, sized);
-}
-
-static ReadBatch to_rb(const vbz_gpu_batch* bt)
-{
-    ReadBatch rb;
-    rb.n_reads = bt->n_reads;
-    rb.src = (const uint8_t*)bt->src;
-    rb.src_off = bt->src_off;
-    rb.src_size = bt->src_size;
-    rb.dst = (uint8_t*)bt->dst;
-    rb.dst_off = bt->dst_off;
-    rb.dst_cap = bt->dst_cap;
-    rb.result = bt->result;
-    rb.gate = nullptr;
-    return rb;
 }
 
 int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int integer_size, int zigzag, int version)

@@ -17,11 +17,13 @@ constexpr uint32_t E_VERSION = 0xFFFFFFFAu;
 constexpr uint32_t E_OOM = 0xFFFFFFF9u;
 constexpr uint32_t E_DEVICE = 0xFFFFFFF8u;
 constexpr uint32_t E_FIRST = E_DEVICE;
+constexpr uint32_t GATE_SKIP = E_FIRST - 1u;   // gate value "not in this launch group"; gate >= GATE_SKIP: no work here
 constexpr int PHASE_SLOTS = 12;  // per-read cycle counters of the timed kernel builds (debug aid)
 
 // One batch of independent reads ("reads" in the reference's vocabulary: one HDF5 chunk each).
 // All pointers are device pointers.  `result[i]` receives the bytes produced or an error code.
-// If `gate` is non-null, reads whose gate[i] is an error code are skipped and the error is kept.
+// If `gate` is non-null, reads whose gate[i] is an error code are skipped and the error is kept; reads whose gate[i] is
+// GATE_SKIP belong to another launch group of the same call (per-read routing: vbz_api.hip): nothing of theirs is touched.
 struct ReadBatch
 {
     uint32_t n_reads;
@@ -115,6 +117,12 @@ hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mu
 // keep one segment and get gate_out[i] = E_OOM; gate_out[i] = gate[i] (or 0) otherwise.  gate_out may be gate.
 hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t max_segs, uint32_t* seg_first,
                            uint32_t* gate_out, hipStream_t s);
+// per-read routing: see route_reads_kernel (helpers.hip).  raw_size[i] = the read's raw (decoded) byte count.
+hipError_t launch_route_reads(const ReadBatch& b, const uint32_t* raw_size, uint32_t min_bytes, uint32_t max_reads, uint64_t max_bytes, uint32_t* gate_small,
+                              uint64_t* l_src_off, uint32_t* l_src_size, uint64_t* l_dst_off, uint32_t* l_dst_cap, uint32_t* l_gate, uint32_t* l_map,
+                              uint32_t* l_count, uint32_t* cand, hipStream_t s);   // cand: route_cand_words() words of scratch
+size_t route_cand_words();
+hipError_t launch_route_results(const uint32_t* l_result, const uint32_t* l_map, const uint32_t* l_count, uint32_t max_reads, uint32_t* result, hipStream_t s);
 // sized decode: read the 4-byte headers -> payload offsets/sizes, original sizes, gate errors
 hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
                               const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,

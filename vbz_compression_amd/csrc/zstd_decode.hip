@@ -1719,8 +1719,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const bool partial = dspans != nullptr && !(sp.flags & DSPAN_WHOLE);
     const uint32_t r = dspans ? sp.read : blockIdx.x;
     if (only && !only[r]) return;  // second launch of span mode: only the frames whose spans did not work out
-    if (b.gate && b.gate[r] >= E_FIRST) {
-        if (lane == 0) b.result[r] = b.gate[r];
+    if (b.gate && b.gate[r] >= GATE_SKIP) {
+        if (lane == 0 && b.gate[r] != GATE_SKIP) b.result[r] = b.gate[r];
         return;
     }
     const uint8_t* src = b.src + b.src_off[r];
@@ -2620,7 +2620,7 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
         q_ok[tid] = 0;
         if (i < b.n_reads) {
             const uint32_t n = b.src_size[i];
-            const bool gated = (b.gate && b.gate[i] >= E_FIRST) || n >= E_FIRST;
+            const bool gated = (b.gate && b.gate[i] >= GATE_SKIP) || n >= E_FIRST;
             if (!gated && n >= 64) {
                 const uint8_t* src = b.src + b.src_off[i];
                 uint32_t magic, hl = 0;

@@ -1188,8 +1188,8 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     const uint32_t r = span_mode ? sp.read : blockIdx.x;
     // the bytes produced (or an error code): the read's result, or the span's size
 #define FINISH(v) do { if (lane == 0) { if (span_mode) span_size[blockIdx.x] = (v); else b.result[r] = (v); } } while (0)
-    if (!span_mode && b.gate && b.gate[r] >= E_FIRST) {
-        FINISH(b.gate[r]);
+    if (!span_mode && b.gate && b.gate[r] >= GATE_SKIP) {
+        if (b.gate[r] != GATE_SKIP) FINISH(b.gate[r]);
         return;
     }
     const uint32_t N = b.src_size[r];
@@ -1753,7 +1753,7 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
         bool skip = false;
         if (i < n) {
             N = svb_size[i];
-            skip = (gate && gate[i] >= E_FIRST) || N >= E_FIRST;
+            skip = (gate && gate[i] >= GATE_SKIP) || N >= E_FIRST;
             if (skip) {
                 cnt = 1;
             } else {
@@ -1863,7 +1863,7 @@ __global__ __launch_bounds__(256) void zstd_span_finish_kernel(ReadBatch b, uint
         return;
     }
     if (spans[s0].flags & SPAN_SKIP) {
-        if (tid == 0) {
+        if (tid == 0 && !(b.gate && b.gate[r] == GATE_SKIP)) {
             const uint32_t N = b.src_size[r];
             b.result[r] = (b.gate && b.gate[r] >= E_FIRST) ? b.gate[r] : (N >= E_FIRST ? N : E_OOM);
         }
