@@ -237,6 +237,37 @@ def committed_traffic(kernels):
     return {}, None, None
 
 
+def committed_traffic_large(direction, nbuf):
+    """HBM bytes per step of one direction of `--workload config4` from profiles/*_config4_hbm_traffic.csv (the profiled run
+    had `buffers_per_step` buffers: traffic is proportional to the bytes coded, so it is scaled to this run's).  A kernel
+    belongs to the encode direction if its name says encode or span_ (span_plan / span_finish / span_compact), to the decode
+    direction if it says decode or dspan; launches per step = its launches / the launches of the once-per-step plan kernel."""
+    import csv
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_config4_hbm_traffic.csv")))
+    if not files:
+        return None, None
+    path = files[-1]
+    rows = list(csv.DictReader(open(path)))
+    enc = lambda k: "encode" in k or "zstd_span_" in k   # noqa: E731
+    dec = lambda k: "decode" in k or "dspan" in k        # noqa: E731
+    steps = 0
+    for r in rows:
+        if r["kernel"].startswith("zstd_span_plan_kernel" if direction == "encode" else "zstd_dspan_plan_kernel"):
+            steps = int(r["launches"])
+    if not steps:
+        return None, None
+    total = sum(float(r["hbm_MB_per_launch"]) * int(r["launches"]) for r in rows if (enc if direction == "encode" else dec)(r["kernel"]))
+    prof_buffers = 8
+    try:
+        with open(path.replace("_hbm_traffic.csv", "_bench.json")) as f:
+            prof_buffers = int(json.load(f)["config"]["buffers_per_step"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return int(total * 1e6 / steps * nbuf / prof_buffers), os.path.basename(path)
+
+
 def max_compressed_sizes(sizes, level):
     """vbz_max_compressed_size (include/vbz.h; reference vbz/vbz.cpp:79-114) for int16 reads, vectorised over a tensor
     of byte sizes: svb bound (n+3)/4 + 4n, ZSTD_COMPRESSBOUND when a level is set, +4."""
@@ -671,6 +702,11 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier):
     dom = max((k for k in per_launch if k not in ("plan_scratch", "seg_plan")), key=lambda k: prof[k][1])
     dom_dir = "encode" if "encode" in dom else "decode"
     t_dom = t_enc if dom_dir == "encode" else t_dec
+    # HBM traffic of the dominant direction per step, from the newest committed PMC summary of this workload
+    # (profiles/*_config4_hbm_traffic.csv: per-kernel bytes per launch x launches per step)
+    traffic = traffic_src = None
+    if kind == "u32":
+        traffic, traffic_src = committed_traffic_large(dom_dir, nbuf)
     out = {
         "metric": METRIC if kind != "u32" else "MB/s encode+decode, uint32 buffers (BASELINE configs[3]: UD=32020,5,0,0,4,0,3), 1 MI355X vs CPU; ratio preserved",
         "value": round(total_raw / elapsed / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -685,7 +721,7 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier):
         "encode_ms": round(enc_ms / args.steps, 4), "decode_ms": round(dec_ms / args.steps, 4),
         "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
         "roofline": {"bound": "hbm", "kernel": dom, "direction": dom_dir, "achieved": round(alg_dir / t_dom / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": round(alg_dir / t_dom / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,
+                     "frac": round(alg_dir / t_dom / 1e9 / PEAK_HBM_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(alg_dir), "algorithmic_bytes_per_value": round(elem + c, 4), "avg_launch_ms": round(t_dom * 1e3, 4),
                      "definition": "SURVEY 8d: (integer size + c) bytes per value per direction over the duration of the direction's launch "
                                    "sequence (HIP events on the codec's stream around every call); a batch of few buffers is bound by the latency "

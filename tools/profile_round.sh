@@ -19,5 +19,14 @@ rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/write" -- python3 bench.py --no-cpu -
 # SQ counters (instruction mix, stalls, LDS conflicts), two more separate passes
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -f csv -d "$out/sq1" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/sq1.log" 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC -f csv -d "$out/sq2" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/sq2.log" 2>&1
-ls -R "$out" | head -40
+# the large-read path (BASELINE configs[3]: uint32 buffers of 10 M elements): bench lines, kernel stats, traffic, SQ counters
+python3 bench.py --workload config4 --no-cpu > "$out/bench_config4.json" 2> "$out/bench_config4.err"
+python3 bench.py --workload config4 --buffers 1 --no-cpu > "$out/bench_config4_one_buffer.json" 2>> "$out/bench_config4.err"
+python3 bench.py --workload config1 --no-cpu > "$out/bench_config1.json" 2>> "$out/bench_config4.err"
+rocprofv3 --kernel-trace --stats -f csv -d "$out/c4kt" -- python3 bench.py --workload config4 --no-cpu --steps 10 --warmup 2 > "$out/c4kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/c4fetch" -- python3 bench.py --workload config4 --no-cpu --steps 3 --warmup 1 > "$out/c4fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/c4write" -- python3 bench.py --workload config4 --no-cpu --steps 3 --warmup 1 > "$out/c4write.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -f csv -d "$out/c4sq1" -- python3 bench.py --workload config4 --no-cpu --steps 3 --warmup 1 > "$out/c4sq1.log" 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC -f csv -d "$out/c4sq2" -- python3 bench.py --workload config4 --no-cpu --steps 3 --warmup 1 > "$out/c4sq2.log" 2>&1
+ls -R "$out" | head -60
 cat "$out/bench.json"

@@ -42,7 +42,7 @@ def main():
             w = csv.writer(f)
             w.writerow(["kernel", "launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "read_MB_corrected(2x)", "write_MB", "hbm_MB_per_launch"])
             for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"][1] + kv[1]["WRITE_SIZE"][1])):
-                if "svb_" not in k and "zstd_" not in k and "elementwise" not in k:
+                if "svb_" not in k and "zstd_" not in k and "elementwise" not in k and "seg_plan" not in k and "plan_scratch" not in k:
                     continue
                 fn, fs = v["FETCH_SIZE"]
                 wn, ws = v["WRITE_SIZE"]
