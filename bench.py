@@ -223,8 +223,10 @@ def committed_traffic(kernels):
     for path in reversed(files):
         found = {}
         for r in csv.DictReader(open(path)):
+            if "second launch group" in r["kernel"]:   # (per-read routing's small-grid launches: tools/summarize_profile.py)
+                continue
             for k in kernels:
-                if r["kernel"].startswith(k + "_kernel"):
+                if r["kernel"].startswith(k + "_kernel") and k not in found:
                     found[k] = int(float(r["hbm_MB_per_launch"]) * 1e6)
         if found:
             reads = 8192

@@ -19,23 +19,64 @@ def short(name):
     return n[:90]
 
 
+SIDE = " [second launch group of per-read routing: small grids]"
+
+
+class GridClasses:
+    """Per-read routing (vbz_api.hip) launches the large-read kernels a second time per call with small grids -- for the long
+    reads of the batch, usually none.  Those launches bear the names of the main ones (same templates); averaged in, they
+    would halve every per-launch figure.  A launch whose grid is below half of the kernel's largest is reported on a
+    line of its own."""
+
+    def __init__(self):
+        self.max_grid = collections.defaultdict(int)
+
+    def see(self, name, grid):
+        self.max_grid[name] = max(self.max_grid[name], grid)
+
+    def key(self, name, grid):
+        return short(name) + (SIDE if "vbzhip" in name and 2 * grid < self.max_grid[name] else "")
+
+
 def main():
     tag, stats = sys.argv[1], sys.argv[2]
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
     os.makedirs(out, exist_ok=True)
-    rows = list(csv.DictReader(open(stats)))
-    rows.sort(key=lambda r: (0 if "vbzhip" in r["Name"] else 1, -float(r["TotalDurationNs"])))
-    with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
-        for r in rows[:16]:
-            w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.4f" % (float(r["AverageNs"]) / 1e6),
-                        r["Percentage"], "%.4f" % (float(r["MinNs"]) / 1e6), "%.4f" % (float(r["MaxNs"]) / 1e6)])
+    trace = stats.replace("kernel_stats.csv", "kernel_trace.csv")
+    if os.path.exists(trace):   # per-launch records: the same figures as rocprofv3's --stats summary, main and side launches apart
+        launches = list(csv.DictReader(open(trace)))
+        gc = GridClasses()
+        for r in launches:
+            gc.see(r["Kernel_Name"], int(r["Grid_Size_X"]))
+        agg = collections.defaultdict(list)
+        for r in launches:
+            agg[gc.key(r["Kernel_Name"], int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        total_all = sum(sum(v) for v in agg.values())
+        rows = sorted(agg.items(), key=lambda kv: -sum(kv[1]))
+        with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
+            for k, v in rows[:24]:
+                w.writerow([k, len(v), "%.3f" % (sum(v) / 1e6), "%.4f" % (sum(v) / len(v) / 1e6), "%.2f" % (100.0 * sum(v) / total_all),
+                            "%.4f" % (min(v) / 1e6), "%.4f" % (max(v) / 1e6)])
+    else:
+        rows = list(csv.DictReader(open(stats)))
+        rows.sort(key=lambda r: (0 if "vbzhip" in r["Name"] else 1, -float(r["TotalDurationNs"])))
+        with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ms", "avg_ms", "percent", "min_ms", "max_ms"])
+            for r in rows[:16]:
+                w.writerow([short(r["Name"]), r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.4f" % (float(r["AverageNs"]) / 1e6),
+                            r["Percentage"], "%.4f" % (float(r["MinNs"]) / 1e6), "%.4f" % (float(r["MaxNs"]) / 1e6)])
     if len(sys.argv) >= 5:
         agg = collections.defaultdict(lambda: {"FETCH_SIZE": [0, 0.0], "WRITE_SIZE": [0, 0.0]})
         for path in sys.argv[3:5]:
-            for r in csv.DictReader(open(path)):
-                a = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
+            recs = list(csv.DictReader(open(path)))
+            gc = GridClasses()
+            for r in recs:
+                gc.see(r["Kernel_Name"], int(r["Grid_Size"]))
+            for r in recs:
+                a = agg[gc.key(r["Kernel_Name"], int(r["Grid_Size"]))][r["Counter_Name"]]
                 a[0] += 1
                 a[1] += float(r["Counter_Value"])
         with open(os.path.join(out, tag + "_hbm_traffic.csv"), "w", newline="") as f:
@@ -55,8 +96,12 @@ def main():
         agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
         names = []
         for path in sys.argv[5:]:
-            for r in csv.DictReader(open(path)):
-                k = short(r["Kernel_Name"])
+            recs = list(csv.DictReader(open(path)))
+            gc = GridClasses()
+            for r in recs:
+                gc.see(r["Kernel_Name"], int(r["Grid_Size"]))
+            for r in recs:
+                k = gc.key(r["Kernel_Name"], int(r["Grid_Size"]))
                 if "svb_" not in k and "zstd_" not in k and "vbz_" not in k:
                     continue
                 a = agg[k][r["Counter_Name"]]
