@@ -4,7 +4,8 @@
     python tools/soak.py [--seconds 120] [--seed 1]
 
 Every round draws a batch of reads of random lengths and shapes (nanopore-like signal, noise, constants, ramps,
-extreme values, sparse spikes, repeated templates; every fourth round few large reads, which take the large-read path)
+extreme values, sparse spikes, repeated templates; every fifth round few large reads, which take the large-read path, every
+fifth many short reads with a few long ones among them, which per-read routing splits into two launch groups)
 and a random option set (levels 0, 1, 3, 4), then checks, read by read:
   * GPU compress -> oracle (reference path + libzstd) decompress == input
   * oracle compress -> GPU decompress == input
@@ -71,9 +72,14 @@ def main():
         level = int(rng.choice([0, 1, 1, 3, 4, 4]))
         ver = int(rng.integers(0, 2))
         sized = bool(rng.integers(0, 2))
-        if rng.random() < 0.25:  # few, large reads: the large-read path (segments and spans)
+        shape = rng.random()
+        if shape < 0.2:  # few, large reads: the large-read path (segments and spans)
             lens = [int(x) for x in rng.integers(300000, 1500000, int(rng.integers(1, 4)))]
             lens += [int(x) for x in rng.choice([0, 5, 4097, 700001, 1048576], 2)]
+        elif shape < 0.4:  # many short reads and a few long ones among them: per-read routing (two launch groups)
+            lens = [int(x) for x in rng.integers(0, 60000, 40)]
+            for _ in range(int(rng.integers(1, 4))):
+                lens.insert(int(rng.integers(0, len(lens) + 1)), int(rng.integers(600000 // size, 2500000 // size)))
         else:
             lens = [int(x) for x in rng.choice([0, 1, 2, 3, 5, 63, 64, 65, 255, 257, 1000, 4095, 4097, 20000, 100003, 300001], 24)]
             lens += [int(x) for x in rng.integers(0, 150000, 8)]
