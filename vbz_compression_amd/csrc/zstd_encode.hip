@@ -47,7 +47,10 @@ constexpr int MAXBLK = 16;                // blocks handled per pass (x4 streams
 // wavefront encodes -- its own histogram, its own Huffman table (first block with the tree, the others treeless) -- into a
 // temporary slot; a compaction pass then strings the spans of a frame together.  16 KB blocks keep the decoder's streams
 // short (4 KB of content per lane) at 0.1 % of header overhead.
-constexpr uint32_t SPAN_BLOCK = 16u << 10;
+#ifndef VBZ_SPAN_BLOCK_KB
+#define VBZ_SPAN_BLOCK_KB 16
+#endif
+constexpr uint32_t SPAN_BLOCK = VBZ_SPAN_BLOCK_KB << 10;
 // blocks per span: 4 (64 KB of stream per wavefront: a 40 MB buffer is 300 spans, one 400 k-sample read 8) up to 256 MB of
 // stream, 16 beyond (the decoder then has all 64 lanes of a wavefront busy).  A span costs its tree description, ~0.15 %.
 #ifndef VBZ_SPAN_SMALL_BLOCKS
