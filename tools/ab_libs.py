@@ -5,7 +5,9 @@ a call is the fastest).  Per-kernel average durations from each library's own HI
 
     python tools/ab_libs.py xlibs/base.so xlibs/new.so [--reads 65536] [--rounds 12]
 
-Each library encodes and decodes its own frames (a build may write trailers the other does not read)."""
+Each library encodes and decodes its own frames (a build may write trailers the other does not read).  The context that is
+created SECOND runs its memory-bound kernels up to 5 % slower whatever its code (where its scratch arena lands in HBM): run
+both orders (`a b` and `b a`) and compare like positions."""
 import argparse
 import ctypes
 import os
