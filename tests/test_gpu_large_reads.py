@@ -375,3 +375,46 @@ def test_long_reads_among_many_short_ones_are_routed():
     raw_ratio = float(B["size"].to(torch.int64).sum()) / float(A["size"].to(torch.int64).sum())
     print("4096 short reads: %.2f ms; with three 5 M-sample reads (%.3f x the bytes): %.2f ms = %.2f x" % (tA * 1e3, raw_ratio, tB * 1e3, tB / tA))
     assert tB < 1.3 * tA, (tA, tB)
+
+
+def test_aliased_sources_beyond_the_scratch_arena():
+    """The same contract on the one-workgroup-per-read path: 3000 descriptors over ONE 180 KB source.  The library sizes its
+    scratch arena by src_bytes, so with the entropy stage on only the first few reads get a slot; the slot plan runs on several workgroups (one per 1024
+    reads, each adding up the slots in front of its own while the others write their verdicts) and must give every read
+    the same verdict on every run: coded right, or refused with OUT_OF_MEMORY -- the first read always fits."""
+    dev = torch.device("cuda", 0)
+    a = O.synth_signal(5, 12, 90_000)
+    raw = torch.from_numpy(np.frombuffer(a.tobytes(), np.uint8).copy()).to(dev)
+    n = 3000
+    for level in (0, 1):
+        go, oo = _lib.CompressionOptions(True, 2, level, 1), O.options(True, 2, level, 1)
+        cap = _lib.load().vbz_max_compressed_size(a.nbytes, ctypes.byref(go))
+        doff, dtotal = batch.layout([cap + 32] * n, 64)
+        runs = []
+        for attempt in range(2):
+            c = batch.GpuCodec(0)   # a fresh context: its scratch arena is as small as this batch asks for
+            with torch.cuda.stream(c.stream):
+                src = torch.zeros(raw.numel() + 64, dtype=torch.uint8, device=dev)
+                src[: raw.numel()] = raw
+                dst = torch.zeros(dtotal + 64, dtype=torch.uint8, device=dev)
+                res = torch.full((n,), -8, dtype=torch.int32, device=dev)
+                c.compress(src[: raw.numel()], torch.zeros(n, dtype=torch.int64, device=dev), torch.full((n,), a.nbytes, dtype=torch.int32, device=dev),
+                           dst, doff.to(dev), torch.full((n,), cap, dtype=torch.int32, device=dev), res, go)
+            c.synchronize()
+            r = [int(x) & 0xFFFFFFFF for x in res.cpu().tolist()]
+            host = dst.cpu().numpy()
+            good = [i for i in range(n) if r[i] != 0xFFFFFFF9]
+            # (without the entropy stage the svb stream goes straight to the destination: no scratch, every read fits)
+            assert good and good[0] == 0 and (len(good) < n if level else len(good) == n), (len(good), hex(r[0]))
+            assert good == list(range(len(good))), "the reads that fit are the first ones"
+            want = O.compress(a, oo) if level == 0 else None
+            for i in good:
+                assert r[i] < 0xFFFFFFF0, hex(r[i])
+                f = host[int(doff[i]) : int(doff[i]) + r[i]]
+                if want is not None:
+                    assert f.tobytes() == want.tobytes()
+                else:
+                    assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes(), (level, i)
+            runs.append(r)
+            c.close() if hasattr(c, "close") else None
+        assert runs[0] == runs[1], "the slot plan gave different verdicts on two runs"
