@@ -692,7 +692,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int RING = VBZ_DEC_RING;      // dwords per lane in the LDS ring (32 or 16)
 constexpr int BATCH = RING / 2;         // dwords fetched per top-up
 constexpr int PERIOD = RING;            // symbols between two top-up points (a period eats <= 11*PERIOD/32 dwords)
-constexpr int BURST = 2;                // periods whose symbols a lane stores together
+#ifndef VBZ_DEC_BURST
+#define VBZ_DEC_BURST 2
+#endif
+constexpr int BURST = VBZ_DEC_BURST;    // periods whose symbols a lane stores together
 
 // next BATCH dwords below `nextbyte`, in consumption order (w[0] holds the highest bytes)
 __device__ __forceinline__ void fetch_batch(gcu8* p, uint32_t& nextbyte, uint32_t (&w)[BATCH])
