@@ -1158,3 +1158,35 @@ def test_bench_line_contract():
     assert d["stages"]["svb_only"]["encode_MBps"] > d["encode_MBps"] and 1.2 < d["stages"]["svb_only"]["svb_bytes_per_sample"] < 1.3
     assert d["host_resident"]["round_trip_ok"] and 0 < d["host_resident"]["encode_decode_MBps"] < d["value"]
     assert d["config"]["distinct_reads"] >= 512
+
+
+def test_many_tiny_reads_in_one_batch():
+    """150 000 reads of 0 ... 300 samples in ONE call (more workgroups than a 16-bit grid index holds, 147 workgroups of the
+    slot plan): every read round-trips on the device, a sample of 600 of them is byte-checked against the oracle in both
+    directions (level 0: identical bytes; level 1: each side decodes the other's frames)."""
+    import gpu_util as G
+    from vbz_compression_amd import _lib
+
+    rng = np.random.default_rng(150)
+    n = 150_000
+    base = [O.synth_signal(5, i, int(k)) for i, k in enumerate(rng.integers(0, 301, 512))]
+    base[0] = np.zeros(0, np.int16)
+    reads = [base[int(j)] for j in rng.integers(0, len(base), n)]
+    pick = rng.choice(n, 600, replace=False)
+    for level in (0, 1):
+        go, oo = _lib.CompressionOptions(True, 2, level, 1), O.options(True, 2, level, 1)
+        comp = G.compress(reads, go)
+        assert all(not isinstance(f, int) for f in comp), "a read was refused"
+        back = G.decompress(comp, [a.nbytes for a in reads], go)
+        for a, b in zip(reads, back):
+            assert not isinstance(b, int) and b.tobytes() == a.tobytes()
+        for i in pick:
+            a = reads[int(i)]
+            want = O.compress(a, oo)
+            if level == 0:
+                assert comp[int(i)].tobytes() == want.tobytes()
+            else:
+                assert O.decompress(comp[int(i)], a.nbytes, oo).tobytes() == a.tobytes()
+        mine = G.decompress([O.compress(reads[int(i)], oo) for i in pick], [reads[int(i)].nbytes for i in pick], go)
+        for i, b in zip(pick, mine):
+            assert not isinstance(b, int) and b.tobytes() == reads[int(i)].tobytes()
