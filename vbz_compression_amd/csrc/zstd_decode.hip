@@ -145,11 +145,16 @@ __device__ __forceinline__ uint32_t lane_get(uint32_t v, uint32_t l) { return (u
 __device__ __forceinline__ uint32_t lane_put(uint32_t reg, uint32_t l, uint32_t v, int lane) { return (uint32_t)lane == l ? v : reg; }
 // the same with wave-uniform l and v in scalar registers: one v_writelane_b32 (the lane select goes through m0: a VOP3
 // instruction of gfx9 reads one scalar register)
+// (this compiler has no __builtin_amdgcn_writelane; m0 is named as clobbered so that nothing the compiler keeps there --
+// it keeps nothing there in this file: no LDS-DMA, no movrel -- is expected to survive, which clang remarks on)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ uint32_t lane_write(uint32_t reg, uint32_t l, uint32_t v)
 {
     asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(v), "s"(l) : "m0");
     return reg;
 }
+#pragma clang diagnostic pop
 
 // FSE table description (RFC 8878 4.1.1) read from LDS bytes; lane 0 only.
 // returns bytes consumed or -1; fills L.u.p.norm[0..nsym)
