@@ -15,15 +15,16 @@
  * in batch->result in stream order.
  *
  * How a batch is laid onto the device is the library's business and never changes a result, only speed:
- *   - the shape rule: a batch whose average read is half a megabyte or more (one HDF5 chunk, a 10 M-element
- *     buffer) runs on the large-read path, many workgroups per read;
+ *   - the shape rule: a batch whose average read is half a megabyte or more (a 10 M-element buffer), or which is too
+ *     small to fill the device with one wavefront per read (up to 96 MB of reads of 64 KB and more: one HDF5 chunk per
+ *     call), runs on the large-read path, many workgroups per read;
  *   - per-read routing: in any other batch the reads of 512 KB and more (at most 16 of them, 64 MB in all;
  *     the largest first) are coded on that path beside the rest of the batch, on a second stream of the
  *     context that is forked from and joined to the context's stream inside the call -- to the caller the
  *     call is still one unit of work in stream order;
  *   - a read whose bytes repeat at one distance (a cycled template) gets that distance coded as zstd matches
  *     at every zstd_compression_level (the reference passes its level to libzstd, whose matcher is on at all
- *     of them); reads on the large-read path do not.
+ *     of them); reads of half a megabyte and more do not.
  * Descriptor tables are untrusted like the data: sizes and offsets that do not fit the declared arenas
  * (src_bytes / dst_bytes) give the read VBZ_INPUT_SIZE_ERROR or VBZ_DESTINATION_SIZE_ERROR, never an
  * access outside the arenas.

@@ -161,6 +161,19 @@ def test_whole_suite_on_the_large_read_path():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+def test_whole_suite_on_the_one_wavefront_path():
+    """The other way round: small batches -- most of what the other tests send -- take the large-read path by default (a call
+    with a handful of reads cannot fill the device with one wavefront per read), so the kernels of the headline workload, one
+    workgroup / one wavefront per read, get the same suites with VBZ_HIP_SEGMENTED=0."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBZ_HIP_SEGMENTED="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"),
+                        os.path.join(root, "tests", "test_gpu_fuzz_corpus.py"), os.path.join(root, "tests", "test_gpu_repeats.py"), "-k",
+                        "not bench_line and not fast5 and not h5repack and not hdf5 and not cpp_caller and not many_threads"],
+                       capture_output=True, text=True, timeout=3000, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_trailers_are_an_option_of_the_context():
     """vbz_gpu_set_trailers(ctx, 0): every compressed buffer is ONE plain zstd frame (nothing behind it), with the same
     blocks -- run sequences included -- as with the trailers; both decode on the device and through libzstd."""

@@ -262,11 +262,17 @@ struct MetaCarver
 // per call) takes the segmented kernels instead: every read is spread over many workgroups.  The rule looks at the batch
 // shape only (the sizes themselves live on the device): average read of half a megabyte or more.
 constexpr uint64_t SEGMENTED_MIN_AVG = 512u << 10;
+// ... and batches too small to fill the device with one wavefront per read: a call with one read of 100 k samples (the
+// single-buffer API, the HDF5 filter) takes 0.39 / 0.25 ms on one wavefront and 0.16 / 0.16 ms as spans (tools/time_one_read.py),
+// whatever the read's length; the one-wavefront kernels win from a few thousand reads per call on, or when the reads are
+// so short that a read is hardly more than one span.
+constexpr uint64_t SMALL_BATCH_MIN_AVG = 64u << 10, SMALL_BATCH_MAX_BYTES = 96u << 20;
 
 bool use_segments(const vbz_gpu_ctx* c, uint64_t raw_arena_bytes, uint32_t n)
 {
     if (c->segmented >= 0) return c->segmented != 0;
-    return raw_arena_bytes / n >= SEGMENTED_MIN_AVG;
+    const uint64_t avg = raw_arena_bytes / n;
+    return avg >= SEGMENTED_MIN_AVG || (avg >= SMALL_BATCH_MIN_AVG && raw_arena_bytes <= SMALL_BATCH_MAX_BYTES);
 }
 
 struct SegTables
@@ -404,6 +410,17 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         uint32_t* span_trail = sm.take<uint32_t>(max_spans);
         uint32_t* span_dst = sm.take<uint32_t>(max_spans);
         z.gate = gate;
+        if (c->zero_run_sequences && c->long_repeats && o->integer_size != 0 && src_bytes / n < SEGMENTED_MIN_AVG) {
+            // a batch that is here because it is small, not because its reads are large: reads that repeat at one distance go
+            // to the one-wavefront matcher after all (reads below the routing threshold: the same reads that get the matcher
+            // in a batch of thousands)
+            uint32_t* gate2 = mc.take<uint32_t>(n);
+            Timed t(c, "zstd_encode_matcher");
+            HIPCHK(c, launch_zstd_encode_matcher(z, bt->src_size, o->integer_size, hdr, svb_cap, c->seqtab.p, c->trailers, (uint32_t)SEGMENTED_MIN_AVG,
+                                                 deep_d, gate, gate2, s),
+                   "zstd_encode (matcher) launch");
+            z.gate = gate2;
+        }
         Timed t(c, "zstd_encode");
         HIPCHK(c, launch_zstd_encode_spans(z, bt->src_size, o->integer_size, hdr, c->zero_run_sequences ? svb_cap : nullptr,
                                            c->zero_run_sequences ? c->seqtab.p : nullptr, desc, span_first, span_count, max_spans,

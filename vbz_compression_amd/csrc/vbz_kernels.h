@@ -84,6 +84,13 @@ hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_siz
                                     const void* seq_tables, void* span_desc, uint32_t* span_first, uint32_t* span_count, uint32_t max_spans,
                                     uint8_t* span_tmp, uint64_t span_tmp_bytes, uint32_t* span_size, uint32_t* span_trail, uint32_t* span_dst,
                                     bool trailers, hipStream_t s);  // trailers: checkpoints and span index behind the frame
+// The long-repeat matcher in front of the span launches (batches too small to fill the device run as spans): a probe over
+// every read below max_raw bytes, the check of launch_zstd_encode's first launch, and its matcher instantiation for the reads
+// whose distance holds.  deep_d[n_reads] is scratch; gate_out[i] = GATE_SKIP for the reads coded here (the spans skip them),
+// gate_in[i] otherwise.  b: as for launch_zstd_encode (source streams in library-owned slots of src_cap[i] bytes).
+hipError_t launch_zstd_encode_matcher(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
+                                      const void* seq_tables, bool trailers, uint32_t max_raw, uint32_t* deep_d, const uint32_t* gate_in,
+                                      uint32_t* gate_out, hipStream_t s);
 // decode: result[i] = frame content size, E_ZSTD for a malformed frame, or `toosmall_code` when the
 // frame's content size exceeds dst_cap[i].
 // seq_dtables (device, from seq_dtables_build): decoding tables of the predefined LL / ML distributions.

@@ -1947,6 +1947,114 @@ __global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, con
     }
 }
 
+// ---- the long-repeat matcher for batches on the large-read path ------------------------------------------------------------------
+// A batch too small to fill the device runs as spans (vbz_api.hip, use_segments), where no wavefront sees a whole read.  The
+// reads of such a batch that repeat at ONE distance -- template-cycling signal, which libzstd codes 10 x smaller at any level --
+// are found here and coded by the one-wavefront matcher instantiation after all; the spans skip them (gate_out).
+//   period_probe_kernel: svb_kernels.hip's probe as a pass of its own over the read's data bytes (one workgroup per read; the
+//     segmented svb kernels have no workgroup that sees the head of the data bytes and the rest): sixteen probe dwords at data
+//     bytes p0 .. p0 + 15 in a hash table, the first dword of every 16-byte chunk looked up, a hit verified on 16 bytes, the
+//     smallest distance proposed in deep_d[r] (0: none).
+//   deep_check_kernel: the check zstd_encode_kernel<.., false> makes at its top (period_holds, deep_layout); deep_d[r] = the
+//     distance or 0, gate_out[r] = GATE_SKIP for the reads the matcher takes.
+constexpr uint32_t PP_TABLE = 512, PP_P0 = 256, PP_TRIES = 4, PP_SHIFT = 80;
+__device__ __forceinline__ uint32_t pp_hash(uint32_t w) { return (w * 0x9E3779B1u) >> 23; }
+
+__device__ __forceinline__ uint32_t matcher_region(const ReadBatch& b, uint32_t r, const uint32_t* orig_size, uint32_t key_elem, uint32_t max_raw,
+                                                   const uint32_t* gate, uint32_t& N)
+{
+    N = 0;
+    if (gate && gate[r] >= GATE_SKIP) return 0;
+    N = b.src_size[r];
+    if (N >= E_FIRST || N < SPLIT_MIN || !key_elem || orig_size[r] >= max_raw) return 0;
+    const uint32_t K = (orig_size[r] / key_elem + 3u) >> 2;
+    return (K >= N || N - K < 8192u) ? 0u : K;
+}
+
+__global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, uint32_t max_raw,
+                                                           const uint32_t* gate, uint32_t* deep_d)
+{
+    __shared__ uint32_t val[PP_TABLE];
+    __shared__ uint8_t idx[PP_TABLE];
+    __shared__ uint32_t best, lost;
+    const uint32_t r = blockIdx.x;
+    const int tid = threadIdx.x;
+    uint32_t N;
+    const uint32_t K = matcher_region(b, r, orig_size, key_elem, max_raw, gate, N);
+    if (K == 0) {
+        if (tid == 0) deep_d[r] = 0;
+        return;
+    }
+    const uint8_t* data = b.src + b.src_off[r] + K;
+    const uint32_t SD = N - K;
+    auto dword_at = [&](uint32_t at) { return (uint32_t)data[at] | ((uint32_t)data[at + 1] << 8) | ((uint32_t)data[at + 2] << 16) | ((uint32_t)data[at + 3] << 24); };
+    for (uint32_t i = tid; i < PP_TABLE; i += 256) val[i] = i == 0 ? 1u : 0u;   // hash(0) = 0, hash(1) != 0: an empty cell matches nothing
+    if (tid == 0) { best = 0xFFFFFFFFu; lost = 0; }
+    __syncthreads();
+    // sixteen distinct probes in sixteen different cells, else another place
+    uint32_t p0 = PP_P0;
+    bool placed = false;
+    for (uint32_t attempt = 0; attempt < PP_TRIES && !placed; ++attempt, p0 += PP_SHIFT) {
+        uint32_t pw = 0, h = 0;
+        if (tid < 16) {
+            pw = dword_at(p0 + tid);
+            h = pp_hash(pw);
+            val[h] = pw;
+            idx[h] = (uint8_t)tid;
+        }
+        __syncthreads();
+        if (tid < 16 && (val[h] != pw || idx[h] != (uint8_t)tid)) lost = 1;
+        __syncthreads();
+        placed = lost == 0;
+        __syncthreads();
+        if (!placed) {
+            if (tid < 16) val[h] = h == 0 ? 1u : 0u;
+            if (tid == 0) lost = 0;
+            __syncthreads();
+        }
+    }
+    if (placed) {
+        p0 -= PP_SHIFT;   // (the loop's increment)
+        const uint32_t nchunk = SD >> 4;
+        for (uint32_t c = tid; c < nchunk; c += 256) {
+            const uint32_t at = 16u * c;
+            const uint32_t w = dword_at(at);
+            const uint32_t h = pp_hash(w);
+            if (val[h] == w) {   // rare: compare the chunk with the 16 bytes behind that probe
+                const uint32_t from = p0 + idx[h];
+                if (at >= from + PERIOD_MIN_D) {
+                    bool same = true;
+                    for (uint32_t k = 0; k < 16; ++k) same = same && data[at + k] == data[from + k];
+                    if (same) atomicMin(&best, at - from);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) deep_d[r] = best == 0xFFFFFFFFu ? 0u : best;
+}
+
+__global__ __launch_bounds__(WAVE) void deep_check_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
+                                                          uint32_t* deep_d, const uint32_t* gate_in, uint32_t* gate_out)
+{
+    const uint32_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t g = gate_in ? gate_in[r] : 0u;
+    const uint32_t hint = deep_d[r];   // (0 for every read the probe did not look at)
+    uint32_t D = 0;
+    if (hint && g < GATE_SKIP) {
+        const uint32_t N = b.src_size[r];
+        const uint32_t K = (orig_size[r] / key_elem + 3u) >> 2;
+        const uint8_t* in = b.src + b.src_off[r];
+        DeepLayout dl;
+        if (deep_layout(N, K, in, src_cap[r], b.dst + b.dst_off[r], b.dst_cap[r], hdr, dl) && period_holds(in + K, N - K, hint, lane)) D = hint;
+    }
+    if (lane == 0) {
+        deep_d[r] = D;
+        gate_out[r] = D ? GATE_SKIP : g;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
@@ -1966,6 +2074,22 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
     if (deep_d)  // the reads in which the first launch found a repeat distance (it wrote deep_d[] for every read)
         hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                            src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d);
+    return hipGetLastError();
+}
+
+// ---- the long-repeat matcher in front of span mode ----------------------------------------------------------------------------
+hipError_t launch_zstd_encode_matcher(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
+                                      const void* seq_tables, bool trailers, uint32_t max_raw, uint32_t* deep_d, const uint32_t* gate_in,
+                                      uint32_t* gate_out, hipStream_t s)
+{
+    if (b.n_reads == 0) return hipSuccess;
+    const SeqCTables* st = reinterpret_cast<const SeqCTables*>(seq_tables);
+    hipLaunchKernelGGL(period_probe_kernel, dim3(b.n_reads), dim3(256), 0, s, b, orig_size, key_elem, max_raw, gate_in, deep_d);
+    hipLaunchKernelGGL(deep_check_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, hdr, src_cap, deep_d, gate_in, gate_out);
+    ReadBatch g = b;
+    g.gate = gate_in;
+    hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, g, orig_size, key_elem, (const uint32_t*)nullptr, hdr,
+                       (unsigned long long*)nullptr, src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, trailers ? 1u : 0u, deep_d);
     return hipGetLastError();
 }
 
