@@ -1955,8 +1955,8 @@ __global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, con
 //     segmented svb kernels have no workgroup that sees the head of the data bytes and the rest): sixteen probe dwords at data
 //     bytes p0 .. p0 + 15 in a hash table, the first dword of every 16-byte chunk looked up, a hit verified on 16 bytes, the
 //     smallest distance proposed in deep_d[r] (0: none).
-//   deep_check_kernel: the check zstd_encode_kernel<.., false> makes at its top (period_holds, deep_layout); deep_d[r] = the
-//     distance or 0, gate_out[r] = GATE_SKIP for the reads the matcher takes.
+//     Its first wavefront then makes the check zstd_encode_kernel<.., false> makes at its top (period_holds, deep_layout):
+//     deep_d[r] = the distance or 0, gate_out[r] = GATE_SKIP for the reads the matcher takes.
 constexpr uint32_t PP_TABLE = 512, PP_P0 = 256, PP_TRIES = 4, PP_SHIFT = 80;
 __device__ __forceinline__ uint32_t pp_hash(uint32_t w) { return (w * 0x9E3779B1u) >> 23; }
 
@@ -1971,8 +1971,8 @@ __device__ __forceinline__ uint32_t matcher_region(const ReadBatch& b, uint32_t 
     return (K >= N || N - K < 8192u) ? 0u : K;
 }
 
-__global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, uint32_t max_raw,
-                                                           const uint32_t* gate, uint32_t* deep_d)
+__global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
+                                                           uint32_t max_raw, const uint32_t* gate, uint32_t* deep_d, uint32_t* gate_out)
 {
     __shared__ uint32_t val[PP_TABLE];
     __shared__ uint8_t idx[PP_TABLE];
@@ -1982,7 +1982,10 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
     uint32_t N;
     const uint32_t K = matcher_region(b, r, orig_size, key_elem, max_raw, gate, N);
     if (K == 0) {
-        if (tid == 0) deep_d[r] = 0;
+        if (tid == 0) {
+            deep_d[r] = 0;
+            gate_out[r] = gate ? gate[r] : 0u;
+        }
         return;
     }
     const uint8_t* data = b.src + b.src_off[r] + K;
@@ -2031,27 +2034,19 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
         }
     }
     __syncthreads();
-    if (tid == 0) deep_d[r] = best == 0xFFFFFFFFu ? 0u : best;
-}
-
-__global__ __launch_bounds__(WAVE) void deep_check_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
-                                                          uint32_t* deep_d, const uint32_t* gate_in, uint32_t* gate_out)
-{
-    const uint32_t r = blockIdx.x;
-    const int lane = threadIdx.x;
-    const uint32_t g = gate_in ? gate_in[r] : 0u;
-    const uint32_t hint = deep_d[r];   // (0 for every read the probe did not look at)
-    uint32_t D = 0;
-    if (hint && g < GATE_SKIP) {
-        const uint32_t N = b.src_size[r];
-        const uint32_t K = (orig_size[r] / key_elem + 3u) >> 2;
-        const uint8_t* in = b.src + b.src_off[r];
-        DeepLayout dl;
-        if (deep_layout(N, K, in, src_cap[r], b.dst + b.dst_off[r], b.dst_cap[r], hdr, dl) && period_holds(in + K, N - K, hint, lane)) D = hint;
-    }
-    if (lane == 0) {
-        deep_d[r] = D;
-        gate_out[r] = D ? GATE_SKIP : g;
+    // the check zstd_encode_kernel<.., false> makes at its top, by the first wavefront: does the distance hold, is there room
+    if (tid < WAVE) {
+        const uint32_t hint = best == 0xFFFFFFFFu ? 0u : best;
+        uint32_t D = 0;
+        if (hint) {
+            const uint8_t* in = b.src + b.src_off[r];
+            DeepLayout dl;
+            if (deep_layout(N, K, in, src_cap[r], b.dst + b.dst_off[r], b.dst_cap[r], hdr, dl) && period_holds(in + K, SD, hint, tid)) D = hint;
+        }
+        if (tid == 0) {
+            deep_d[r] = D;
+            gate_out[r] = D ? GATE_SKIP : (gate ? gate[r] : 0u);
+        }
     }
 }
 
@@ -2084,8 +2079,7 @@ hipError_t launch_zstd_encode_matcher(const ReadBatch& b, const uint32_t* orig_s
 {
     if (b.n_reads == 0) return hipSuccess;
     const SeqCTables* st = reinterpret_cast<const SeqCTables*>(seq_tables);
-    hipLaunchKernelGGL(period_probe_kernel, dim3(b.n_reads), dim3(256), 0, s, b, orig_size, key_elem, max_raw, gate_in, deep_d);
-    hipLaunchKernelGGL(deep_check_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, hdr, src_cap, deep_d, gate_in, gate_out);
+    hipLaunchKernelGGL(period_probe_kernel, dim3(b.n_reads), dim3(256), 0, s, b, orig_size, key_elem, hdr, src_cap, max_raw, gate_in, deep_d, gate_out);
     ReadBatch g = b;
     g.gate = gate_in;
     hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, g, orig_size, key_elem, (const uint32_t*)nullptr, hdr,
