@@ -431,3 +431,32 @@ def test_aliased_sources_beyond_the_scratch_arena():
             runs.append(r)
             c.close() if hasattr(c, "close") else None
         assert runs[0] == runs[1], "the slot plan gave different verdicts on two runs"
+
+
+def test_small_batches_take_the_large_read_path():
+    """The shape rule's second clause: a call whose reads cannot fill the device with one wavefront each -- one read of 100 k
+    samples, say: the single-buffer API, the HDF5 filter -- is coded as spans (its frame carries the span index), a batch of
+    thousands of such reads is not (one wavefront per read: checkpoints only), and reads of less than 32 k samples stay on
+    one wavefront however few they are.  Either way the reference's decoder reads the frames and the device reads them
+    back; and a read that cycles a template gets its matches on both paths."""
+    go, oo = _lib.CompressionOptions(True, 2, 1, 1), O.options(True, 2, 1, 1)
+
+    def kinds(frames):
+        return [sorted({int(t[:4].view("<u4")[0]) for t in _trailers(f)[1]}) for f in frames]
+
+    one = [O.synth_signal(5, 40, 100_000)]
+    few = [O.synth_signal(5, 41 + i, 70_000 + 1000 * i) for i in range(5)]
+    short = [O.synth_signal(5, 50 + i, 20_000) for i in range(4)]
+    many = [O.synth_signal(5, 60 + (i % 16), 60_000) for i in range(1200)]   # 144 MB: beyond what counts as a small batch
+    cyc = [np.resize(O.synth_signal(5, 9, 15643), 120_000).astype(np.int16)]
+    for reads, want_idx in ((one, True), (few, True), (short, False), (many, False), (cyc, False)):
+        comp = G.compress(reads, go)
+        k = kinds(comp[:8])
+        assert all((IDX_MAGIC in x) == want_idx for x in k), (len(reads), k)
+        back = G.decompress(comp, [a.nbytes for a in reads], go)
+        for a, f, b in list(zip(reads, comp, back))[:: max(1, len(reads) // 40)]:
+            assert not isinstance(b, int) and b.tobytes() == a.tobytes()
+            assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes()
+    # the cycled read went to the one-wavefront matcher (no span index) and compresses like libzstd's
+    f = G.compress(cyc, go)[0]
+    assert len(f) <= 1.25 * len(O.compress(cyc[0], oo)), (len(f), len(O.compress(cyc[0], oo)))
