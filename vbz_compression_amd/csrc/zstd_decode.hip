@@ -1562,6 +1562,143 @@ __device__ __noinline__ bool general_sequence_records(const uint8_t* bs_, uint32
     return true;
 }
 
+// The same walk with the three state machines on three LANES (lane 0: offsets, lane 1: match lengths, lane 2: literal
+// lengths) instead of one after the other on the scalar unit: one LDS read fetches the three table entries, the places of
+// the six bit fields of a sequence -- three groups of extra bits, three groups of state bits -- come from two short DPP
+// scans, and every lane cuts its two fields out of a copy of the window in LDS.  Half the instructions per sequence of the
+// scalar walk (a lone wavefront: 950 -> ~500 cycles per sequence); the repeat-offset rules and the checks are the scalar
+// walk's, on the three values read back from the lanes.  Works in LDS that is idle at this point: the extra-bit count of
+// every state in hbuf / norm / symnext, the code -> baseline tables in wfse / weights, the window in the task arrays.
+__device__ __noinline__ bool general_sequence_records_lanes(const uint8_t* bs_, uint32_t bsn_, uint4* rec, uint32_t nseq_, uint32_t log_ll_,
+                                                            uint32_t log_of_, uint32_t log_ml_, uint32_t regen_, uint32_t opos_, uint32_t fcs_,
+                                                            uint32_t (&rep)[3], int lane)
+{
+    static_assert(HBUF + 512 + 512 >= 3 * FSE_SLOT, "room for one byte per state behind the sequence tables");
+    const uint32_t bsn = uni(bsn_), nseq = uni(nseq_), log_ll = uni(log_ll_), log_of = uni(log_of_), log_ml = uni(log_ml_);
+    const uint32_t regen = uni(regen_), opos0 = uni(opos_), fcs = uni(fcs_);
+    uint32_t rep0 = uni(rep[0]), rep1 = uni(rep[1]), rep2 = uni(rep[2]);
+    const uint8_t* bs = reinterpret_cast<const uint8_t*>(((uint64_t)uni((uint32_t)((uint64_t)bs_ >> 32)) << 32) |
+                                                         uni((uint32_t)(uint64_t)bs_));
+    if (bsn == 0) return false;
+    uint8_t* NB = L.u.p.hbuf;          // [3][FSE_SLOT]: extra bits of the code of every state (role order: OF, ML, LL)
+    uint32_t* XT = L.wfse;             // [2][64]: code -> baseline | extra bits << 24 (ML, LL)
+    uint32_t* WIN = L.t_src;           // the window: WIN[j] = dword k0 + j counted from the end of the stream
+    // role of this lane: 0 offsets, 1 match lengths, 2 literal lengths (lanes >= 3 run along with empty fields)
+    const uint32_t role = (uint32_t)lane < 3u ? (uint32_t)lane : 0u;
+    const bool live = (uint32_t)lane < 3u;
+    const uint32_t tsel = role == 0 ? 1u : (role == 1 ? 2u : 0u);   // the role's table in L.u.p.fse (LL, OF, ML)
+    wave_lds_sync();
+    XT[lane] = lane < 53 ? ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24) : 0u;
+    XT[64 + lane] = lane < 36 ? LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24) : 0u;
+    wave_lds_sync();
+    for (uint32_t s0 = (uint32_t)lane; s0 < (uint32_t)FSE_SLOT; s0 += WAVE) {
+        NB[s0] = (uint8_t)(L.u.p.fse[1][s0] & 31u);
+        NB[FSE_SLOT + s0] = (uint8_t)(XT[L.u.p.fse[2][s0] & 63u] >> 24);
+        NB[2 * FSE_SLOT + s0] = (uint8_t)(XT[64 + (L.u.p.fse[0][s0] & 63u)] >> 24);
+    }
+    auto load_window = [&](uint32_t k0) -> uint32_t {
+        const int64_t off = (int64_t)bsn - 4 * (int64_t)(k0 + (uint32_t)lane + 1);
+        uint32_t v = 0;
+        if (off >= 0) {
+            __builtin_memcpy(&v, bs + off, 4);
+        } else if (off > -4) {
+            for (int b = 0; b < 4 + (int)off; ++b) v |= (uint32_t)bs[b] << (8 * (b - (int)off));
+        }
+        return v;
+    };
+    uint32_t k0 = 0;
+    WIN[lane] = load_window(0);
+    if (lane < 8) WIN[64 + lane] = 0;
+    wave_lds_sync();
+    const uint32_t top = uni(WIN[0]) >> 24;
+    if (top == 0) return false;
+    uint32_t pos = 8u - (uint32_t)hbit(top);   // bits consumed (wave-uniform)
+    // bits [P, P + w) of the stream, w <= 32 (per lane)
+    auto field = [&](uint32_t P, uint32_t w) -> uint32_t {
+        const uint32_t k = (P >> 5) - k0;
+        const uint64_t two = ((uint64_t)WIN[k] << 32) | WIN[k + 1];
+        return (uint32_t)(((two << (P & 31u)) >> 1) >> (63u - w));
+    };
+    // the initial states: LL, OF, ML in that order
+    uint32_t st;
+    {
+        const uint32_t at = role == 2 ? 0u : (role == 0 ? log_ll : log_ll + log_of);
+        st = field(pos + at, role == 2 ? log_ll : (role == 0 ? log_of : log_ml));
+        pos += log_ll + log_of + log_ml;
+    }
+    uint64_t sum_ll = 0, outp = opos0;
+    uint32_t worst = 0, astray = 0;
+    uint32_t r_ll = 0, r_ml = 0, r_of = 0;
+    const uint32_t tbase = tsel * (uint32_t)FSE_SLOT, nbase_role = role * (uint32_t)FSE_SLOT;
+    const uint32_t* FSE = &L.u.p.fse[0][0];
+    const uint32_t xt_role = role == 2 ? 64u : 0u;
+    // the table entry and the extra-bit count of the current state are requested as soon as the state is known, one
+    // sequence ahead of their use: the LDS round trip runs behind the repeat-offset rules of the sequence before
+    uint32_t e = FSE[tbase + st], a_raw = NB[nbase_role + st];
+    for (uint32_t i = 0; i < nseq; ++i) {
+        if ((pos >> 5) - k0 > 58) {
+            k0 = pos >> 5;
+            wave_lds_sync();
+            WIN[lane] = load_window(k0);
+            wave_lds_sync();
+        }
+        const bool last = i + 1 == nseq;
+        uint32_t a = a_raw;
+        const uint32_t code = e & 0xFFu;
+        uint32_t nb = last ? 0u : (e >> 8) & 0xFFu;
+        a = live ? a : 0u;
+        nb = live ? nb : 0u;
+        worst = (live && code > worst) ? code : worst;
+        // where the lane's extra bits and state bits stand: extras in the order OF, ML, LL, then the states LL, ML, OF
+        const uint32_t x1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x111, 0xF, 0xF, false);   // row_shr:1
+        const uint32_t x2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, 0x112, 0xF, 0xF, false);   // row_shr:2
+        const uint32_t xoff = x1 + x2;
+        const uint32_t S = lane_get(xoff + a, 2);
+        const uint32_t s1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nb, 0x101, 0xF, 0xF, false);  // row_shl:1
+        const uint32_t s2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)nb, 0x102, 0xF, 0xF, false);  // row_shl:2
+        const uint32_t soff = S + s1 + s2;
+        const uint32_t total = lane_get(soff + nb, 0);
+        const uint32_t extra = field(pos + xoff, a);
+        const uint32_t sbits = field(pos + soff, nb);
+        st = live ? (e >> 16) + sbits : 0u;
+        e = FSE[tbase + st];
+        a_raw = NB[nbase_role + st];
+        const uint32_t xb = XT[xt_role + (code & 63u)] & 0xFFFFFFu;            // (read by the offsets' lane too: no branch)
+        const uint32_t pw = 1u << (code & 31u);
+        const uint32_t val = (role == 0 ? pw : xb) + extra;
+        pos += total;
+        const uint32_t ofv = lane_get(val, 0), mlen = lane_get(val, 1), llen = lane_get(val, 2);
+        // repeat offsets (3.1.1.5), branch free: idx 0 = rep0 as it is, 1 = rep1, 2 = rep2, 3 = rep0 - 1
+        const bool isrep = ofv <= 3;
+        const uint32_t idx = ofv - 1 + (llen == 0 ? 1u : 0u);
+        uint32_t cand = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - (idx == 3 ? 1u : 0u));
+        cand = cand ? cand : 1u;  // libzstd forces an invalid 0 to 1
+        const uint32_t offset = isrep ? cand : ofv - 3;
+        rep2 = (isrep && idx <= 1) ? rep2 : rep1;
+        rep1 = (isrep && idx == 0) ? rep1 : rep0;
+        rep0 = offset;
+        sum_ll += llen;
+        outp += llen;
+        astray += offset > outp ? 1u : 0u;
+        outp += mlen;
+        const bool mine = (uint32_t)lane == (i & 63);
+        r_ll = mine ? llen : r_ll;
+        r_ml = mine ? mlen : r_ml;
+        r_of = mine ? offset : r_of;
+        if ((i & 63) == 63) rec[(i & ~63u) + (uint32_t)lane] = make_uint4(r_ll, r_ml, r_of, 0u);
+    }
+    if ((uint32_t)lane < (nseq & 63)) rec[(nseq & ~63u) + (uint32_t)lane] = make_uint4(r_ll, r_ml, r_of, 0u);
+    const uint32_t worst_o = lane_get(worst, 0), worst_m = lane_get(worst, 1), worst_l = lane_get(worst, 2);
+    wave_lds_sync();
+    if (worst_l > 35 || worst_m > 52 || worst_o > 31 || astray) return false;
+    if (sum_ll > regen || outp > fcs || outp - opos0 > BLOCK_MAX) return false;  // both only grow
+    if (pos != 8u * bsn) return false;  // every bit consumed, none beyond
+    rep[0] = rep0;
+    rep[1] = rep1;
+    rep[2] = rep2;
+    return true;
+}
+
 // all lanes.  The same walk as zero_run_chain, split at the encoder's checkpoints (zstd_encode.hip, CP_MAGIC): lane
 // j decodes sequences [j * spacing, (j + 1) * spacing) from (unread bits, LL state, ML state) = checkpoint j - 1
 // (lane 0: from the top of the stream).  The bit stream is staged in LDS (the ring's area, idle while headers are
@@ -2345,8 +2482,13 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     uint4* seqbuf = reinterpret_cast<uint4*>(dst + ws_seq);
                     {
                         uint32_t reps[3] = { rep0, rep1, rep2 };
+#ifdef VBZ_SEQ_CHAIN_SCALAR
                         const bool good = general_sequence_records(bs, bsn, seqbuf, nseq, (uint32_t)__shfl(log_ll, 0, 64), (uint32_t)__shfl(log_of, 0, 64),
                                                                    (uint32_t)__shfl(log_ml, 0, 64), regen, opos, fcs, reps, lane);
+#else
+                        const bool good = general_sequence_records_lanes(bs, bsn, seqbuf, nseq, (uint32_t)__shfl(log_ll, 0, 64), (uint32_t)__shfl(log_of, 0, 64),
+                                                                         (uint32_t)__shfl(log_ml, 0, 64), regen, opos, fcs, reps, lane);
+#endif
                         if (!good) FAIL();
                         rep0 = reps[0];
                         rep1 = reps[1];
