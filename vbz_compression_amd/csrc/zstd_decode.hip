@@ -1576,7 +1576,9 @@ __device__ __noinline__ bool general_sequence_records_lanes(const uint8_t* bs_, 
     static_assert(HBUF + 512 + 512 >= 3 * FSE_SLOT, "room for one byte per state behind the sequence tables");
     const uint32_t bsn = uni(bsn_), nseq = uni(nseq_), log_ll = uni(log_ll_), log_of = uni(log_of_), log_ml = uni(log_ml_);
     const uint32_t regen = uni(regen_), opos0 = uni(opos_), fcs = uni(fcs_);
-    uint32_t rep0 = uni(rep[0]), rep1 = uni(rep[1]), rep2 = uni(rep[2]);
+    // (the repeat offsets and the sums live in vector registers, the same value in every lane: as scalar code the rules below
+    // come out as a chain of compares and BRANCHES, which a lone wavefront pays for with a refetch each)
+    uint32_t rep0 = rep[0], rep1 = rep[1], rep2 = rep[2];
     const uint8_t* bs = reinterpret_cast<const uint8_t*>(((uint64_t)uni((uint32_t)((uint64_t)bs_ >> 32)) << 32) |
                                                          uni((uint32_t)(uint64_t)bs_));
     if (bsn == 0) return false;
@@ -1627,7 +1629,8 @@ __device__ __noinline__ bool general_sequence_records_lanes(const uint8_t* bs_, 
         pos += log_ll + log_of + log_ml;
     }
     uint64_t sum_ll = 0, outp = opos0;
-    uint32_t worst = 0, astray = 0;
+    uint32_t worst = 0;
+    bool astray = false;
     uint32_t r_ll = 0, r_ml = 0, r_of = 0;
     const uint32_t tbase = tsel * (uint32_t)FSE_SLOT, nbase_role = role * (uint32_t)FSE_SLOT;
     const uint32_t* FSE = &L.u.p.fse[0][0];
@@ -1667,19 +1670,24 @@ __device__ __noinline__ bool general_sequence_records_lanes(const uint8_t* bs_, 
         const uint32_t pw = 1u << (code & 31u);
         const uint32_t val = (role == 0 ? pw : xb) + extra;
         pos += total;
-        const uint32_t ofv = lane_get(val, 0), mlen = lane_get(val, 1), llen = lane_get(val, 2);
+        // the three values to every lane through the LDS crossbar (results the compiler takes for per-lane values)
+        const uint32_t ofv = (uint32_t)__builtin_amdgcn_ds_bpermute(0, (int)val), mlen = (uint32_t)__builtin_amdgcn_ds_bpermute(4, (int)val),
+                       llen = (uint32_t)__builtin_amdgcn_ds_bpermute(8, (int)val);
         // repeat offsets (3.1.1.5), branch free: idx 0 = rep0 as it is, 1 = rep1, 2 = rep2, 3 = rep0 - 1
-        const bool isrep = ofv <= 3;
-        const uint32_t idx = ofv - 1 + (llen == 0 ? 1u : 0u);
-        uint32_t cand = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - (idx == 3 ? 1u : 0u));
-        cand = cand ? cand : 1u;  // libzstd forces an invalid 0 to 1
-        const uint32_t offset = isrep ? cand : ofv - 3;
-        rep2 = (isrep && idx <= 1) ? rep2 : rep1;
-        rep1 = (isrep && idx == 0) ? rep1 : rep0;
+        // (written with masks, not with conditions: no control flow on the chain)
+        const uint32_t isrep = 0u - (uint32_t)(ofv <= 3);                       // all ones / zero
+        const uint32_t idx = ofv - 1 + (uint32_t)(llen == 0);
+        const uint32_t is1 = 0u - (uint32_t)(idx == 1), is2 = 0u - (uint32_t)(idx == 2);
+        uint32_t cand = ((rep1 & is1) | (rep2 & is2) | (rep0 & ~(is1 | is2))) - (uint32_t)(idx == 3);
+        cand += (uint32_t)(cand == 0);  // libzstd forces an invalid 0 to 1
+        const uint32_t offset = (cand & isrep) | ((ofv - 3) & ~isrep);
+        const uint32_t keep2 = isrep & (0u - (uint32_t)(idx <= 1)), keep1 = isrep & (0u - (uint32_t)(idx == 0));
+        rep2 = (rep2 & keep2) | (rep1 & ~keep2);
+        rep1 = (rep1 & keep1) | (rep0 & ~keep1);
         rep0 = offset;
         sum_ll += llen;
         outp += llen;
-        astray += offset > outp ? 1u : 0u;
+        astray = astray || offset > outp;
         outp += mlen;
         const bool mine = (uint32_t)lane == (i & 63);
         r_ll = mine ? llen : r_ll;
@@ -1690,12 +1698,12 @@ __device__ __noinline__ bool general_sequence_records_lanes(const uint8_t* bs_, 
     if ((uint32_t)lane < (nseq & 63)) rec[(nseq & ~63u) + (uint32_t)lane] = make_uint4(r_ll, r_ml, r_of, 0u);
     const uint32_t worst_o = lane_get(worst, 0), worst_m = lane_get(worst, 1), worst_l = lane_get(worst, 2);
     wave_lds_sync();
-    if (worst_l > 35 || worst_m > 52 || worst_o > 31 || astray) return false;
-    if (sum_ll > regen || outp > fcs || outp - opos0 > BLOCK_MAX) return false;  // both only grow
+    if (worst_l > 35 || worst_m > 52 || worst_o > 31 || __any(astray)) return false;
+    if (__any(sum_ll > regen || outp > fcs || outp - opos0 > BLOCK_MAX)) return false;  // both only grow
     if (pos != 8u * bsn) return false;  // every bit consumed, none beyond
-    rep[0] = rep0;
-    rep[1] = rep1;
-    rep[2] = rep2;
+    rep[0] = uni(rep0);
+    rep[1] = uni(rep1);
+    rep[2] = uni(rep2);
     return true;
 }
 
