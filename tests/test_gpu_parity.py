@@ -1188,3 +1188,35 @@ def test_many_tiny_reads_in_one_batch():
         mine = G.decompress([O.compress(reads[int(i)], oo) for i in pick], [reads[int(i)].nbytes for i in pick], go)
         for i, b in zip(pick, mine):
             assert not isinstance(b, int) and b.tobytes() == reads[int(i)].tobytes()
+
+
+def test_zstd_decode_libzstd_frames_of_several_blocks():
+    """Frames the reference writes for 4-byte integers: svb streams of 150 ... 400 KB, i.e. several 128 KB blocks per frame,
+    whose sequence chains hand their repeat offsets (and, in Repeat_Mode, their tables) from block to block -- the state
+    the decoder keeps in lane 0 only.  Every data shape of the soak tool, both integer types, each frame in a call of its own
+    and all of them in one batch: the device must decode what the reference path (oracle + libzstd 1.4.8) wrote, bit for bit.
+    (A soak run found a decoder variant that started later blocks from stale lanes' repeat offsets; one-block int16 frames,
+    which is what the other tests send, do not notice.)"""
+    import sys
+
+    import gpu_util as G
+    from vbz_compression_amd import _lib
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak
+
+    rng = np.random.default_rng(141)
+    cases = []
+    for dt in (np.uint32, np.int32):
+        for kind in (0, 1, 3, 4, 5, 6):
+            for n in (100003, 70001):
+                cases.append(soak.make_read(rng, dt, kind, n))
+    for level in (1, 3):
+        go, oo = _lib.CompressionOptions(True, 4, level, 1), O.options(True, 4, level, 1)
+        frames = [O.compress(a, oo) for a in cases]
+        for a, f in zip(cases, frames):
+            b = G.decompress([f], [a.nbytes], go)[0]
+            assert not isinstance(b, int) and b.tobytes() == a.tobytes(), (a.dtype, len(a), level)
+        back = G.decompress(frames, [a.nbytes for a in cases], go)
+        for a, b in zip(cases, back):
+            assert not isinstance(b, int) and b.tobytes() == a.tobytes(), (a.dtype, len(a), level, "batch")

@@ -1578,7 +1578,8 @@ __device__ __noinline__ bool general_sequence_records_lanes(const uint8_t* bs_, 
     const uint32_t regen = uni(regen_), opos0 = uni(opos_), fcs = uni(fcs_);
     // (the repeat offsets and the sums live in vector registers, the same value in every lane: as scalar code the rules below
     // come out as a chain of compares and BRANCHES, which a lone wavefront pays for with a refetch each)
-    uint32_t rep0 = rep[0], rep1 = rep[1], rep2 = rep[2];
+    // (the caller's repeat offsets are lane 0's: the other lanes' copies may be stale)
+    uint32_t rep0 = uni(rep[0]), rep1 = uni(rep[1]), rep2 = uni(rep[2]);
     const uint8_t* bs = reinterpret_cast<const uint8_t*>(((uint64_t)uni((uint32_t)((uint64_t)bs_ >> 32)) << 32) |
                                                          uni((uint32_t)(uint64_t)bs_));
     if (bsn == 0) return false;
