@@ -62,6 +62,8 @@ struct vbz_gpu_ctx
     DevBuf seqdtab;   // decoding tables of the same distributions
     DevBuf segmeta;   // segment / span tables of the large-read path
     DevBuf spanmeta, spantmp;  // span tables and temporary slots of the entropy stage in the large-read path
+    DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
+    bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
@@ -522,10 +524,16 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
         HIPCHK(c, launch_zstd_decode_spans(z, E_STREAM, c->seqdtab.p, desc, dspan_first, dspan_count, max_spans, dspan_status, redo, s),
                "zstd_decode (spans) launch");
     } else {
-        Timed t(c, "zstd_decode");
         // a frame whose content cannot be a valid svb stream of the expected size: the reference would
         // decode it and then fail in the svb stage with a stream error
-        HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, c->seqdtab.p, s), "zstd_decode launch");
+        if (c->fast_decode && !dbg) {
+            if (!ensure(c, c->fastmeta, zstd_fast_meta_bytes(n))) return -1;
+            Timed t(c, "zstd_decode");
+            HIPCHK(c, launch_zstd_decode_fast(z, E_STREAM, c->seqdtab.p, c->fastmeta.p, s), "zstd_decode (batched) launch");
+        } else {
+            Timed t(c, "zstd_decode");
+            HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, c->seqdtab.p, s), "zstd_decode launch");
+        }
     }
     dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable header queue | general sequences: flush tables records literals matches", dbg);
     ReadBatch d = rb;
@@ -714,6 +722,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);
     if (const char* e = getenv("VBZ_HIP_FUSE_SVB")) c->fuse_svb = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_FAST_DECODE")) c->fast_decode = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e);
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
@@ -759,7 +768,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

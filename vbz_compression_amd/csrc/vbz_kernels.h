@@ -101,6 +101,14 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
 // gets what launch_svb_decode(2, zigzag) would have reported after launch_zstd_decode, and no svb_decode launch follows.
 hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, uint8_t* out, const uint64_t* out_off,
                                         const uint32_t* out_size, hipStream_t s);
+// The one-wavefront decoder for the reads with only[i] != 0 (the others are left alone).
+hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, const uint32_t* only, hipStream_t s);
+// Batched decoder for frames of the shape zstd_encode.hip writes (zstd_decode_fast.hip: one lane per frame for the headers, one lane
+// per tree description, one wavefront per frame for nothing but the streams, one for the zero-run block); every frame that is not of
+// that shape or fails a check, and every error verdict, goes through launch_zstd_decode_only at the end.  Same results as
+// launch_zstd_decode.  meta: zstd_fast_meta_bytes(n_reads) bytes of device scratch.
+size_t zstd_fast_meta_bytes(uint32_t n_reads);
+hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, hipStream_t s);
 size_t seq_dtables_bytes();
 void seq_dtables_build(void* host_buffer);
 // The same for batches of few, large reads: frames that carry the encoder's span index are decoded one span per wavefront

@@ -1,0 +1,769 @@
+// zstd_decode_fast.hip -- the batched decoder for the frames zstd_encode.hip writes (and any frame of the same shape).
+//
+// zstd_decode.hip decodes ANY conforming frame with one wavefront per frame; on the device's own frames it spends a third of its
+// time in the serial parts of a frame (block headers found one after the other, two tree descriptions, the sequence chain) as
+// wave-uniform scalar code with 63 lanes idle, and the rest in a stream phase that sits on the memory system's ceiling for mixed
+// scattered 64-byte accesses (profiles/r04_stream_scaling.md).  Here the same work is cut by what bounds it:
+//
+//   fast_scan_kernel     one LANE per frame: frame header, trailer, every block header; checks the shape (below) and leaves one
+//                        task per Huffman stream: where it starts, how long it is, where its bytes go, which table it uses
+//   fast_weights_kernel  one LANE per Huffman tree description: the FSE-coded weights (RFC 8878 4.2.1.1) -> 256 weight bytes
+//   fast_streams_kernel  one wavefront per frame, nothing but the streams: 64 lanes, one stream each, whole aligned 128-byte lines
+//                        requested per lane (a 64-dword ring per lane in LDS), 128 bytes stored per lane and burst
+//   fast_runs_kernel     one wavefront per frame: the zero-run block (state chains from the encoder's checkpoints, placement from
+//                        prefix sums: zstd_runs.h)
+//
+// The shape: a single frame with a content size and no dictionary, compressed blocks only, every literals section four Huffman
+// streams, at most two trees (one of at most 9-bit codes, none above 11), no sequences except zero-run sequences (predefined LL / ML
+// tables, offsets = repeat offset 1) in the FIRST block, at most 64 streams.  Nothing is trusted: a frame that is not of this shape,
+// or that fails any check on the way (a stream that does not end on its first bit, a chain that does not regenerate what the later
+// blocks leave of the content size ...), is marked in redo[] and decoded by zstd_decode_kernel in a last launch gated by that
+// array -- which is also what decides every error verdict.  A frame decoded here gets exactly the bytes the one-wavefront decoder
+// writes: same tables, same streams, same placement code.
+// Replaces, like zstd_decode.hip, the reference's ZSTD_decompress call (vbz/vbz.cpp:236-273).
+#include "vbz_kernels.h"
+#include "zstd_runs.h"
+
+namespace vbzhip {
+
+namespace {
+
+constexpr uint32_t FAST_TASKS = 64;
+constexpr uint32_t CP_MAGIC = 0x184D2A5Bu, IDX_MAGIC = 0x184D2A5Cu;
+constexpr uint32_t TASK_REL = 1u << 31, TASK_TAB = 1u << 30, TASK_CNT = TASK_TAB - 1u;
+
+struct FastFrame  // 128 bytes per read
+{
+    uint32_t fcs, ntask, ntree, block_max;
+    uint32_t tree_off[2], tree_len[2];
+    uint32_t tlog[2], nw[2];          // fast_weights_kernel
+    uint32_t seq_off, seq_len, nseq;  // the zero-run block's bit stream (behind count, modes and the RLE symbol); nseq 0: none
+    uint32_t b0_regen, base_out;      // its literals; the bytes it regenerates = where the later blocks' content starts
+    uint32_t ws_lit, ws_pairs;        // staging in the destination slot (literals, length pairs)
+    uint32_t cp_off, cp_count, cp_spacing;
+    uint32_t pad[10];
+};
+static_assert(sizeof(FastFrame) == 128, "FastFrame");
+
+struct FastTask
+{
+    uint32_t src, size;  // the stream in the read's source
+    uint32_t out;        // where its bytes go: offset in the destination slot (TASK_REL: behind the zero-run block)
+    uint32_t cnt;        // symbols | TASK_TAB (second tree) | TASK_REL
+};
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t ld64(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// ---- one lane per frame ------------------------------------------------------------------------------------------------------------
+// Everything zstd_decode_kernel checks on its way through a frame of this shape is checked here (or in the kernels behind), in the
+// same terms; whatever is not of this shape returns early and leaves redo[r] = 1.  (Reads of up to 16 bytes past the read are inside
+// the arena's slack, as in zstd_decode_kernel.)
+__global__ __launch_bounds__(256) void fast_scan_kernel(ReadBatch b, FastFrame* frames, FastTask* tasks, uint32_t* redo)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= b.n_reads) return;
+    redo[r] = 1;
+    if (b.gate && b.gate[r] >= GATE_SKIP) return;
+    const uint32_t n = b.src_size[r];
+    if (n >= E_FIRST || n < 32) return;
+    const uint8_t* src = b.src + b.src_off[r];
+    const uint32_t cap = b.dst_cap[r];
+    FastFrame F = {};
+    uint32_t pos;
+    uint32_t has_checksum;
+    {
+        const uint64_t h0 = ld64(src), h1 = ld64(src + 8);
+        auto hb = [&](uint32_t i) -> uint32_t { return (uint32_t)((i < 8 ? h0 >> (8 * i) : h1 >> (8 * (i - 8))) & 0xFF); };
+        const uint32_t fhd = hb(4);
+        if ((uint32_t)h0 != 0xFD2FB528u || (fhd & 0x08) || (fhd & 3)) return;  // (a Dictionary_ID field: the careful decoder)
+        const uint32_t single = (fhd >> 5) & 1, fcs_flag = fhd >> 6;
+        pos = 5;
+        uint64_t window = 0;
+        if (!single) {
+            const uint32_t wd = hb(pos++);
+            const uint32_t wlog = 10 + (wd >> 3);
+            if (wlog > 31) return;
+            window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
+        }
+        const uint32_t fsz = fcs_flag == 0 ? (single ? 1u : 0u) : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+        if (fsz == 0) return;
+        uint64_t fcs = 0;
+        for (uint32_t i = 0; i < fsz; ++i) fcs |= (uint64_t)hb(pos + i) << (8 * i);
+        if (fsz == 2) fcs += 256;
+        pos += fsz;
+        if (fcs > cap || fcs >= (1u << 30)) return;
+        if (single) window = fcs;
+        F.fcs = (uint32_t)fcs;
+        F.block_max = (uint32_t)(window < BLOCK_MAX ? window : BLOCK_MAX);
+        has_checksum = (fhd >> 2) & 1;
+    }
+    // the encoder's checkpoint trailer (see zero_run_chain_segments); an index trailer may follow it
+    if (n >= 64) {
+        uint32_t tb = ld32(src + n - 4), ne = n;
+        if (tb >= 24 && tb <= n - 16 && (tb & 7u) == 0) {
+            if (ld32(src + n - tb) == IDX_MAGIC && ld32(src + n - tb + 4) == tb - 8) {
+                ne = n - tb;
+                tb = ld32(src + ne - 4);
+            }
+        }
+        if (tb >= 20 && tb <= 8 + 4 + 4 * 63 + 4 && tb + 16 <= ne) {
+            const uint32_t m0 = ld32(src + ne - tb), m1 = ld32(src + ne - tb + 4), m2 = ld32(src + ne - tb + 8);
+            const uint32_t cnt = m2 >> 16;
+            if (m0 == CP_MAGIC && m1 == tb - 8 && tb == 16 + 4 * cnt && cnt >= 1) {
+                F.cp_off = ne - tb + 12;
+                F.cp_count = cnt;
+                F.cp_spacing = m2 & 0xFFFFu;
+            }
+        }
+    }
+    FastTask* T = tasks + (size_t)r * FAST_TASKS;
+    uint32_t ntask = 0, ntree = 0;
+    uint64_t rel = 0;  // content of the blocks behind the zero-run block (or of all blocks)
+    int cur_tab = -1;
+    for (;;) {
+        if (pos + 3 > n) return;
+        const uint64_t a0 = ld64(src + pos), a1 = ld64(src + pos + 8);
+        auto win = [&](uint32_t o) -> uint64_t { return o == 0 ? a0 : ((a0 >> (8 * o)) | (a1 << (64 - 8 * o))); };  // 8 bytes from offset o <= 8
+        const uint32_t bh = (uint32_t)a0 & 0xFFFFFFu;
+        const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype != 2 || bsize < 5 || bsize >= BLOCK_MAX || (uint64_t)pos + 3 + bsize > n) return;
+        const uint32_t blk = pos + 3;
+        uint32_t lh, regen, csize;
+        uint32_t ltype;
+        {
+            const uint64_t v = win(3);
+            const uint32_t h0 = (uint32_t)v & 0xFF, fmt = (h0 >> 2) & 3;
+            ltype = h0 & 3;
+            if (ltype < 2 || fmt == 0) return;
+            if (fmt == 1) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; }
+            else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; }
+            else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; }
+        }
+        if (regen == 0 || csize == 0 || regen > BLOCK_MAX || lh + csize >= bsize) return;
+        uint32_t tree_used = 0;
+        if (ltype == 2) {
+            if (ntree == 2) return;
+            const uint32_t hb = src[blk + lh];
+            if (hb >= 128) tree_used = 1 + ((hb - 127) + 1) / 2;
+            else if (hb == 0) return;
+            else tree_used = 1 + hb;
+            if (tree_used > csize) return;
+            F.tree_off[ntree] = blk + lh;
+            F.tree_len[ntree] = tree_used;
+            cur_tab = (int)ntree++;
+        } else if (cur_tab < 0) {
+            return;
+        }
+        uint32_t q = blk + lh + tree_used, qn = csize - tree_used;
+        if (qn < 10) return;
+        const uint64_t j = ltype == 3 ? win(3 + lh) : ld64(src + q);
+        const uint32_t s1 = (uint32_t)j & 0xFFFFu, s2 = (uint32_t)(j >> 16) & 0xFFFFu, s3 = (uint32_t)(j >> 32) & 0xFFFFu;
+        q += 6;
+        qn -= 6;
+        if (s1 + s2 + s3 > qn) return;
+        const uint32_t seg = (regen + 3) >> 2;
+        if (seg * 3 > regen) return;
+        const uint32_t sq = blk + lh + csize, sqn = bsize - (lh + csize);
+        const uint64_t sq8 = ld64(src + sq);  // (bytes past the block are never looked at)
+        const uint32_t nseq0 = (uint32_t)sq8 & 0xFF;
+        uint32_t out0, flags = cur_tab ? TASK_TAB : 0u;
+        if (nseq0 == 0) {
+            if (sqn != 1 || regen > F.block_max) return;
+            out0 = (uint32_t)rel;
+            flags |= TASK_REL;
+            rel += regen;
+            if (rel > F.fcs) return;
+        } else {
+            // zero-run sequences: the first block only, predefined LL / ML tables, OF = RLE of code 0 (repeat offset 1 is 1 there)
+            if (ntask != 0 || sqn < 4) return;
+            const uint32_t used0 = nseq0 < 128 ? 1u : (nseq0 < 255 ? 2u : 3u);
+            const uint32_t b1 = (uint32_t)(sq8 >> 8) & 0xFF, b2 = (uint32_t)(sq8 >> 16) & 0xFF;
+            const uint32_t ns0 = nseq0 < 128 ? nseq0 : (nseq0 < 255 ? ((nseq0 - 128) << 8) + b1 : b1 + (b2 << 8) + 0x7F00);
+            if (used0 + 2 >= sqn || ns0 == 0) return;
+            if (((uint32_t)(sq8 >> (8 * used0)) & 0xFF) != 0x10u || ((uint32_t)(sq8 >> (8 * (used0 + 1))) & 0xFF) != 0u) return;
+            const uint64_t ws_lit64 = ((uint64_t)F.fcs + 15u) & ~15ull;
+            if (ws_lit64 + BLOCK_MAX + 16 >= 0xFFFFFFF0ull) return;
+            F.ws_lit = (uint32_t)ws_lit64;
+            F.ws_pairs = F.ws_lit + ((regen + 7u) & ~7u);
+            if ((uint64_t)F.ws_pairs + 8ull * ns0 + 8 > cap) return;
+            F.seq_off = sq + used0 + 2;
+            F.seq_len = sqn - (used0 + 2);
+            F.nseq = ns0;
+            F.b0_regen = regen;
+            out0 = F.ws_lit;
+        }
+        if (ntask + 4 > FAST_TASKS) return;
+        {
+            const uint32_t so[4] = { 0u, s1, s1 + s2, s1 + s2 + s3 };
+            const uint32_t sz[4] = { s1, s2, s3, qn - s1 - s2 - s3 };
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                FastTask t;
+                t.src = q + so[k];
+                t.size = sz[k];
+                t.out = out0 + (uint32_t)k * seg;
+                t.cnt = (k < 3 ? seg : regen - 3 * seg) | flags;
+                T[ntask + k] = t;
+            }
+        }
+        ntask += 4;
+        pos = blk + bsize;
+        if (last) break;
+    }
+    if (has_checksum) {
+        if (pos + 4 > n) return;
+        pos += 4;  // xxh64 of the content: not verified (like zstd_decode_kernel)
+    }
+    while (n - pos >= 8) {  // skippable frames behind the frame
+        const uint32_t m0 = ld32(src + pos), m1 = ld32(src + pos + 4);
+        if ((m0 & 0xFFFFFFF0u) != 0x184D2A50u || (uint64_t)pos + 8 + m1 > n) break;
+        pos += 8 + m1;
+    }
+    if (pos != n) return;
+    if (F.nseq) {
+        F.base_out = F.fcs - (uint32_t)rel;  // what the zero-run block must regenerate (fast_runs_kernel holds it to that)
+        if (F.base_out > F.block_max) return;
+    } else if (rel != F.fcs) {
+        return;
+    }
+    F.ntask = ntask;
+    F.ntree = ntree;
+    frames[r] = F;
+    redo[r] = 0;
+}
+
+// ---- one lane per tree description ---------------------------------------------------------------------------------------------------
+// The serial reader of zstd_decode.hip (huf_read_weights: read_ncount, fse_build, two interleaved FSE states over a backward bit
+// stream, the checks on the weights) with one description per LANE: what it indexes lives in LDS columns of its own ([index][lane]:
+// no bank conflicts), the weights go to memory.  Descriptions it cannot hold (a symbol value above 15 in the weights' alphabet, a
+// 12-bit code) are left to the careful decoder like every failure.
+constexpr int WMAXS = 15;
+struct WeightsLds
+{
+    uint32_t desc[34][WAVE];  // the description behind its header byte, zero beyond
+    uint32_t tab[64][WAVE];   // FSE decoding table of the weights: symbol | nbBits << 8 | base << 16
+    int16_t norm[WMAXS + 1][WAVE];
+    uint16_t symnext[WMAXS + 1][WAVE];
+};
+
+__global__ __launch_bounds__(WAVE) void fast_weights_kernel(ReadBatch b, FastFrame* frames, uint8_t* weights, uint32_t* redo)
+{
+    __shared__ WeightsLds S;
+    const int lane = threadIdx.x;
+    const uint32_t t = blockIdx.x * (uint32_t)WAVE + (uint32_t)lane;
+    const uint32_t r = t >> 1, k = t & 1;
+    if (r >= b.n_reads || redo[r]) return;
+    FastFrame* F = frames + r;
+    if (k >= F->ntree) return;
+    const uint8_t* g = b.src + b.src_off[r] + F->tree_off[k];
+    const uint32_t used = F->tree_len[k];
+    uint8_t* W = weights + ((size_t)r * 2 + k) * 256;
+    const uint32_t hb = g[0];
+    uint32_t nw = 0;
+#define WFAIL()       \
+    do {              \
+        redo[r] = 1;  \
+        return;       \
+    } while (0)
+    if (hb >= 128) {  // direct representation: 4 bits per weight
+        nw = hb - 127;
+        for (uint32_t i = 0; i < nw; ++i) {
+            const uint32_t by = g[1 + i / 2];
+            W[i] = (uint8_t)((i & 1) ? (by & 0xF) : (by >> 4));
+        }
+    } else {
+        for (uint32_t j = 0; j < 34; ++j) {
+            const uint32_t off = 1 + 4 * j;
+            uint32_t v = 0;
+            if (off < used) {
+                v = ld32(g + off);
+                if (off + 4 > used) v &= (1u << (8 * (used - off))) - 1u;
+            }
+            S.desc[j][lane] = v;
+        }
+        auto bits = [&](uint32_t bitpos, uint32_t nb) -> uint32_t {  // nb <= 16 bits at bit position bitpos of the description
+            const uint32_t idx = bitpos >> 5;
+            const uint64_t v = (uint64_t)S.desc[idx < 33 ? idx : 33][lane] | ((uint64_t)S.desc[idx < 32 ? idx + 1 : 33][lane] << 32);
+            return (uint32_t)(v >> (bitpos & 31)) & ((1u << nb) - 1u);
+        };
+        // ---- probabilities (RFC 8878 4.1.1): read_ncount(p + 1, hb, 255, 6) of zstd_decode.hip
+        const int log = (int)bits(0, 4) + 5;
+        if (log > 6) WFAIL();
+        uint32_t bitpos = 4;
+        int remaining = (1 << log) + 1, threshold = 1 << log, nbits = log + 1, sym = 0;
+        bool prev0 = false;
+        while (remaining > 1 && sym <= WMAXS) {
+            if (bitpos > 8u * 128u) WFAIL();
+            if (prev0) {
+                for (;;) {
+                    const uint32_t rr = bits(bitpos, 2);
+                    bitpos += 2;
+                    for (uint32_t i = 0; i < rr; ++i) {
+                        if (sym > WMAXS) WFAIL();
+                        S.norm[sym++][lane] = 0;
+                    }
+                    if (rr != 3) break;
+                    if (bitpos > 8u * 128u) WFAIL();
+                }
+                prev0 = false;
+                if (sym > WMAXS) break;
+                continue;
+            }
+            const int max = (2 * threshold - 1) - remaining;
+            const uint32_t v = bits(bitpos, (uint32_t)nbits);
+            int count;
+            if ((int)(v & (uint32_t)(threshold - 1)) < max) {
+                count = (int)(v & (uint32_t)(threshold - 1));
+                bitpos += (uint32_t)(nbits - 1);
+            } else {
+                count = (int)(v & (uint32_t)(2 * threshold - 1));
+                if (count >= threshold) count -= max;
+                bitpos += (uint32_t)nbits;
+            }
+            count--;
+            remaining -= count < 0 ? -count : count;
+            S.norm[sym++][lane] = (int16_t)count;
+            prev0 = (count == 0);
+            while (remaining < threshold) {
+                nbits--;
+                threshold >>= 1;
+            }
+        }
+        if (remaining != 1 || sym > WMAXS + 1) WFAIL();
+        const uint32_t hdr = (bitpos + 7) >> 3;
+        if (hdr > hb) WFAIL();
+        const int nsym = sym;
+        // ---- decoding table: fse_build
+        const int size = 1 << log;
+        {
+            int high = size - 1;
+            for (int s = 0; s < nsym; ++s) {
+                const int c = S.norm[s][lane];
+                if (c == -1) {
+                    S.tab[high--][lane] = (uint32_t)s;
+                    S.symnext[s][lane] = 1;
+                } else {
+                    S.symnext[s][lane] = (uint16_t)c;
+                }
+            }
+            const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+            int p = 0;
+            for (int s = 0; s < nsym; ++s) {
+                const int c = S.norm[s][lane];
+                for (int i = 0; i < c; ++i) {
+                    S.tab[p][lane] = (uint32_t)s;
+                    do {
+                        p = (p + step) & mask;
+                    } while (p > high);
+                }
+            }
+            if (p != 0) WFAIL();
+            for (int u = 0; u < size; ++u) {
+                const uint32_t s = S.tab[u][lane] & 0xFF;
+                const uint32_t ns = S.symnext[s][lane];
+                S.symnext[s][lane] = (uint16_t)(ns + 1);
+                const int nb = log - hbit(ns);
+                S.tab[u][lane] = s | ((uint32_t)nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xFFFFu) << 16);
+            }
+        }
+        // ---- two interleaved states over the backward bit stream behind the probabilities
+        const int qn = (int)hb - (int)hdr;
+        auto qbyte = [&](int i) -> uint32_t {
+            const uint32_t o = hdr + (uint32_t)i;
+            return (S.desc[o >> 2][lane] >> (8 * (o & 3))) & 0xFF;
+        };
+        if (qn < 1 || qbyte(qn - 1) == 0) WFAIL();
+        const int top = hbit(qbyte(qn - 1));
+        int left = (qn - 1) * 8 + top;
+        uint64_t buf = top ? ((uint64_t)(qbyte(qn - 1) & ((1u << top) - 1u)) << (64 - top)) : 0ull;
+        int avail = top, nextb = qn - 1;
+        auto rd = [&](int nb) -> uint32_t {
+            while (avail <= 56 && nextb > 0) {
+                --nextb;
+                buf |= (uint64_t)qbyte(nextb) << (56 - avail);
+                avail += 8;
+            }
+            const uint32_t v = nb ? (uint32_t)(buf >> (64 - nb)) : 0u;
+            buf <<= nb;
+            avail = avail > nb ? avail - nb : 0;
+            left -= nb;
+            return v;
+        };
+        uint32_t s1 = rd(log), s2 = rd(log);
+        if (left < 0) WFAIL();
+        for (;;) {
+            if (nw > 253) WFAIL();
+            uint32_t e = S.tab[s1][lane];
+            W[nw++] = (uint8_t)e;
+            s1 = (e >> 16) + rd((int)((e >> 8) & 0xFF));
+            if (left < 0) {
+                W[nw++] = (uint8_t)S.tab[s2][lane];
+                break;
+            }
+            if (nw > 253) WFAIL();
+            e = S.tab[s2][lane];
+            W[nw++] = (uint8_t)e;
+            s2 = (e >> 16) + rd((int)((e >> 8) & 0xFF));
+            if (left < 0) {
+                W[nw++] = (uint8_t)S.tab[s1][lane];
+                break;
+            }
+        }
+    }
+    // ---- the weights must describe a complete code (4.2.1): the last weight follows from the others
+    uint32_t total = 0;
+    int r1 = 0;
+    for (uint32_t i = 0; i < nw; ++i) {
+        const uint32_t wt = W[i];
+        if (wt >= 12) WFAIL();
+        total += wt ? (1u << (wt - 1)) : 0u;
+        r1 += (wt == 1);
+    }
+    if (total == 0) WFAIL();
+    const int tlog = hbit(total) + 1;
+    if (tlog > 11) WFAIL();  // (12-bit codes are legal: the careful decoder has the table for them)
+    const uint32_t rest = (1u << tlog) - total;
+    if (rest & (rest - 1)) WFAIL();
+    const uint32_t lastw = (uint32_t)hbit(rest) + 1;
+    W[nw++] = (uint8_t)lastw;
+    r1 += (lastw == 1);
+    if (r1 < 2 || (r1 & 1)) WFAIL();
+    F->tlog[k] = (uint32_t)tlog;
+    F->nw[k] = nw;
+#undef WFAIL
+}
+
+// ---- one wavefront per frame: the streams ---------------------------------------------------------------------------------------------
+// Table of a tree from its weight bytes: like huf_fill_table of zstd_decode.hip (cells by increasing weight, then symbol value; starts
+// from ballots), the cells per weight counted with ballots too.
+__device__ __forceinline__ void fast_fill_table(uint16_t* T, const uint8_t* W, uint32_t nw, uint32_t tlog, int lane)
+{
+    uint32_t wt[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        wt[j] = s < nw ? W[s] : 0u;
+    }
+    uint32_t base[13];
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int v = 1; v <= 12; ++v) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c += (uint32_t)__popcll(__ballot(wt[j] == (uint32_t)v));
+            base[v] = acc;
+            acc += c << (v - 1);
+        }
+        base[0] = 0;
+    }
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t st[4], len[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        st[j] = 0;
+        len[j] = wt[j] ? 1u << (wt[j] - 1) : 0u;
+#pragma unroll
+        for (int v = 1; v <= 12; ++v) {
+            const uint64_t m = __ballot(wt[j] == (uint32_t)v);
+            if (wt[j] == (uint32_t)v) st[j] = base[v] + ((uint32_t)__popcll(m & below) << (v - 1));
+            base[v] += (uint32_t)__popcll(m) << (v - 1);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t s = (uint32_t)lane + 64u * j;
+        const uint16_t ent = (uint16_t)(s | ((tlog + 1 - wt[j]) << 8));
+        if (len[j] && len[j] < 64)
+            for (uint32_t i = 0; i < len[j]; ++i) T[st[j] + i] = ent;
+        uint64_t big = __ballot(len[j] >= 64);
+        while (big) {
+            const int src_lane = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint32_t bst = (uint32_t)__shfl((int)st[j], src_lane, 64);
+            const uint32_t blen = (uint32_t)__shfl((int)len[j], src_lane, 64);
+            const uint32_t bent = (uint32_t)__shfl((int)ent, src_lane, 64);
+            for (uint32_t i = lane; i < blen; i += WAVE) T[bst + i] = (uint16_t)bent;
+        }
+    }
+}
+
+typedef __attribute__((address_space(1))) const uint8_t gcu8;
+typedef __attribute__((address_space(1))) uint8_t gu8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RING = 64;          // dwords per lane in the LDS ring
+constexpr int BATCH = 32;         // one request: a whole aligned 128-byte line
+constexpr int PERIOD = 32;        // symbols between two requests (at most 11 dwords: the ring cannot run dry, profiles/r04_stream_scaling.md)
+constexpr int BURST = 128;        // bytes a lane stores together
+constexpr uint32_t TBL_BIG = 2048, TBL_SMALL = 512;  // entries: one table of up to 11-bit codes, one of up to 9-bit codes
+
+// The decoder of zstd_decode.hip's flush_tasks_ring (no bit buffer: the next 32 unread bits are one v_alignbit of two ring dwords held
+// in registers, two symbols per 32 fresh bits, the ring upside down with a mirror slot) around a different memory side:
+//  * a lane requests whole aligned 128-byte LINES, from the one that holds the stream's last byte down to the one that holds its
+//    first: never an address outside the lines the stream itself touches (so no assumption about the arena around it), and a line is
+//    fetched once.  Bit positions count from the top of the first line; the bytes between the stream's end and that top are consumed
+//    before the first symbol;
+//  * request and commit of a batch are one stretch of straight-line code (request, decode a period, commit): the wait in front of
+//    the commit is a counted vmcnt, not the vmcnt(0) a loop-carried batch costs;
+//  * 128 decoded bytes per lane leave together.
+__global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const FastFrame* frames, const FastTask* tasks, const uint8_t* weights, uint32_t* redo)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t T[TBL_BIG + TBL_SMALL];
+    __shared__ uint32_t ringbuf[RING + 1][WAVE];
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    if (redo[r]) return;
+    const FastFrame* F = frames + r;
+    const uint32_t ntree = F->ntree, ntask = F->ntask;
+    uint32_t tlog0 = F->tlog[0], tlog1 = ntree > 1 ? F->tlog[1] : 0u;
+    uint32_t tb0 = 0, tb1 = TBL_BIG;
+    if (ntree > 1 && tlog1 > tlog0) {  // the wider table takes the large slot
+        tb0 = TBL_BIG;
+        tb1 = 0;
+    }
+    {
+        const uint32_t big = tlog0 > tlog1 ? tlog0 : tlog1, small = tlog0 > tlog1 ? tlog1 : tlog0;
+        if (big > 11 || (ntree > 1 && small > 9)) {
+            if (lane == 0) redo[r] = 1;
+            return;
+        }
+    }
+    fast_fill_table(T + tb0, weights + ((size_t)r * 2) * 256, F->nw[0], tlog0, lane);
+    if (ntree > 1) fast_fill_table(T + tb1, weights + ((size_t)r * 2 + 1) * 256, F->nw[1], tlog1, lane);
+    const uint8_t* src = b.src + b.src_off[r];
+    uint8_t* dst = b.dst + b.dst_off[r];
+    const bool mine = (uint32_t)lane < ntask;
+    FastTask t = { 0, 0, 0, 0 };
+    if (mine) t = tasks[(size_t)r * FAST_TASKS + lane];
+    uint32_t cnt = t.cnt & TASK_CNT;
+    const bool second = (t.cnt & TASK_TAB) != 0;
+    const uint32_t sL = 32u - (second ? tlog1 : tlog0);
+    const uint16_t* Tl = T + (second ? tb1 : tb0);
+    gu8* o = (gu8*)dst + t.out + ((t.cnt & TASK_REL) ? F->base_out : 0u);
+    const uint32_t nbytes = t.size;
+    uint32_t* ring = &ringbuf[0][0] + lane;
+    wave_lds_sync();
+
+    bool bad = false;
+    int32_t n = -1;
+    uint32_t widx = 0, end_bits = 0;
+    uint64_t nextline = 0, lowline = 0;  // the next request reads [nextline - 128, nextline); no line below lowline is read
+    if (mine) {
+        const uint8_t* p = src + t.src;
+        const uint32_t last = nbytes ? p[nbytes - 1] : 0u;
+        if (last == 0) {
+            bad = true;
+            cnt = 0;
+        } else {
+            const uint64_t e = (uint64_t)(p + nbytes);
+            nextline = (e + 127ull) & ~127ull;
+            lowline = (uint64_t)p & ~127ull;
+            const uint32_t pad = (uint32_t)(nextline - e);
+            n = -(int32_t)(8u * pad + 8u - (uint32_t)(31 - __clz((int)last)));  // bytes above the stream, padding bits, end mark
+            end_bits = 8u * (nbytes + pad);
+        }
+    }
+    typedef __attribute__((address_space(1))) const u32x4 gq4;
+#define FETCH(pend)                                                         \
+    do {                                                                    \
+        gcu8* q__ = (gcu8*)(nextline - 128ull);                             \
+        _Pragma("unroll") for (int v = 0; v < BATCH / 4; ++v) {             \
+            const u32x4 x__ = *(gq4*)(q__ + 16 * (BATCH / 4 - 1 - v));      \
+            pend[4 * v + 0] = x__.w;                                        \
+            pend[4 * v + 1] = x__.z;                                        \
+            pend[4 * v + 2] = x__.y;                                        \
+            pend[4 * v + 3] = x__.x;                                        \
+        }                                                                   \
+        nextline -= 128ull;                                                 \
+    } while (0)
+#define RING_PUT(pend)                                                                                 \
+    do {                                                                                               \
+        const uint32_t wb__ = (uint32_t)RING - (widx & (uint32_t)(RING - 1));                          \
+        _Pragma("unroll") for (int k = 0; k < BATCH; ++k) ring[(wb__ - (uint32_t)k) * WAVE] = pend[k]; \
+        if (wb__ == (uint32_t)RING) ring[0] = pend[0];                                                 \
+        widx += BATCH;                                                                                 \
+    } while (0)
+#define MORE() (nextline > lowline)
+    for (int f = 0; f < 2; ++f) {
+        uint32_t pend0[BATCH];
+        if (cnt > 0 && MORE()) {
+            FETCH(pend0);
+            RING_PUT(pend0);
+        }
+    }
+    int32_t tprev = n >> 5;
+    uint32_t w0 = ring[((((uint32_t)tprev) & (uint32_t)(RING - 1)) + 1u) * WAVE];
+    uint32_t w1 = ring[(((uint32_t)tprev) & (uint32_t)(RING - 1)) * WAVE];
+    uint32_t w2 = ring[(((uint32_t)tprev - 1u) & (uint32_t)(RING - 1)) * WAVE];
+#define HUF_PAIR(e1, e2)                                                     \
+    do {                                                                     \
+        const int32_t t__ = n >> 5;                                          \
+        const bool adv__ = t__ != tprev;                                     \
+        const uint32_t a__ = adv__ ? w1 : w0, b__ = adv__ ? w2 : w1;         \
+        w0 = a__;                                                            \
+        w1 = b__;                                                            \
+        tprev = t__;                                                         \
+        w2 = ring[(((uint32_t)t__ - 1u) & (uint32_t)(RING - 1)) * WAVE];     \
+        uint32_t x__ = __builtin_amdgcn_alignbit(a__, b__, (uint32_t)n);     \
+        e1 = Tl[x__ >> sL];                                                  \
+        x__ <<= (e1 >> 8);                                                   \
+        e2 = Tl[x__ >> sL];                                                  \
+    } while (0)
+#define QUAD(dstword)                                                                             \
+    do {                                                                                          \
+        uint32_t e1, e2, e3, e4;                                                                  \
+        HUF_PAIR(e1, e2);                                                                         \
+        n -= (int32_t)((e1 >> 8) + (e2 >> 8));                                                    \
+        HUF_PAIR(e3, e4);                                                                         \
+        n -= (int32_t)((e3 >> 8) + (e4 >> 8));                                                    \
+        dstword = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((e3 & 0xFFu) << 16) | (e4 << 24);         \
+    } while (0)
+    // room for a batch: at most RING - BATCH dwords of the ring are still unread
+#define ROOM() (widx - (((uint32_t)~n) >> 5) <= (uint32_t)(RING - BATCH))
+    typedef __attribute__((address_space(1), aligned(1))) u32x4 gs4;
+    // ---- whole bursts
+    while (__any(cnt >= (uint32_t)BURST)) {
+        if (cnt >= (uint32_t)BURST) {
+            uint32_t ow[BURST / 4];
+#pragma unroll
+            for (int h = 0; h < BURST / PERIOD; ++h) {
+                uint32_t pend[BATCH];
+                const bool issue = ROOM() && MORE();
+                if (issue) FETCH(pend);
+#pragma unroll
+                for (int q = h * PERIOD / 4; q < (h + 1) * PERIOD / 4; ++q) QUAD(ow[q]);
+                if (h == BURST / PERIOD - 1) {  // the stores go out in front of the last commit: its wait is vmcnt(stores)
+#pragma unroll
+                    for (int q = 0; q < BURST / 16; ++q) {
+                        const u32x4 ov = { ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3] };
+                        *(gs4*)(o + 16 * q) = ov;
+                    }
+                }
+                if (issue) RING_PUT(pend);
+            }
+            o += BURST;
+            cnt -= BURST;
+        }
+    }
+    // ---- the rest of a stream: groups of 16 symbols, then symbol by symbol
+    while (__any(cnt >= 16u)) {
+        uint32_t pend[BATCH];
+        const bool issue = cnt >= 16u && ROOM() && MORE();
+        if (issue) FETCH(pend);
+        if (cnt >= 16u) {
+            uint32_t ow[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) QUAD(ow[q]);
+            const u32x4 ov = { ow[0], ow[1], ow[2], ow[3] };
+            *(gs4*)o = ov;
+            o += 16;
+            cnt -= 16;
+        }
+        if (issue) RING_PUT(pend);
+    }
+    while (__any(cnt > 0)) {
+        uint32_t pend[BATCH];
+        const bool issue = cnt > 0 && ROOM() && MORE();
+        if (issue) FETCH(pend);
+#pragma unroll 1
+        for (int i = 0; i < 16; ++i) {
+            if (cnt > 0) {
+                uint32_t e1, e2;
+                HUF_PAIR(e1, e2);
+                (void)e2;  // only the first symbol of the pair is taken
+                n -= (int32_t)(e1 >> 8);
+                *o = (uint8_t)e1;
+                ++o;
+                --cnt;
+            }
+        }
+        if (issue) RING_PUT(pend);
+    }
+#undef HUF_PAIR
+#undef QUAD
+#undef ROOM
+#undef MORE
+#undef RING_PUT
+#undef FETCH
+    if (mine && !bad && n != -(int32_t)end_bits) bad = true;  // every bit of the stream must be consumed, none beyond
+    if (__any(bad)) {
+        if (lane == 0) redo[r] = 1;
+    } else if (F->nseq == 0 && lane == 0) {
+        b.result[r] = F->fcs;
+    }
+}
+
+// ---- one wavefront per frame: the zero-run block ----------------------------------------------------------------------------------------
+constexpr uint32_t RUNS_LDS = 8704;
+__global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const FastFrame* frames, const SeqDTables* dtabs, uint32_t* redo)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[RUNS_LDS / 4];
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    if (redo[r]) return;
+    const FastFrame* F = frames + r;
+    const uint32_t nseq = F->nseq;
+    if (nseq == 0) return;
+    const uint8_t* src = b.src + b.src_off[r];
+    uint8_t* dst = b.dst + b.dst_off[r];
+    const uint2 llt = dtabs->ll[lane], mlt = dtabs->ml[lane];
+    uint2* pairs = reinterpret_cast<uint2*>(dst + F->ws_pairs);
+    const uint32_t regen = F->b0_regen, base_out = F->base_out;
+    uint32_t total = 0, ok = 3;
+    if (F->cp_count)
+        ok = zero_run_chain_segments(src + F->seq_off, F->seq_len, pairs, nseq, llt, mlt, regen, src + F->cp_off, F->cp_count, F->cp_spacing, lane, &total, lds,
+                                     RUNS_LDS);
+    if (ok == 3) ok = zero_run_chain(src + F->seq_off, F->seq_len, pairs, nseq, llt, mlt, 6, 6, regen, lane, &total);
+    if (ok != 1 || total != base_out) {  // corrupt, not a pure zero-run block, or not what the other blocks leave of the content size
+        if (lane == 0) redo[r] = 1;
+        return;
+    }
+    __syncthreads();  // the pairs are in memory
+    const uint32_t end = place_zero_runs(dst, pairs, nseq, dst + F->ws_lit, 2u, regen, 0u, F->fcs, F->block_max, reinterpret_cast<uint8_t*>(lds), RUNS_LDS - 8u, lane);
+    if (lane == 0) {
+        if (end != base_out) redo[r] = 1;
+        else b.result[r] = F->fcs;
+    }
+}
+
+}  // namespace
+
+size_t zstd_fast_meta_bytes(uint32_t n_reads)
+{
+    return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4) + 1024;
+}
+
+hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, hipStream_t s)
+{
+    const uint32_t n = b.n_reads;
+    if (n == 0) return hipSuccess;
+    uint8_t* m = reinterpret_cast<uint8_t*>(meta);
+    FastFrame* frames = reinterpret_cast<FastFrame*>(m);
+    m += (size_t)n * sizeof(FastFrame);
+    FastTask* tasks = reinterpret_cast<FastTask*>(m);
+    m += (size_t)n * FAST_TASKS * sizeof(FastTask);
+    uint8_t* weights = m;
+    m += (size_t)n * 512;
+    uint32_t* redo = reinterpret_cast<uint32_t*>(m);
+    hipLaunchKernelGGL(fast_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, frames, tasks, redo);
+    hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo);
+    hipLaunchKernelGGL(fast_streams_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, tasks, weights, redo);
+    hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return launch_zstd_decode_only(b, toosmall_code, seq_dtables, redo, s);  // whatever is not of the shape, and every error verdict
+}
+
+}  // namespace vbzhip
