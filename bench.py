@@ -110,6 +110,84 @@ def cpu_baseline_u32(n_buffers, count, min_seconds=6.0):
     }
 
 
+def decode_reference_frames(codec, n_reads=16384, launches=5):
+    """Decode rate on frames THE REFERENCE wrote: every vbz file in existence was written by
+    vbz_compress -> ZSTD_compress (vbz/vbz.cpp:194-207: one 128 KB block per read, ~1 100 general sequences, four long Huffman
+    streams), and such frames carry none of this library's decoder hints.  Frames of reads [0, n_reads) of the same generator are
+    written by the oracle (the reference path restated + the pinned libzstd, level 1) on the host's cores, decoded by the batched
+    entry point `launches` times, and every decoded read is compared with the generator's samples on the device.  Never `value`."""
+    import concurrent.futures
+
+    import numpy as np
+    import torch
+
+    from vbz_compression_amd import batch
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    dev = codec.device
+    oo = O.options(True, 2, 1, 1)
+    opts = codec.options(True, 2, 1, 1)
+    O.lib()
+
+    def make(i):
+        a = O.synth_signal(5, i, O.synth_read_length(5, i))
+        return a.nbytes, O.compress(a, oo)
+
+    t0 = time.perf_counter()
+    with concurrent.futures.ThreadPoolExecutor(max(1, usable_cpus()[0])) as ex:   # (ctypes calls release the GIL)
+        made = list(ex.map(make, range(n_reads)))
+    t_make = time.perf_counter() - t0
+    sizes = torch.tensor([m[0] for m in made], dtype=torch.int64)
+    fsizes = torch.tensor([len(m[1]) for m in made], dtype=torch.int64)
+    foff, ftotal = batch.layout(fsizes, 64)
+    arena = np.zeros(ftotal + 64, np.uint8)
+    for (_, f), o in zip(made, foff.tolist()):
+        arena[o : o + len(f)] = f
+    del made
+    src = torch.from_numpy(arena).to(dev)
+    off, total = batch.layout(sizes, 64)
+    want = torch.zeros(total, dtype=torch.uint8, device=dev)
+    lens = (sizes // 2).to(torch.int32).to(dev)
+    offd = off.to(dev)
+    codec.synth_signal(5, 0, want, offd, lens)
+    back = torch.zeros(total, dtype=torch.uint8, device=dev)
+    res = torch.zeros(n_reads, dtype=torch.int32, device=dev)
+    foffd, fs32, s32 = foff.to(dev), fsizes.to(torch.int32).to(dev), sizes.to(torch.int32).to(dev)
+
+    def go():
+        codec.decompress(src, foffd, fs32, back, offd, s32, res, opts)
+
+    go()
+    torch.cuda.synchronize()
+    ok = bool((res == s32).all()) and torch.equal(back, want)
+    codec.profile_reset()
+    codec.profile(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        go()
+    e1.record()
+    torch.cuda.synchronize()
+    codec.profile(False)
+    prof = codec.profile_read()
+    ms = e0.elapsed_time(e1) / launches
+    raw = int(sizes.sum())
+    per = {k: round(v[1] / max(v[0], 1), 4) for k, v in prof.items()}
+    c = float(fsizes.sum()) / (raw / 2)   # frame bytes per sample
+    return {
+        "MBps": round(raw / (ms * 1e-3) / 1e6, 1), "unit": "MB/s of decoded int16 signal", "reads": n_reads, "raw_MB": round(raw / 1e6, 1), "ms_per_launch": round(ms, 3),
+        "kernels_ms_per_launch": per,
+        "entropy_stage_ms_per_2048_reads": round(per.get("zstd_decode", 0.0) * 2048 / n_reads, 4),
+        "hbm_frac": round((2 + c) * (raw / 2) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+        "ratio": round(raw / float(fsizes.sum()), 4), "verified": ok,
+        "frames": "written by the oracle: the reference path restated + libzstd %s level 1 (one 128 KB block per read, general sequences, "
+                  "no decoder hints), %d host threads, %.1f s" % ((O.lib().vbo_zstd_version() or b"?").decode(), usable_cpus()[0], t_make),
+        "note": "decode only, inputs resident in HBM; never `value`",
+    }
+
+
 def cpu_baseline(min_seconds=8.0, n_reads=16384):
     """The oracle (port of the reference CPU path: the int16 zig-zag stage in SSSE3 form like the reference's hot path --
     oracle/vbz_oracle_simd.c, own code, byte-identical to the scalar restatement -- plus the pinned libzstd, dlopen'd) timed on
@@ -609,6 +687,8 @@ def run_rank(args):
             out["host_resident"] = {"encode_decode_MBps": h["encode_decode_MBps"], "encode_MBps": h["encode_MBps"], "decode_MBps": h["decode_MBps"],
                                     "h2d_GBps": h["h2d_GBps"], "d2h_GBps": h["d2h_GBps"], "round_trip_ok": h["round_trip_ok"],
                                     "note": "PCIe-inclusive rate with pinned host buffers both ends (tools/pcie_pipeline.py); never `value`"}
+        if world == 1 and not args.no_cpu and not fixed_job:
+            out["decode_reference_frames"] = decode_reference_frames(codec)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
             if "single_socket" in out["cpu_baseline"]:
@@ -748,18 +828,18 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier):
         n = 0
         for it in range(k + 2):
             if it == 2:
-                t0 = time.perf_counter()
+                tc0 = time.perf_counter()
             n = L.vbz_compress(h.ctypes.data, nbytes, cbuf.ctypes.data, bound, ctypes.byref(o2))
-        t1 = time.perf_counter()
+        tc1 = time.perf_counter()
         assert not _lib.is_error(n) and n == len(f)
         for it in range(k + 2):
             if it == 2:
-                t1 = time.perf_counter()
+                td0 = time.perf_counter()
             m = L.vbz_decompress(cbuf.ctypes.data, n, dbuf.ctypes.data, nbytes, ctypes.byref(o2))
-        t2 = time.perf_counter()
+        td1 = time.perf_counter()
         assert m == nbytes and dbuf.tobytes() == h.tobytes()
-        out["host_api"] = {"vbz_compress_ms": round((t1 - t0) / k * 1e3, 3), "vbz_decompress_ms": round((t2 - t1) / k * 1e3, 3),
-                           "encode_decode_MBps": round(nbytes / ((t2 - t0) / k) / 1e6, 1),
+        out["host_api"] = {"vbz_compress_ms": round((tc1 - tc0) / k * 1e3, 3), "vbz_decompress_ms": round((td1 - td0) / k * 1e3, 3),
+                           "encode_decode_MBps": round(nbytes / (((tc1 - tc0) + (td1 - td0)) / k) / 1e6, 1),
                            "note": "one buffer per call through include/vbz.h, pageable host memory in and out, buffers reused by the caller"}
     if world == 1 and not args.no_cpu:
         if kind == "u32":

@@ -22,8 +22,11 @@
  *     (reference vbz/vbz.cpp:321-329 turns VBZ_INPUT_SIZE_ERROR into 2).
  *   - the zstd stage is this library's own encoder: frames are standard zstd (RFC 8878) and decode
  *     with any libzstd / the reference's vbz_decompress, but are not byte-identical to libzstd's.
- *     A compressed buffer may end in one zstd skippable frame (magic 0x184D2A5B, <= 272 bytes) with
- *     checkpoints for this library's parallel decoder; libzstd skips it (RFC 8878 3.1.2).
+ *     A compressed buffer may end in zstd skippable frames with hints for this library's parallel decoder, which
+ *     libzstd skips (RFC 8878 3.1.2): checkpoints of the sequences section (magic 0x184D2A5B, <= 272 bytes) and, behind
+ *     reads of half a megabyte or more (and behind every read of a small batch), an index of the frame's spans (magic
+ *     0x184D2A5C, 8 bytes per 8-64 KB of content: not bounded by a constant).  vbz_gpu_set_trailers / VBZ_HIP_TRAILERS=0
+ *     writes plain single frames.
  *   - the decoder reads RFC 8878 frames only.  zstd's legacy frame formats (v0.2 ... v0.7, magic 0xFD2FB522 ... 27), which
  *     a libzstd built with ZSTD_LEGACY_SUPPORT also decodes, are VBZ_ZSTD_ERROR here (no vbz writer ever produced them;
  *     32 files of the reference's fuzz corpus start with the v0.7 magic).  A frame may carry a Dictionary_ID field of 0

@@ -14,20 +14,25 @@
  * Calls are asynchronous on the context's stream; results (per-read sizes or vbz error codes) land
  * in batch->result in stream order.
  *
- * How a batch is laid onto the device is the library's business and never changes a result, only speed:
+ * How a batch is laid onto the device is the library's business and never changes the DECODED data.  The compressed bytes
+ * (and so result[i] of a compress call) may depend on it: reads on the large-read path are coded as spans and get no
+ * long-repeat matcher, a batch too small to fill the device is coded as spans too, and the matcher is used only where
+ * dst_cap[i] leaves room for its workspace above the worst-case frame.  The library may write anywhere inside a read's
+ * destination slot [dst_off[i], dst_off[i] + dst_cap[i]) (workspace, staging), not only the result[i] bytes it reports.
  *   - the shape rule: a batch whose average read is half a megabyte or more (a 10 M-element buffer), or which is too
  *     small to fill the device with one wavefront per read (up to 96 MB of reads of 64 KB and more: one HDF5 chunk per
  *     call), runs on the large-read path, many workgroups per read;
  *   - per-read routing: in any other batch the reads of 512 KB and more (at most 16 of them, 64 MB in all;
- *     the largest first) are coded on that path beside the rest of the batch, on a second stream of the
+ *     the first in batch order; none if the batch holds more than 1024 such reads) are coded on that path beside the rest of the batch, on a second stream of the
  *     context that is forked from and joined to the context's stream inside the call -- to the caller the
  *     call is still one unit of work in stream order;
  *   - a read whose bytes repeat at one distance (a cycled template) gets that distance coded as zstd matches
  *     at every zstd_compression_level (the reference passes its level to libzstd, whose matcher is on at all
  *     of them); reads of half a megabyte and more do not.
- * Descriptor tables are untrusted like the data: sizes and offsets that do not fit the declared arenas
- * (src_bytes / dst_bytes) give the read VBZ_INPUT_SIZE_ERROR or VBZ_DESTINATION_SIZE_ERROR, never an
- * access outside the arenas.
+ * Descriptor tables are untrusted like the data: before any other kernel runs, one thread per read checks
+ * src_off + src_size <= src_bytes and dst_off + dst_cap <= dst_bytes (64-bit arithmetic); a read that fails gets
+ * VBZ_INPUT_SIZE_ERROR or VBZ_DESTINATION_SIZE_ERROR and none of its addresses is ever formed
+ * (vbz_gpu_compress_batch / vbz_gpu_decompress_batch; the stage-level entry points below trust their tables).
  */
 #ifndef VBZ_GPU_H_MI355X
 #define VBZ_GPU_H_MI355X

@@ -1220,3 +1220,140 @@ def test_zstd_decode_libzstd_frames_of_several_blocks():
         back = G.decompress(frames, [a.nbytes for a in cases], go)
         for a, b in zip(cases, back):
             assert not isinstance(b, int) and b.tobytes() == a.tobytes(), (a.dtype, len(a), level, "batch")
+
+
+def test_descriptor_tables_are_checked_against_the_declared_arenas():
+    """include/vbz_gpu.h: the descriptor table is untrusted like the data.  A read whose source slot does not lie inside
+    [0, src_bytes) gets VBZ_INPUT_SIZE_ERROR, one whose destination slot does not lie inside [0, dst_bytes) gets
+    VBZ_DESTINATION_SIZE_ERROR (64-bit arithmetic: offsets near 2^64 do not wrap), the other reads of the batch are coded as
+    usual and nothing outside the arenas is touched (canaries behind both arenas)."""
+    import torch
+
+    import gpu_util as G
+    from vbz_compression_amd import _lib, batch
+
+    c = G.codec()
+    dev = c.device
+    L = _lib.load()
+    reads = [O.synth_signal(5, 40 + i, 3000 + 500 * i) for i in range(8)]
+    for sized in (False, True):
+        opts = c.options(True, 2, 1, 1)
+        arena, off, sizes = G._pack(reads)
+        src = torch.from_numpy(arena).to(dev)
+        caps = [L.vbz_max_compressed_size(a.nbytes, ctypes.byref(opts)) for a in reads]
+        doff, dtotal = batch.layout([x + 32 for x in caps], 64)
+        canary = 4096
+        dst_all = torch.full((dtotal + 64 + canary,), 0xA5, dtype=torch.uint8, device=dev)
+        dst = dst_all[: dtotal + 64]
+        src_off = off.clone()
+        src_size = torch.tensor(sizes, dtype=torch.int64)
+        dst_off = doff.clone()
+        dst_cap = torch.tensor(caps, dtype=torch.int64)
+        src_off[1] = src.numel() - 10                 # sticks out of the source arena
+        src_off[2] = (1 << 62)                        # nowhere near it
+        src_size[3] = 0xFFFFFFF0                      # a size that is no size
+        dst_off[4] = dst.numel() - 8                  # slot sticks out of the destination arena
+        dst_cap[5] = 0xFFFFFF00                       # capacity beyond the arena
+        dst_off[6] = -16                              # 2^64 - 16: offset + capacity would wrap
+        want = {1: _lib.VBZ_INPUT_SIZE_ERROR, 2: _lib.VBZ_INPUT_SIZE_ERROR, 3: _lib.VBZ_INPUT_SIZE_ERROR,
+                4: _lib.VBZ_DESTINATION_SIZE_ERROR, 5: _lib.VBZ_DESTINATION_SIZE_ERROR, 6: _lib.VBZ_DESTINATION_SIZE_ERROR}
+
+        def i32(t):
+            return torch.where(t >= 2**31, t - 2**32, t).to(torch.int32).to(dev)
+
+        result = torch.full((len(reads),), -8, dtype=torch.int32, device=dev)
+        c.compress(src, src_off.to(dev), i32(src_size), dst, dst_off.to(dev), i32(dst_cap), result, opts, sized=sized)
+        torch.cuda.synchronize()
+        res = [int(x) & 0xFFFFFFFF for x in result.cpu().tolist()]
+        host = dst_all.cpu().numpy()
+        assert (host[dtotal + 64:] == 0xA5).all()
+        frames = {}
+        for i, a in enumerate(reads):
+            if i in want:
+                assert res[i] == want[i], (sized, i, hex(res[i]))
+            else:
+                assert not _lib.is_error(res[i])
+                f = host[int(doff[i]) : int(doff[i]) + res[i]].copy()
+                assert O.decompress(f, a.nbytes, O.options(True, 2, 1, 1), sized=sized).tobytes() == a.tobytes()
+                frames[i] = f
+        # the same table checks on the way back
+        good = sorted(frames)
+        fr = [frames[i] for i in good]
+        farena, foff, fsizes = G._pack(fr)
+        fsrc = torch.from_numpy(farena).to(dev)
+        ocaps = [reads[i].nbytes for i in good]
+        ooff, ototal = batch.layout([x + 32 for x in ocaps], 64)
+        out_all = torch.full((ototal + 64 + canary,), 0x5A, dtype=torch.uint8, device=dev)
+        out = out_all[: ototal + 64]
+        fo = foff.clone()
+        oo = ooff.clone()
+        fo[0] = fsrc.numel() + 5
+        oo[1] = out.numel() - 3
+        result = torch.full((len(good),), -8, dtype=torch.int32, device=dev)
+        c.decompress(fsrc, fo.to(dev), torch.tensor(fsizes, dtype=torch.int32, device=dev), out, oo.to(dev),
+                     torch.tensor(ocaps, dtype=torch.int32, device=dev), result, opts, sized=sized)
+        torch.cuda.synchronize()
+        res = [int(x) & 0xFFFFFFFF for x in result.cpu().tolist()]
+        host = out_all.cpu().numpy()
+        assert (host[ototal + 64:] == 0x5A).all()
+        assert res[0] == _lib.VBZ_INPUT_SIZE_ERROR and res[1] == _lib.VBZ_DESTINATION_SIZE_ERROR
+        for k in range(2, len(good)):
+            a = reads[good[k]]
+            assert res[k] == a.nbytes and host[int(ooff[k]) : int(ooff[k]) + a.nbytes].tobytes() == a.tobytes()
+
+
+def test_batched_own_frame_decoder_and_its_fallbacks():
+    """zstd_decode_fast.hip decodes frames of the shape this library writes with one lane per frame for the headers and one
+    wavefront per frame for the streams; everything else -- frames libzstd wrote, frames with a window descriptor or raw blocks,
+    damaged frames -- must come out of the same call exactly as the one-wavefront decoder (VBZ_HIP_FAST_DECODE=0) gives it:
+    same bytes, same verdicts, in one batch, with both kinds of frame next to each other."""
+    import subprocess
+    import sys
+
+    import gpu_util as G
+
+    rng = np.random.default_rng(77)
+    reads = [O.synth_signal(5, 300 + i, n) for i, n in enumerate([100000, 90001, 33333, 4096, 17, 0, 1, 250000])]
+    reads.append(np.zeros(120000, np.int16))                                     # RLE / raw blocks: not the fast shape
+    reads.append(rng.integers(-32768, 32767, 60000, endpoint=True).astype(np.int16))   # incompressible: raw blocks
+    reads.append(np.tile(O.synth_signal(5, 1, 7000), 20))                        # repeated template: general sequences
+    opts = G.codec().options(True, 2, 1, 1)
+    os.environ["VBZ_HIP_SEGMENTED"] = "0"   # (a handful of reads would take the large-read path otherwise)
+    code = r"""
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gpu_util as G, oracle_lib as O
+reads, = pickle.load(open(sys.argv[1], 'rb'))
+opts = G.codec().options(True, 2, 1, 1)
+own = G.compress(reads, opts)
+ref = [O.compress(a, O.options(True, 2, 1, 1)) for a in reads]
+frames, caps = [], []
+for a, f, g in zip(reads, own, ref):
+    frames += [f, g]; caps += [a.nbytes, a.nbytes]
+# damaged copies of own frames: a flipped byte in a stream, a truncated frame, a flipped byte in the tree description
+for k in (0, 1, 2):
+    f = own[k].copy(); f[len(f) // 2] ^= 0x40; frames.append(f); caps.append(reads[k].nbytes)
+    f = own[k][: len(own[k]) - 7].copy(); frames.append(f); caps.append(reads[k].nbytes)
+    f = own[k].copy(); f[40] ^= 0x08; frames.append(f); caps.append(reads[k].nbytes)
+    frames.append(own[k].copy()); caps.append(reads[k].nbytes - 2)      # destination too small
+out = G.decompress(frames, caps, opts)
+pickle.dump([o if isinstance(o, int) else o.tobytes() for o in out], open(sys.argv[2], 'wb'))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    import pickle
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        pickle.dump((reads,), open(os.path.join(td, "in.pkl"), "wb"))
+        outs = {}
+        for fast in ("1", "0"):
+            env = dict(os.environ, VBZ_HIP_FAST_DECODE=fast, VBZ_HIP_SEGMENTED="0")
+            subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.pkl"), os.path.join(td, "out%s.pkl" % fast)], check=True, env=env)
+            outs[fast] = pickle.load(open(os.path.join(td, "out%s.pkl" % fast), "rb"))
+    os.environ.pop("VBZ_HIP_SEGMENTED", None)
+    assert len(outs["1"]) == len(outs["0"]) == 2 * len(reads) + 12
+    for i, (a, b) in enumerate(zip(outs["1"], outs["0"])):
+        assert a == b, i
+    for i, a in enumerate(reads):   # and both are right
+        assert outs["1"][2 * i] == a.tobytes() and outs["1"][2 * i + 1] == a.tobytes()
+    assert sum(isinstance(o, int) for o in outs["1"][2 * len(reads):]) >= 9

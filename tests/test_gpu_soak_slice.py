@@ -1,0 +1,47 @@
+"""A bounded slice of the soak tools inside the suite the driver runs: tools/soak.py and
+tools/soak_corrupt.py draw random batches / damage device-written buffers and cross-check GPU <-> oracle in all directions; the
+out-of-suite runs take minutes to hours, these take about a minute in all.  Fixed seeds, three launch paths (by batch shape, the
+one-wavefront / batched kernels forced, the large-read path forced)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(tool, seconds, seed, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", tool), "--seconds", str(seconds), "--seed", str(seed)], env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("seed,env", [(3, {}), (20260902, {"VBZ_HIP_SEGMENTED": "0"}), (7, {"VBZ_HIP_SEGMENTED": "1"})])
+def test_soak_slice(seed, env):
+    out = _run("soak.py", 18, seed, env)
+    assert "reads" in out
+
+
+def test_soak_corrupt_slice():
+    _run("soak_corrupt.py", 10, 5, {"VBZ_HIP_SEGMENTED": "0"})
+
+
+def test_config5_workload_at_one_gpu():
+    """BASELINE configs[4] (a fixed job sharded over the ranks through the work queue) at N = 1, reduced: strong scaling, the
+    rank's range covers the whole job, every batch verified."""
+    import json
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "config5", "--total-reads", "20000", "--reads", "4096",
+                        "--no-cpu", "--no-pcie", "--no-stages"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["rank_imbalance"] == pytest.approx(1.0)
+    assert d["config"]["distinct_reads"] == 20000 and d["steps"] == 5   # 20 000 reads in batches of 4 096
+    assert d["config"]["workload"].startswith("configs[4]: a FIXED job of 20000 reads")
+    assert 2.3 < d["ratio"] < 2.5

@@ -168,13 +168,16 @@ __global__ __launch_bounds__(1024) void route_pick_kernel(ReadBatch b, const uin
             }
             __syncthreads();
         }
+    // More long reads than the list holds: WHICH of them got onto it depends on the order the atomics arrived in, so nothing is
+    // routed (the same batch must give the same compressed bytes every time; such a batch is nearly one the shape rule takes anyway)
+    const bool overflow = *cand_count > ROUTE_CAND_MAX;
     if (tid == 0) {   // (a handful of entries: one thread walks them)
         uint64_t bytes = 0;
         uint32_t taken = 0;
         for (uint32_t j = 0; j < n; ++j) {
             const uint32_t i = key[j];
             const uint32_t g = b.gate ? b.gate[i] : 0u;
-            if (taken < max_reads && bytes + raw_size[i] <= max_bytes) {
+            if (!overflow && taken < max_reads && bytes + raw_size[i] <= max_bytes) {
                 bytes += raw_size[i];
                 l_src_off[taken] = b.src_off[i];
                 l_src_size[taken] = b.src_size[i];
@@ -198,15 +201,31 @@ __global__ void route_results_kernel(const uint32_t* l_result, const uint32_t* l
     if (j < max_reads && j < *l_count) result[l_map[j]] = l_result[j];
 }
 
+// The descriptor table of a batch is untrusted like the data (include/vbz_gpu.h): a read whose source or destination slot does not
+// lie inside the arena the caller declared gets its error here, before any kernel forms an address from it.
+__global__ void validate_batch_kernel(uint32_t n, const uint64_t* src_off, const uint32_t* src_size, uint64_t src_bytes,
+                                      const uint64_t* dst_off, const uint32_t* dst_cap, uint64_t dst_bytes, uint32_t* gate)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t so = src_off[i], d0 = dst_off[i];
+    uint32_t g = 0;
+    if (so > src_bytes || (uint64_t)src_size[i] > src_bytes - so) g = E_INPUT_SIZE;
+    else if (d0 > dst_bytes || (uint64_t)dst_cap[i] > dst_bytes - d0) g = E_DESTINATION_SIZE;
+    gate[i] = g;
+}
+
 __global__ void parse_sized_kernel(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
-                                   const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
+                                   const uint32_t* dst_cap, const uint32_t* gate_in, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
                                    uint32_t* gate)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t sz = src_size[i];
     uint32_t g = 0, orig = 0;
-    if (sz < 4) {
+    if (gate_in && gate_in[i] >= GATE_SKIP) {
+        g = gate_in[i];
+    } else if (sz < 4) {
         g = E_INPUT_SIZE;  // vbz/vbz.cpp:345-348
     } else {
         const uint8_t* p = src + src_off[i];
@@ -334,12 +353,20 @@ hipError_t launch_route_results(const uint32_t* l_result, const uint32_t* l_map,
 }
 
 hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
-                              const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
+                              const uint32_t* dst_cap, const uint32_t* gate_in, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
                               uint32_t* gate, hipStream_t s)
 {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(parse_sized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, src, src_off, src_size, dst_cap, pay_off,
+    hipLaunchKernelGGL(parse_sized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, src, src_off, src_size, dst_cap, gate_in, pay_off,
                        pay_size, orig_size, gate);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate_batch(uint32_t n, const uint64_t* src_off, const uint32_t* src_size, uint64_t src_bytes, const uint64_t* dst_off,
+                                 const uint32_t* dst_cap, uint64_t dst_bytes, uint32_t* gate, hipStream_t s)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(validate_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, src_off, src_size, src_bytes, dst_off, dst_cap, dst_bytes, gate);
     return hipGetLastError();
 }
 

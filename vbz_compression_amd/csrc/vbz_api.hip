@@ -62,6 +62,7 @@ struct vbz_gpu_ctx
     DevBuf seqdtab;   // decoding tables of the same distributions
     DevBuf segmeta;   // segment / span tables of the large-read path
     DevBuf spanmeta, spantmp;  // span tables and temporary slots of the entropy stage in the large-read path
+    DevBuf vgate;     // verdicts on the caller's descriptor table (one word per read)
     DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
     bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
@@ -631,20 +632,37 @@ int route_join(vbz_gpu_ctx* c, const Routed& r, uint32_t* result)
     return 0;
 }
 
+// The caller's descriptor table is untrusted (vbz_gpu.h): one thread per read checks its slots against the declared arenas before any
+// other kernel forms an address from them; the verdicts are the gate every launch group of the call starts from.
+int validate_descriptors(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, ReadBatch* rb)
+{
+    if (!ensure(c, c->vgate, (size_t)bt->n_reads * 4 + 64)) return -1;
+    uint32_t* g = reinterpret_cast<uint32_t*>(c->vgate.p);
+    HIPCHK(c, launch_validate_batch(bt->n_reads, bt->src_off, bt->src_size, bt->src_bytes, bt->dst_off, bt->dst_cap, bt->dst_bytes, g, c->stream), "validate launch");
+    rb->gate = g;
+    return 0;
+}
+
 int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
 {
     const uint32_t n = bt->n_reads;
     if (n == 0) return 0;
     ReadBatch rb = to_rb(bt);
+    if (validate_descriptors(c, bt, &rb) != 0) return -1;
     const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n);
     if (by_shape || !routing_applies(c, o, bt->src_bytes, n)) return compress_group(c, rb, bt->src_bytes, o, sized, by_shape);
     Routed r;
     if (route(c, rb, bt->src_size, &r) != 0) return -1;
     ReadBatch small = rb;
     small.gate = r.gate_small;
-    if (c->routing != 2 && compress_group(c->large, r.large, ROUTE_MAX_BYTES, o, sized, true) != 0) return -1;   // (first: its launches are short)
-    if (compress_group(c, small, bt->src_bytes, o, sized, false) != 0) return -1;
-    return route_join(c, r, bt->result);
+    // (the second group first: its launches are short.)  Whatever fails from here on, the second stream is joined before the call
+    // returns -- it may still be writing the caller's arenas -- and its error message becomes the context's
+    int rc = 0;
+    if (c->routing != 2 && compress_group(c->large, r.large, ROUTE_MAX_BYTES, o, sized, true) != 0) rc = -1;
+    if (rc == 0 && compress_group(c, small, bt->src_bytes, o, sized, false) != 0) rc = -1;
+    if (rc != 0 && c->error.empty() && !c->large->error.empty()) c->error = c->large->error;
+    if (route_join(c, r, bt->result) != 0) rc = -1;
+    return rc;
 }
 
 int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
@@ -653,6 +671,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     if (n == 0) return 0;
     hipStream_t s = c->stream;
     ReadBatch rb = to_rb(bt);
+    if (validate_descriptors(c, bt, &rb) != 0) return -1;
     if (sized) {  // vbz.cpp:332-366: strip the header, the original size becomes the exact destination size
         if (!ensure(c, c->meta, (size_t)n * 24 + 512)) return -1;
         MetaCarver mc(c->meta.p);
@@ -661,7 +680,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         uint32_t* orig_size = mc.take<uint32_t>(n);
         uint32_t* gate = mc.take<uint32_t>(n);
         Timed t(c, "parse_sized");
-        HIPCHK(c, launch_parse_sized(n, rb.src, bt->src_off, bt->src_size, bt->dst_cap, pay_off, pay_size, orig_size, gate, s),
+        HIPCHK(c, launch_parse_sized(n, rb.src, bt->src_off, bt->src_size, bt->dst_cap, rb.gate, pay_off, pay_size, orig_size, gate, s),
                "parse_sized launch");
         rb.src_off = pay_off;
         rb.src_size = pay_size;
@@ -674,9 +693,12 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     if (route(c, rb, rb.dst_cap, &r) != 0) return -1;   // by the decoded size
     ReadBatch small = rb;
     small.gate = r.gate_small;
-    if (c->routing != 2 && decompress_group(c->large, r.large, ROUTE_MAX_BYTES, o, true) != 0) return -1;
-    if (decompress_group(c, small, bt->dst_bytes, o, false) != 0) return -1;
-    return route_join(c, r, bt->result);
+    int rc = 0;   // (as in compress_batch_impl: the second stream is joined whatever happens)
+    if (c->routing != 2 && decompress_group(c->large, r.large, ROUTE_MAX_BYTES, o, true) != 0) rc = -1;
+    if (rc == 0 && decompress_group(c, small, bt->dst_bytes, o, false) != 0) rc = -1;
+    if (rc != 0 && c->error.empty() && !c->large->error.empty()) c->error = c->large->error;
+    if (route_join(c, r, bt->result) != 0) rc = -1;
+    return rc;
 }
 
 }  // namespace
@@ -768,7 +790,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);

@@ -138,10 +138,15 @@ hipError_t launch_route_reads(const ReadBatch& b, const uint32_t* raw_size, uint
                               uint32_t* l_count, uint32_t* cand, hipStream_t s);   // cand: route_cand_words() words of scratch
 size_t route_cand_words();
 hipError_t launch_route_results(const uint32_t* l_result, const uint32_t* l_map, const uint32_t* l_count, uint32_t max_reads, uint32_t* result, hipStream_t s);
-// sized decode: read the 4-byte headers -> payload offsets/sizes, original sizes, gate errors
+// sized decode: read the 4-byte headers -> payload offsets/sizes, original sizes, gate errors (gate_in, nullable: reads that
+// already carry an error keep it and are not looked at)
 hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* src_off, const uint32_t* src_size,
-                              const uint32_t* dst_cap, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
+                              const uint32_t* dst_cap, const uint32_t* gate_in, uint64_t* pay_off, uint32_t* pay_size, uint32_t* orig_size,
                               uint32_t* gate, hipStream_t s);
+// descriptor table against the declared arenas: gate[i] = 0, E_INPUT_SIZE (source slot outside [0, src_bytes)) or
+// E_DESTINATION_SIZE (destination slot outside [0, dst_bytes)); 64-bit arithmetic
+hipError_t launch_validate_batch(uint32_t n, const uint64_t* src_off, const uint32_t* src_size, uint64_t src_bytes, const uint64_t* dst_off,
+                                 const uint32_t* dst_cap, uint64_t dst_bytes, uint32_t* gate, hipStream_t s);
 // integer_size == 0 && level == 0: per-read copy (reference vbz/vbz.cpp:130-133)
 hipError_t launch_copy_bytes(const ReadBatch& b, uint32_t hdr, hipStream_t s);
 hipError_t launch_synth_lengths(uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len, hipStream_t s);
