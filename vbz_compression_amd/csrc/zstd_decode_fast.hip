@@ -23,7 +23,6 @@
 // Replaces, like zstd_decode.hip, the reference's ZSTD_decompress call (vbz/vbz.cpp:236-273).
 #include "vbz_kernels.h"
 #include "zstd_runs.h"
-#include <stdlib.h>
 
 namespace vbzhip {
 
@@ -724,140 +723,9 @@ __global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const F
     }
 }
 
-// ---- placement of a zero-run block, by output position ---------------------------------------------------------------------------------
-// The block's content is, sequence after sequence, ll literals and then ml copies of the last of them (the offset is 1).  With the
-// prefix sums of a chunk of sequences in LDS -- where each starts in the output (Pa) and in the literals (La) -- a lane builds 16
-// OUTPUT bytes at a time: one binary search for the sequence its granule starts in, then byte x of sequence s is literal
-// La[s] + min(x - Pa[s], ll - 1).  Same bytes as place_zero_runs (zstd_runs.h), which builds every chunk of 64 sequences in LDS with
-// scans over the literals; here a frame costs ~6 k wave-instructions instead of ~40 k.  Returns the output position behind the
-// block, or 0xFFFFFFFF if the pairs do not fit the block / the frame.
-constexpr uint32_t PL_CH = 512;        // sequences per chunk (eight per lane)
-constexpr uint32_t PL_LIT = 4096;      // bytes of a chunk's literals held in LDS (more: read from memory)
-__device__ __noinline__ uint32_t place_runs_by_output(uint8_t* dst, const uint2* pairs, uint32_t nseq, const uint8_t* lit, uint32_t regen, uint32_t fcs,
-                                                      uint32_t* lds, int lane)
-{
-    typedef __attribute__((address_space(1), aligned(1))) const u32x4 gq4u;
-    typedef __attribute__((address_space(1), aligned(1))) u32x4 gs4u;
-    uint32_t* Pa = lds;                   // [PL_CH + 1]
-    uint32_t* La = lds + (PL_CH + 8);     // [PL_CH + 1]
-    uint8_t* litbuf = reinterpret_cast<uint8_t*>(lds + 2 * (PL_CH + 8));  // [PL_LIT + 16]
-    uint32_t O = 0, Lb = 0;  // output / literal position of the chunk
-    for (uint32_t base = 0; base < nseq; base += PL_CH) {
-        const uint32_t cnt = nseq - base < PL_CH ? nseq - base : PL_CH;
-        // ---- prefix sums of the chunk: lane j holds sequences base + 8 j .. + 7
-        uint32_t ll[8], tt8[8];
-        {
-            const uint32_t i0 = 8u * (uint32_t)lane;
-            u32x4 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v[q] = (u32x4){ 0u, 0u, 0u, 0u };
-                if (i0 + 2 * q + 1 < cnt) v[q] = *(gq4u*)(reinterpret_cast<const uint8_t*>(pairs + base + i0 + 2 * q));
-                else if (i0 + 2 * q < cnt) {
-                    const uint2 one = pairs[base + i0 + 2 * q];
-                    v[q].x = one.x;
-                    v[q].y = one.y;
-                }
-                ll[2 * q] = v[q].x;
-                tt8[2 * q] = v[q].x + v[q].y;
-                ll[2 * q + 1] = v[q].z;
-                tt8[2 * q + 1] = v[q].z + v[q].w;
-            }
-        }
-        uint32_t sl = 0, st = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            sl += ll[k];
-            st += tt8[k];
-        }
-        // (a frame's content is below 2^30 and a block's below 2^17: sums of 512 lengths of up to 2^17 + 2^16 each cannot wrap)
-        const uint32_t il = wave_incl_scan_u32(sl), it = wave_incl_scan_u32(st);
-        const uint32_t tl = (uint32_t)__shfl((int)il, 63, 64), tt = (uint32_t)__shfl((int)it, 63, 64);
-        if ((uint64_t)Lb + tl > regen || (uint64_t)O + tt > fcs || tt > BLOCK_MAX) return 0xFFFFFFFFu;
-        wave_lds_sync();  // (the previous chunk's readers are done)
-        {
-            uint32_t pl = Lb + il - sl, pt = O + it - st;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                Pa[8 * lane + k] = pt;
-                La[8 * lane + k] = pl;
-                pl += ll[k];
-                pt += tt8[k];
-            }
-            if (lane == 63) {
-                Pa[PL_CH] = pt;
-                La[PL_CH] = pl;
-            }
-        }
-        const bool lit_in_lds = tl <= PL_LIT;
-        if (lit_in_lds)
-            for (uint32_t j = 4u * (uint32_t)lane; j < tl; j += 4u * WAVE) {
-                uint32_t v;
-                __builtin_memcpy(&v, lit + Lb + j, 4);  // may read 3 bytes past the literals (staging slack, as place_zero_runs)
-                *reinterpret_cast<uint32_t*>(litbuf + j) = v;
-            }
-        wave_lds_sync();
-        // ---- 16 output bytes per lane and step
-        for (uint32_t g0 = 0; g0 < tt; g0 += 16u * WAVE) {
-            const uint32_t x0 = g0 + 16u * (uint32_t)lane;
-            if (x0 < tt) {
-                const uint32_t X = O + x0;
-                uint32_t lo = 0, hi = PL_CH;  // the last sequence that starts at or before X (empty slots behind cnt start at O + tt > X)
-#pragma unroll
-                for (int b = 0; b < 9; ++b) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (Pa[mid] <= X) lo = mid;
-                    else hi = mid;
-                }
-                uint32_t sq = lo, ps = Pa[sq], pn = Pa[sq + 1], l0 = La[sq], l1 = La[sq + 1];
-                const uint32_t nb = tt - x0 < 16u ? tt - x0 : 16u;
-                uint32_t w[4] = { 0u, 0u, 0u, 0u };
-                auto lit_at = [&](uint32_t li) -> uint32_t { return lit_in_lds ? (uint32_t)litbuf[li - Lb] : (uint32_t)lit[li]; };
-                if (nb == 16u && X + 16u <= pn && X - ps >= l1 - l0 - 1u) {  // inside one run: sixteen copies of its byte
-                    const uint32_t v = lit_at(l1 - 1u) * 0x01010101u;
-                    w[0] = w[1] = w[2] = w[3] = v;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        if ((uint32_t)k < nb) {
-                            const uint32_t x = X + (uint32_t)k;
-                            while (x >= pn) {  // the next sequence (every sequence has at least one literal: at least one byte)
-                                ++sq;
-                                ps = pn;
-                                pn = Pa[sq + 1];
-                                l0 = l1;
-                                l1 = La[sq + 1];
-                            }
-                            const uint32_t off = x - ps, llen = l1 - l0;
-                            w[k >> 2] |= lit_at(l0 + (off < llen ? off : llen - 1u)) << (8 * (k & 3));
-                        }
-                    }
-                }
-                uint8_t* o = dst + X;
-                if (nb == 16u) {
-                    const u32x4 ov = { w[0], w[1], w[2], w[3] };
-                    *(gs4u*)o = ov;
-                } else {
-                    for (uint32_t k = 0; k < nb; ++k) o[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
-                }
-            }
-        }
-        O += tt;
-        Lb += tl;
-    }
-    // literals behind the last sequence
-    const uint32_t rest = regen - Lb;
-    if ((uint64_t)O + rest > fcs) return 0xFFFFFFFFu;
-    for (uint32_t k = lane; k < rest; k += WAVE) dst[O + k] = lit[Lb + k];
-    O += rest;
-    if (O > BLOCK_MAX) return 0xFFFFFFFFu;
-    return O;
-}
-
 // ---- one wavefront per frame: the zero-run block ----------------------------------------------------------------------------------------
 constexpr uint32_t RUNS_LDS = 8704;
-static_assert(RUNS_LDS >= 2 * 4 * (PL_CH + 8) + PL_LIT + 16, "placement workspace");
-__global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const FastFrame* frames, const SeqDTables* dtabs, uint32_t* redo, int mode)
+__global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const FastFrame* frames, const SeqDTables* dtabs, uint32_t* redo)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[RUNS_LDS / 4];
     const int lane = threadIdx.x;
@@ -872,8 +740,7 @@ __global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const Fast
     uint2* pairs = reinterpret_cast<uint2*>(dst + F->ws_pairs);
     const uint32_t regen = F->b0_regen, base_out = F->base_out;
     uint32_t total = 0, ok = 3;
-    if (mode == 2) { ok = 1; total = base_out; }
-    else if (F->cp_count)
+    if (F->cp_count)
         ok = zero_run_chain_segments(src + F->seq_off, F->seq_len, pairs, nseq, llt, mlt, regen, src + F->cp_off, F->cp_count, F->cp_spacing, lane, &total, lds,
                                      RUNS_LDS);
     if (ok == 3) ok = zero_run_chain(src + F->seq_off, F->seq_len, pairs, nseq, llt, mlt, 6, 6, regen, lane, &total);
@@ -882,9 +749,7 @@ __global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const Fast
         return;
     }
     __syncthreads();  // the pairs are in memory
-    if (mode == 1) { if (lane == 0) b.result[r] = F->fcs; return; }
-    const uint32_t end = mode == 3 ? place_zero_runs(dst, pairs, nseq, dst + F->ws_lit, 2u, regen, 0u, F->fcs, F->block_max, reinterpret_cast<uint8_t*>(lds), RUNS_LDS - 8u, lane)
-                                   : place_runs_by_output(dst, pairs, nseq, dst + F->ws_lit, regen, F->fcs, lds, lane);
+    const uint32_t end = place_zero_runs(dst, pairs, nseq, dst + F->ws_lit, 2u, regen, 0u, F->fcs, F->block_max, reinterpret_cast<uint8_t*>(lds), RUNS_LDS - 8u, lane);
     if (lane == 0) {
         if (end != base_out) redo[r] = 1;
         else b.result[r] = F->fcs;
@@ -913,7 +778,7 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
     hipLaunchKernelGGL(fast_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, frames, tasks, redo);
     hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo);
     hipLaunchKernelGGL(fast_streams_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, tasks, weights, redo);
-    hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo, getenv("VBZ_HIP_FAST_RUNS_MODE") ? atoi(getenv("VBZ_HIP_FAST_RUNS_MODE")) : 0);
+    hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     return launch_zstd_decode_only(b, toosmall_code, seq_dtables, redo, s);  // whatever is not of the shape, and every error verdict
