@@ -63,6 +63,8 @@ struct vbz_gpu_ctx
     DevBuf segmeta;   // segment / span tables of the large-read path
     DevBuf spanmeta, spantmp;  // span tables and temporary slots of the entropy stage in the large-read path
     DevBuf vgate;     // verdicts on the caller's descriptor table (one word per read)
+    DevBuf encplan;   // per-read plans of the staged encoder (tables of both regions: zstd_encode.hip STAGE 1 / 2)
+    bool staged_encode = true;  // VBZ_HIP_STAGED_ENCODE=0: the fused encoder kernel for every read
     DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
     bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
@@ -354,7 +356,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
@@ -434,8 +436,13 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     unsigned long long* dbg = dbg_begin(c, n);
     {
         Timed t(c, "zstd_encode");
+        void* plan = nullptr;
+        if (c->staged_encode && !dbg && c->zero_run_sequences) {
+            if (!ensure(c, c->encplan, zstd_encode_plan_bytes(n))) return -1;
+            plan = c->encplan.p;
+        }
         HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, c->zero_run_sequences ? svb_cap : nullptr,
-                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, s),
+                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, plan, s),
                "zstd_encode launch");
     }
     dbg_end(c, n, "zstd_encode: setup hist plan size hdr encode", dbg);
@@ -745,6 +752,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);
     if (const char* e = getenv("VBZ_HIP_FUSE_SVB")) c->fuse_svb = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_FAST_DECODE")) c->fast_decode = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_STAGED_ENCODE")) c->staged_encode = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e);
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
@@ -790,7 +798,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -862,7 +870,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, nullptr, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, c->stream), "zstd_encode launch");
     return 0;
 }
 

@@ -69,9 +69,13 @@ hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigz
 // whose proposal holds are coded by a second launch with the long-repeat matcher (what libzstd's match finder gets out of
 // template-cycling signal, at every level); deep_d[r] is rewritten with the verdict.  The matcher's workspace is the top of
 // the destination slot (reads whose slot is too small for frame and workspace are coded without it).
+// plan_meta (nullable, zstd_encode_plan_bytes(n_reads) bytes of device scratch): the ordinary read is coded by two launches (tables,
+// then packing at twice the occupancy: zstd_encode.hip STAGE 1 / 2) and only what they leave over by the fused kernel.  Same frames
+// either way.
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              uint32_t* deep_d, hipStream_t s);
+                              uint32_t* deep_d, void* plan_meta, hipStream_t s);
+size_t zstd_encode_plan_bytes(uint32_t n_reads);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);
 // The same stage for batches of few, large reads: one wavefront per SPAN of a read's stream (see zstd_encode.hip).

@@ -1160,18 +1160,50 @@ __device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN,
     if (N == 0) dataN = 1;  // the empty frame
 }
 
+#ifndef VBZ_ENC_PACK_WAVES
+#define VBZ_ENC_PACK_WAVES 5   // waves per SIMD the packing launch is compiled for (6: 80 registers with 20 spilled, slower)
+#endif
+#ifndef VBZ_PACK_PREFETCH
+#define VBZ_PACK_PREFETCH 1    // the next step's bytes are requested before the current step is packed
+#endif
 #ifndef VBZ_ENC_WAVES
 #define VBZ_ENC_WAVES 4   // measured: 2.2 ms (4 waves/SIMD, 16 symbols/lane) vs 2.85 ms (2 waves, 32 symbols/lane)
 #endif
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
 // DEEP: with the long-repeat matcher (level >= 4); a separate instantiation so that the ordinary kernel does not carry its registers
-template <bool TIMED, bool DEEP>
+// STAGE: 0 the whole frame in one launch (span mode, the long-repeat matcher, phase timers, and every read the staged launches
+// leave in redo[]: then only those).  1: the PLANNING launch of the staged encoder -- for the ordinary read (control-byte region with
+// run sequences or without, data-byte region, both Huffman coded, one pass of streams each) everything up to and including the
+// table construction of both regions and the sequences section, left in an EncPlan per read; zstd_pack_kernel then only packs
+// (tree, streams, headers, the sequences section moved into place, trailer).  The packing loop is 65 % of the fused kernel and
+// needs half its registers (profiles/r04_experiments.md): on its own it runs at 1.5 x the occupancy.  A read that is not of the
+// ordinary shape, or whose packing overruns (a sampled histogram that misled), keeps redo[r] = 1 and is coded by the STAGE 0
+// launch behind (which takes the tokeniser's result from the plan: that step works in place).
+struct EncRegionPlan
+{
+    uint32_t S, nblk, nrec, seqmode, Sh, treeSize, huffLog, pad;
+    uint32_t ctable[256];   // code | length << 16
+    uint32_t tree[34];      // the tree description (136 bytes)
+};
+struct EncPlan
+{
+    EncRegionPlan reg[2];
+    uint32_t seqBytes, seqOff;      // the sequences section of region 0, coded by the planning launch at the top of the destination slot
+    uint32_t cpCount, cpSpacing;    // its decoder checkpoints (CP_MAGIC trailer)
+    uint32_t cp[64];
+    // the tokeniser compacts the control bytes' literals IN PLACE: once the planning launch has run it, whoever codes the read
+    // afterwards (the packing launch, or the fused kernel for a read left in redo[]) takes its result from here
+    uint32_t tok_done, tok_nrec, tok_lit;
+    uint32_t pad[9];
+};
+
+template <bool TIMED, bool DEEP, int STAGE = 0>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab, const EncSpan* spans,
                                                            const uint32_t* span_count, uint8_t* span_tmp, uint32_t* span_size,
-                                                           uint32_t* span_trail, uint32_t trailers, uint32_t* deep_d)
+                                                           uint32_t* span_trail, uint32_t trailers, uint32_t* deep_d, EncPlan* plans, uint32_t* redo)
 {
     __shared__ __attribute__((aligned(16))) EncLds L;
     unsigned long long tph[PHASE_SLOTS] = {};
@@ -1190,7 +1222,12 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     }
     const uint32_t r = span_mode ? sp.read : blockIdx.x;
     // the bytes produced (or an error code): the read's result, or the span's size
-#define FINISH(v) do { if (lane == 0) { if (span_mode) span_size[blockIdx.x] = (v); else b.result[r] = (v); } } while (0)
+#define FINISH(v) do { if (lane == 0) { if (span_mode) span_size[blockIdx.x] = (v); else if (STAGE == 0) b.result[r] = (v); } } while (0)
+    if (STAGE == 0 && redo && !span_mode && !redo[r]) return;   // the launch behind the staged ones: only what they left
+    if (STAGE == 1 && lane == 0) {
+        redo[r] = 1;                                            // until this read's plan is complete
+        plans[r].tok_done = 0;
+    }
     if (!span_mode && b.gate && b.gate[r] >= GATE_SKIP) {
         if (b.gate[r] != GATE_SKIP) FINISH(b.gate[r]);
         return;
@@ -1245,7 +1282,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     bool frame_cp = false;  // a sequences section with checkpoints was written
     if (!span_mode || (sp.flags & SPAN_FIRST)) {
         NEED(hdr + 9 + (N == 0 ? 3 : 0));
-        if (lane == 0) {
+        if (lane == 0 && STAGE != 1) {
             if (hdr) put_le(out, orig_size[r], 4);
             uint8_t* p = out + hdr;
             put_le(p, 0xFD2FB528u, 4);
@@ -1256,6 +1293,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         opos = hdr + 5 + (N < 256 ? 1 : (N < 65536 + 256 ? 2 : 4));
     }
     if (N == 0) {
+        if (STAGE != 0) return;   // (left to the launch behind)
         if (lane == 0) put_le(out + opos, 1, 3);
         FINISH(opos + 3);
         return;
@@ -1338,8 +1376,19 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             if (need <= slot) {
                 uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * recs_all) & ~7u) + 8u * (r0 / RMIN + 2u * ord);
                 uint32_t Lit = 0;
-                tokenise_runs<false>(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, nullptr, lane);
-                __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
+                if (STAGE == 0 && plans && !span_mode && plans[r].tok_done) {
+                    // the launch behind the staged ones: the planning launch has tokenised this region already
+                    nrec = plans[r].tok_nrec;
+                    Lit = plans[r].tok_lit;
+                } else {
+                    tokenise_runs<false>(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, nullptr, lane);
+                    __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
+                    if (STAGE == 1 && lane == 0) {
+                        plans[r].tok_nrec = nrec;
+                        plans[r].tok_lit = Lit;
+                        plans[r].tok_done = 1;
+                    }
+                }
                 if (nrec) {
                     seqmode = true;
                     rec = reinterpret_cast<const uint2*>(ws);
@@ -1387,7 +1436,52 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             goto region_done;
         }
         const uint32_t mode = L.mode;
-        if (seqmode && mode != 2) {
+        if (STAGE == 1) {
+            // the ordinary read: both regions Huffman coded, the first with run sequences or without; everything else is left
+            // to the launch behind (redo[r] stays 1)
+            if (mode != 2u || region > 1) return;
+            EncRegionPlan* P = &plans[r].reg[region];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint2 e = L.ctable[lane + 64 * j];
+                P->ctable[lane + 64 * j] = e.x | (e.y << 16);
+            }
+            if (lane < 34) P->tree[lane] = reinterpret_cast<const uint32_t*>(L.tree)[lane];
+            if (lane == 0) {
+                P->S = S;
+                P->nblk = nblk;
+                P->nrec = nrec;
+                P->seqmode = seqmode ? 1u : 0u;
+                P->Sh = Sh;
+                P->treeSize = (uint32_t)L.treeSize;
+                P->huffLog = L.huffLog;
+            }
+            if (nblk > (uint32_t)MAXBLK) return;   // (more than one pass of streams: the fused kernel)
+            if (region == 0) {
+                EncPlan* FP = &plans[r];
+                uint32_t sb = 0, so = 0;
+                if (seqmode) {
+                    // the sequences section does not depend on the packing: it is coded here, at the top of the read's destination
+                    // slot, and the packing launch moves it behind the block's literals (it checks that the frame stays below it)
+                    const uint64_t room = 24ull + 8ull * nrec;
+                    if (room + 4096u > cap) return;
+                    so = (uint32_t)((cap - room) & ~15ull);
+                    wave_lds_sync();
+                    sb = encode_zero_run_sequences(L, out + so, rec, nrec, lane, 0u);
+                    wave_lds_sync();
+                    if (lane < 64) FP->cp[lane] = L.cp[lane];
+                }
+                if (lane == 0) {
+                    FP->seqBytes = sb;
+                    FP->seqOff = so;
+                    FP->cpCount = seqmode ? L.cpCount : 0u;
+                    FP->cpSpacing = seqmode ? L.cpSpacing : 0u;
+                }
+            }
+            wave_lds_sync();
+            goto region_done;
+        }
+        if (STAGE == 0 && seqmode && mode != 2) {
             // literals do not pay for a Huffman table: Raw_Literals_Block + sequences in one compressed block
             const uint32_t lh = S < 32 ? 1u : (S < 4096 ? 2u : 3u);
             NEED(3ull + lh + S + 8 + 8ull * nrec);
@@ -1404,7 +1498,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             opos += 3 + lh + S + sb;
             goto region_done;
         }
-        if (mode == 1) {
+        if (STAGE == 0 && mode == 1) {
             // RLE blocks (Block_Type 1): Block_Size = run length, one byte of content
             const uint32_t nb = (S + BLOCK_MAX - 1) / BLOCK_MAX;
             NEED(4ull * nb);
@@ -1421,7 +1515,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             opos += 4 * nb;
             goto region_done;
         }
-        if (mode == 0) {
+        if (STAGE == 0 && mode == 0) {
             // raw blocks (Block_Type 0), copied by the whole wave
             const uint32_t nb = (S + BLOCK_MAX - 1) / BLOCK_MAX;
             NEED(3ull * nb + S);
@@ -1685,6 +1779,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         }
     region_done:
         if (need_redo) {
+            if (STAGE != 0) return;   // a sample that misled: the launch behind codes the read with the exact histogram
             exact_hist = true;
             opos = opos_region;
             wave_lds_sync();
@@ -1692,6 +1787,10 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             exact_hist = false;
             ++region;
         }
+    }
+    if (STAGE == 1) {   // both regions planned
+        if (lane == 0) redo[r] = 0;
+        return;
     }
     const uint32_t main_bytes = opos;
     if (frame_cp && (trailers & 1u) && (!span_mode || (sp.flags & SPAN_FIRST))) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
@@ -1722,6 +1821,313 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 #undef PHASE
 #undef NEED
 #undef FINISH
+}
+
+// ---- the packing launch of the staged encoder ---------------------------------------------------------------------------------
+// What zstd_encode_kernel does behind its table constructions, for the reads the planning launch (STAGE 1) has prepared: frame
+// header; per region the tree description, the streams packed one after the other in frame order (the same loop: 16 symbols per lane
+// and step, a wave prefix sum of the bit counts, bits OR-ed into an LDS buffer, 16-byte quads out), the block headers; the sequences
+// section of the first block moved into place; the checkpoint trailer.  Byte for byte the fused kernel's frame.  80 registers and
+// 5 KB of LDS instead of 128 (+ spills) and 10 KB: 24 waves per CU instead of 16 (profiles/r04_experiments.md).
+struct PackLds
+{
+    uint32_t ctable[256];   // code | length << 16
+    uint32_t tree[34];
+    uint32_t ssize[WAVE], sbeg[WAVE], scnt[WAVE];
+    uint32_t obuf[OBUF_WORDS];
+};
+
+__global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
+                                                                             uint32_t hdr, uint32_t trailers, const EncPlan* plans, uint32_t* redo)
+{
+    __shared__ __attribute__((aligned(16))) PackLds L;
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    if (redo[r]) return;
+#define REDO()                          \
+    do {                                \
+        if (lane == 0) redo[r] = 1;     \
+        return;                         \
+    } while (0)
+    const uint32_t N = b.src_size[r];
+    const uint32_t cap = b.dst_cap[r];
+    const uint8_t* in = b.src + b.src_off[r];
+    uint8_t* out = b.dst + b.dst_off[r];
+    const EncPlan* FP = &plans[r];
+    uint32_t K = 0;
+    if (N >= SPLIT_MIN) {
+        if (key_bytes) K = key_bytes[r];
+        else if (key_elem) K = (orig_size[r] / key_elem + 3u) >> 2;
+        if (K >= N) K = 0;
+    }
+    const uint32_t seqBytes = FP->seqBytes, seqOff = FP->seqOff;
+    const uint32_t limit = seqBytes ? seqOff : cap;   // the frame grows below the staged sequences section
+    uint32_t opos = 0;
+    if ((uint64_t)hdr + 9 > limit) REDO();
+    if (lane == 0) {
+        if (hdr) put_le(out, orig_size[r], 4);
+        uint8_t* p = out + hdr;
+        put_le(p, 0xFD2FB528u, 4);
+        if (N < 256) { p[4] = 0x20; p[5] = (uint8_t)N; }
+        else if (N < 65536 + 256) { p[4] = 0x60; put_le(p + 5, N - 256, 2); }
+        else { p[4] = 0xA0; put_le(p + 5, N, 4); }
+    }
+    opos = hdr + 5 + (N < 256 ? 1 : (N < 65536 + 256 ? 2 : 4));
+    for (int region = 0; region < 2; ++region) {
+        if (region == 1 && K == 0) break;
+        const uint32_t r0 = region == 0 ? 0u : K;
+        const uint32_t r1 = region == 0 ? (K ? K : N) : N;
+        const bool lastRegion = r1 == N;
+        const uint8_t* rin = in + r0;
+        const EncRegionPlan* P = &FP->reg[region];
+        const uint32_t S = P->S, nblk = P->nblk, Sh = P->Sh, treeSize = P->treeSize;
+        const bool seqmode = P->seqmode != 0;
+        const uint32_t opos_region = opos;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L.ctable[lane + 64 * j] = P->ctable[lane + 64 * j];
+        if (lane < 34) L.tree[lane] = P->tree[lane];
+        const uint32_t base = S / nblk, extra = S % nblk;
+        {
+            const uint32_t bj = (uint32_t)(lane >> 2);   // this lane describes stream q of block bj
+            const int q = lane & 3;
+            const bool active = bj < nblk;
+            uint32_t bs = 0, boff = 0;
+            if (active) {
+                bs = base + (bj < extra ? 1u : 0u);
+                boff = bj * base + (bj < extra ? bj : extra);
+            }
+            const bool single = bs < 256;
+            const uint32_t seg = single ? bs : (bs + 3) >> 2;
+            uint32_t cnt = 0;
+            if (active) {
+                if (single) cnt = q == 0 ? bs : 0;
+                else cnt = q < 3 ? seg : bs - 3 * seg;
+            }
+            L.sbeg[lane] = active ? (cnt ? boff + (uint32_t)q * seg : boff + bs) : S;
+            L.scnt[lane] = cnt;
+            L.ssize[lane] = 0;
+        }
+        for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;
+        wave_lds_sync();
+        const uint32_t nb = nblk;
+        uint32_t st = 0;
+        while (st < 4 * nb && L.scnt[st] == 0) ++st;
+        uint32_t done = 0;
+#if VBZ_PACK_PREFETCH
+        uint32_t cur[STEP_DW], nxt[STEP_DW];
+#else
+        uint32_t cur[STEP_DW];
+#endif
+        auto load_chunk = [&](uint32_t sbeg, uint32_t scount, uint32_t dn, uint32_t (&w)[STEP_DW]) {
+#pragma unroll
+            for (int k = 0; k < STEP_DW; ++k) w[k] = 0;
+            const int32_t room = (int32_t)(scount - dn) - STEP_LANE * lane;
+            if (room > 0) {
+                const uint8_t* p = rin + sbeg + room - STEP_LANE;  // may start before the stream: those bytes are masked when used
+                const bool headroom = (uint64_t)r0 + sbeg >= (uint32_t)STEP_LANE;  // ... but not before the input buffer
+                if (room >= STEP_LANE || headroom) {
+                    uint4 v0;
+                    __builtin_memcpy(&v0, p, 16);
+                    w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < STEP_LANE; ++k) {
+                        const uint32_t byte = (room - STEP_LANE + k >= 0) ? (uint32_t)p[k] : 0u;
+                        w[k >> 2] |= byte << (8 * (k & 3));
+                    }
+                }
+            }
+        };
+        auto blk_bs = [&](uint32_t j) { return base + (j < extra ? 1u : 0u); };
+        auto blk_lh = [&](uint32_t j) {
+            const uint32_t jbs = blk_bs(j);
+            const uint32_t worst = (j == 0 ? treeSize : 0u) + 6u + ((jbs * 11u + 7u) >> 3) + 4u;  // every code <= 11 bits
+            const uint32_t big = jbs > worst ? jbs : worst;
+            return 3u + (big >= 1024u ? 1u : 0u) + (big >= 16384u ? 1u : 0u);
+        };
+        auto block_headers = [&](uint32_t j, uint32_t at, uint32_t seqB) {
+            if (lane == 0) {
+                const uint32_t jbs = blk_bs(j);
+                const bool jsingle = jbs < 256u;
+                const uint32_t lh = blk_lh(j), tsz = j == 0 ? treeSize : 0u;
+                const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
+                const uint32_t lit = tsz + (jsingle ? 0u : 6u) + s0 + s1 + s2 + s3;
+                uint8_t* bp = out + at;
+                const uint32_t last = (lastRegion && j + 1 == nblk) ? 1u : 0u;
+                put_le(bp, ((lh + lit + seqB) << 3) | (2u << 1) | last, 3);
+                const uint64_t type = j == 0 ? 2 : 3;  // Compressed_Literals_Block / Treeless
+                if (lh == 3) put_le(bp + 3, type | ((jsingle ? 0ull : 1ull) << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 14), 3);
+                else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 18), 4);
+                else put_le(bp + 3, type | (3ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 22), 5);
+                if (!jsingle) {
+                    uint8_t* tp = bp + 3 + lh + tsz;
+                    put_le(tp, s0, 2);
+                    put_le(tp + 2, s1, 2);
+                    put_le(tp + 4, s2, 2);
+                }
+            }
+        };
+        uint32_t ocur = opos;        // where the current block starts
+        uint32_t spos = 0;           // where the current stream starts
+        uint32_t curblk = 0xFFFFFFFFu;
+        if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
+        uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
+        uint32_t flushed = 0;     // bytes of the stream already written to memory
+        while (st < 4 * nb) {
+            if ((st >> 2) != curblk) {  // first stream of a block: reserve its headers, place the tree
+                curblk = st >> 2;
+                const uint32_t tsz = curblk == 0 ? treeSize : 0u;
+                const uint32_t hl = 3u + blk_lh(curblk) + tsz + (blk_bs(curblk) < 256u ? 0u : 6u);
+                if ((uint64_t)ocur + hl > limit) REDO();
+                for (uint32_t i = lane; i < tsz; i += WAVE) out[ocur + 3u + blk_lh(curblk) + i] = reinterpret_cast<const uint8_t*>(L.tree)[i];
+                spos = ocur + hl;
+            }
+            const uint32_t scnt = L.scnt[st];
+            uint8_t* sop = out + spos;
+            uint32_t nst = st, ndone = done + STEP_SYMS;
+            if (ndone >= scnt) {
+                ndone = 0;
+                ++nst;
+                while (nst < 4 * nb && L.scnt[nst] == 0) ++nst;
+            }
+#if VBZ_PACK_PREFETCH
+            if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, nxt);
+#endif
+            const int32_t room = (int32_t)(scnt - done) - STEP_LANE * lane;
+            const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
+            uint32_t ent[STEP_LANE];   // code | length << 16 of the lane's symbols
+#pragma unroll
+            for (int k = 0; k < STEP_LANE; ++k) ent[k] = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
+            if (skip != 0) {  // only the last step of a stream has lanes in front of its start
+#pragma unroll
+                for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
+            }
+            uint32_t Tb = 0;  // bits of this lane's codes
+#pragma unroll
+            for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k] >> 16;
+            const uint32_t incl = wave_incl_scan_u32(Tb);
+            const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+            const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
+            const uint32_t fq = allbits >> 7;             // complete 16-byte quads
+            if ((uint64_t)spos + flushed + 16ull * fq + 24 > limit) REDO();
+            {
+                const uint32_t pos = base_bits + incl - Tb;
+                uint32_t word = pos >> 5;
+                uint32_t accbits = pos & 31;
+                uint64_t acc = 0;
+#pragma unroll
+                for (int k = STEP_LANE - 1; k >= 0; k -= 2) {
+                    // two symbols (at most 22 bits) per flush check: accbits < 32 before, < 54 after
+                    const uint32_t e1 = ent[k], e0 = ent[k - 1];
+                    const uint32_t l1 = e1 >> 16, l0 = e0 >> 16;
+                    const uint64_t pair = (uint64_t)((e1 & 0xFFFFu) | ((e0 & 0xFFFFu) << l1));
+                    acc |= pair << accbits;
+                    accbits += l1 + l0;
+                    if (accbits >= 32) {
+                        atomicOr(&L.obuf[word], (uint32_t)acc);
+                        acc >>= 32;
+                        accbits -= 32;
+                        ++word;
+                    }
+                }
+                if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
+            }
+            wave_lds_sync();
+            {   // complete quads leave as 16-byte stores and are cleared on the way; the rest moves to the front
+                uint4* obq = reinterpret_cast<uint4*>(L.obuf);
+                for (uint32_t q = lane; q < fq; q += WAVE) {
+                    const uint4 v = obq[q];
+                    obq[q] = make_uint4(0u, 0u, 0u, 0u);
+                    __builtin_memcpy(sop + flushed + 16u * q, &v, 16);
+                }
+                if (fq) {
+                    const uint4 c = obq[fq];
+                    wave_lds_sync();
+                    if (lane == 0) {
+                        obq[fq] = make_uint4(0u, 0u, 0u, 0u);
+                        obq[0] = c;
+                    }
+                }
+            }
+            flushed += 16u * fq;
+            base_bits = allbits & 127u;
+            wave_lds_sync();
+            if (nst != st) {
+                // stream finished: end mark and the bits still in quad 0 (lane k writes byte k)
+                const uint32_t nbytes = (base_bits + 1 + 7) >> 3;  // <= 16
+                {
+                    uint4* obq = reinterpret_cast<uint4*>(L.obuf);
+                    const uint4 c = obq[0];
+                    const uint32_t cw[4] = { c.x, c.y, c.z, c.w };
+                    uint32_t mine = cw[(lane >> 2) & 3];
+                    if ((uint32_t)(lane >> 2) == (base_bits >> 5)) mine |= 1u << (base_bits & 31u);
+                    if ((uint32_t)lane < nbytes) sop[flushed + lane] = (uint8_t)(mine >> (8 * (lane & 3)));
+                    wave_lds_sync();
+                    if (lane == 0) {
+                        obq[0] = make_uint4(0u, 0u, 0u, 0u);
+                        L.ssize[st] = flushed + nbytes;
+                    }
+                }
+                spos += flushed + nbytes;
+                base_bits = 0;
+                flushed = 0;
+                if ((nst >> 2) != curblk && !seqmode) {
+                    // block finished: a plain block ends with Number_of_Sequences = 0; then the headers
+                    wave_lds_sync();
+                    if ((uint64_t)spos + 1 > limit) REDO();
+                    if (lane == 0) out[spos] = 0;
+                    block_headers(curblk, ocur, 1u);
+                    ocur = spos + 1u;
+                }
+            }
+#if VBZ_PACK_PREFETCH
+#pragma unroll
+            for (int k = 0; k < STEP_DW; ++k) cur[k] = nxt[k];
+#else
+            if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, cur);
+#endif
+            st = nst;
+            done = ndone;
+        }
+        if (seqmode && curblk != 0xFFFFFFFFu) {
+            // the block with the run sequences: its sequences section, coded by the planning launch above the frame, moves behind
+            // the literals (upwards in memory never: the frame has stayed below it)
+            wave_lds_sync();
+            if ((uint64_t)spos + seqBytes > seqOff) REDO();
+            for (uint32_t i = 16u * (uint32_t)lane; i < seqBytes; i += 16u * WAVE) {
+                uint4 v;
+                __builtin_memcpy(&v, out + seqOff + i, 16);   // (reads up to 15 bytes past the section: inside the slot)
+                if (i + 16u <= seqBytes) __builtin_memcpy(out + spos + i, &v, 16);
+                else {
+                    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+                    for (uint32_t k = i; k < seqBytes; ++k) out[spos + k] = (uint8_t)(w[(k - i) >> 2] >> (8 * ((k - i) & 3)));
+                }
+            }
+            wave_lds_sync();
+            block_headers(curblk, ocur, seqBytes);
+            ocur = spos + seqBytes;
+        }
+        opos = ocur;
+        if (Sh != S && opos - opos_region > S + (S >> 6) + 256u) REDO();   // a sample that misled: coded again from the exact histogram
+    }
+    if (FP->cpCount != 0 && (trailers & 1u)) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
+        const uint32_t count = FP->cpCount, tb = 8u + 4u + 4u * count + 4u;
+        if ((uint64_t)opos + tb <= cap) {
+            __syncthreads();   // (the section has left the top of the slot)
+            uint8_t* tp = out + opos;
+            if (lane == 0) {
+                put_le(tp, CP_MAGIC, 4);
+                put_le(tp + 4, tb - 8u, 4);
+                put_le(tp + 8, FP->cpSpacing | (count << 16), 4);
+                put_le(tp + 12 + 4 * count, tb, 4);
+            }
+            if ((uint32_t)lane < count) put_le(tp + 12 + 4 * lane, FP->cp[lane], 4);
+            opos += tb;
+        }
+    }
+    if (lane == 0) b.result[r] = opos;
+#undef REDO
 }
 
 // ---- span mode: plan, finish, compaction --------------------------------------------------------------------------------
@@ -2054,23 +2460,35 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              uint32_t* deep_d, hipStream_t s)
+                              uint32_t* deep_d, void* plan_meta, hipStream_t s)
 {
     const uint32_t tr = trailers ? 1u : 0u;
     if (b.n_reads == 0) return hipSuccess;
     const SeqCTables* st = reinterpret_cast<const SeqCTables*>(seq_tables);
     if (dbg) {
         hipLaunchKernelGGL((zstd_encode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, nullptr);
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, nullptr, nullptr, nullptr);
         return hipGetLastError();
     }
+    EncPlan* plans = reinterpret_cast<EncPlan*>(plan_meta);
+    uint32_t* redo = plans ? reinterpret_cast<uint32_t*>(plans + b.n_reads) : nullptr;
+    if (plans && src_cap && st) {
+        // the ordinary read in two launches (plan, pack at twice the occupancy); whatever they leave in redo[] in the fused form
+        hipLaunchKernelGGL((zstd_encode_kernel<false, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
+        hipLaunchKernelGGL(zstd_pack_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo);
+    } else {
+        redo = nullptr;
+    }
     hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                       src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d);
+                       src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, redo);
     if (deep_d)  // the reads in which the first launch found a repeat distance (it wrote deep_d[] for every read)
         hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d);
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, nullptr, nullptr);
     return hipGetLastError();
 }
+
+size_t zstd_encode_plan_bytes(uint32_t n_reads) { return (size_t)n_reads * (sizeof(EncPlan) + 4) + 256; }
 
 // ---- the long-repeat matcher in front of span mode ----------------------------------------------------------------------------
 hipError_t launch_zstd_encode_matcher(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
@@ -2083,7 +2501,7 @@ hipError_t launch_zstd_encode_matcher(const ReadBatch& b, const uint32_t* orig_s
     ReadBatch g = b;
     g.gate = gate_in;
     hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, g, orig_size, key_elem, (const uint32_t*)nullptr, hdr,
-                       (unsigned long long*)nullptr, src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, trailers ? 1u : 0u, deep_d);
+                       (unsigned long long*)nullptr, src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, trailers ? 1u : 0u, deep_d, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -2113,7 +2531,7 @@ hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_siz
                        (src_cap && seq_tables) ? 1u : 0u, max_spans, span_tmp_bytes, spans, span_first, span_count);
     hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
                        reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u,
-                       nullptr);
+                       nullptr, nullptr, nullptr);
     hipLaunchKernelGGL(zstd_span_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, hdr, spans, span_first, max_spans, span_size, span_trail,
                        span_dst, index_trailer ? 1u : 0u);
     hipLaunchKernelGGL(zstd_span_compact_kernel, dim3(max_spans), dim3(256), 0, s, b, spans, span_count, span_tmp, span_size, span_trail, span_dst,
