@@ -289,6 +289,13 @@ def usable_cpus():
     return n, note
 
 
+# kernels behind the library's timed labels (vbz_api.hip `Timed`), as rocprofv3 names them
+LABEL_KERNELS = {
+    "zstd_decode": ("zstd_decode_kernel", "fast_scan_kernel", "fast_weights_kernel", "fast_streams_kernel", "fast_runs_kernel"),
+    "zstd_encode": ("zstd_encode_kernel", "zstd_pack_kernel"),
+}
+
+
 def committed_traffic(kernels):
     """HBM bytes per launch of each of `kernels` from the newest rocprofv3 PMC summary committed under profiles/
     (tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).
@@ -304,8 +311,10 @@ def committed_traffic(kernels):
             if "second launch group" in r["kernel"]:   # (per-read routing's small-grid launches: tools/summarize_profile.py)
                 continue
             for k in kernels:
-                if r["kernel"].startswith(k + "_kernel") and k not in found:
-                    found[k] = int(float(r["hbm_MB_per_launch"]) * 1e6)
+                # one timed label of the library may cover several launches (the batched decoder, the staged encoder): their
+                # traffic adds up (every one of them runs once per call)
+                if any(r["kernel"].startswith(p) for p in LABEL_KERNELS.get(k, (k + "_kernel",))):
+                    found[k] = found.get(k, 0) + int(float(r["hbm_MB_per_launch"]) * 1e6)
         if found:
             reads = 8192
             try:

@@ -83,7 +83,7 @@ def main():
             w = csv.writer(f)
             w.writerow(["kernel", "launches", "FETCH_SIZE_KB_avg", "WRITE_SIZE_KB_avg", "read_MB_corrected(2x)", "write_MB", "hbm_MB_per_launch"])
             for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]["FETCH_SIZE"][1] + kv[1]["WRITE_SIZE"][1])):
-                if "svb_" not in k and "zstd_" not in k and "elementwise" not in k and "seg_plan" not in k and "plan_scratch" not in k:
+                if "svb_" not in k and "zstd_" not in k and "fast_" not in k and "elementwise" not in k and "seg_plan" not in k and "plan_scratch" not in k:
                     continue
                 fn, fs = v["FETCH_SIZE"]
                 wn, ws = v["WRITE_SIZE"]
@@ -102,7 +102,7 @@ def main():
                 gc.see(r["Kernel_Name"], int(r["Grid_Size"]))
             for r in recs:
                 k = gc.key(r["Kernel_Name"], int(r["Grid_Size"]))
-                if "svb_" not in k and "zstd_" not in k and "vbz_" not in k:
+                if "svb_" not in k and "zstd_" not in k and "fast_" not in k and "vbz_" not in k:
                     continue
                 a = agg[k][r["Counter_Name"]]
                 a[0] += 1
