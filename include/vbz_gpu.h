@@ -128,6 +128,12 @@ VBZ_EXPORT void vbz_gpu_profile_enable(vbz_gpu_ctx* ctx, int enable);
 VBZ_EXPORT int vbz_gpu_profile_read(vbz_gpu_ctx* ctx, const char** names, uint32_t* launches, double* total_ms, int cap);
 VBZ_EXPORT void vbz_gpu_profile_reset(vbz_gpu_ctx* ctx);
 
+/* How the frames of the context's last decompress launch group were decoded (a diagnostic; synchronizes): *batched = frames decoded by
+ * the batched decoder for frames this library wrote, *walked = frames whose sequence chains were walked one lane per frame ahead of the
+ * general decoder (frames the reference wrote with libzstd).  Returns the number of frames of that group, 0 when it did not run on these
+ * paths (the large-read path, VBZ_HIP_FAST_DECODE=0), < 0 on a device error.  The bytes and verdicts never depend on the path. */
+VBZ_EXPORT int vbz_gpu_decode_paths(vbz_gpu_ctx* ctx, uint32_t* batched, uint32_t* walked);
+
 /* Version string of the library: "vbz_hip <semver> gfx950". */
 VBZ_EXPORT const char* vbz_gpu_version(void);
 

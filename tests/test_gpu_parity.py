@@ -1357,3 +1357,115 @@ pickle.dump([o if isinstance(o, int) else o.tobytes() for o in out], open(sys.ar
     for i, a in enumerate(reads):   # and both are right
         assert outs["1"][2 * i] == a.tobytes() and outs["1"][2 * i + 1] == a.tobytes()
     assert sum(isinstance(o, int) for o in outs["1"][2 * len(reads):]) >= 9
+
+
+def test_walked_chains_of_reference_frames():
+    """zstd_decode_ref.hip walks the sequence chains of frames the reference wrote (libzstd: FSE-coded sequences, Repeat_Mode tables,
+    several blocks) one lane per frame and hands the records to the one-wavefront decoder.  The call must give exactly what it gives
+    with VBZ_HIP_REF_CHAINS=0 -- same bytes, same verdicts, damaged frames included -- the walked frames must be the ones expected
+    (vbz_gpu_decode_paths), and the bytes must be the reference's."""
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+
+    if O.lib().vbo_zstd_version() is None:
+        pytest.skip("no libzstd on this box")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak
+
+    rng = np.random.default_rng(4242)
+    reads = [O.synth_signal(5, 900 + i, n) for i, n in enumerate([100000, 110000, 104000, 250000, 400000, 450000, 33333, 700, 17, 1, 0])]
+    reads.append(np.tile(O.synth_signal(5, 1, 7000), 20))                                  # repeated template: long matches
+    reads.append(np.zeros(120000, np.int16))                                               # RLE blocks, no sequences
+    reads.append(rng.integers(-32768, 32767, 60000, endpoint=True).astype(np.int16))       # raw blocks
+    for kind in (0, 1, 3, 4, 5, 6):
+        reads.append(soak.make_read(rng, np.int16, kind, 90001))
+    wide = [soak.make_read(rng, dt, kind, 100003) for dt in (np.uint32, np.int32) for kind in (0, 3, 5)]   # several blocks per frame
+    code = r"""
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gpu_util as G, oracle_lib as O
+from vbz_compression_amd import _lib
+reads, wide, frames16, frames32, zoo, zoo_n, bad, bad_n = pickle.load(open(sys.argv[1], 'rb'))
+out = {}
+caps16 = [a.nbytes for a in reads] * (len(frames16) // len(reads))
+out['i16'] = G.decompress(frames16, caps16, _lib.CompressionOptions(True, 2, 1, 1))
+out['i16_paths'] = G.codec().decode_paths()
+caps32 = [a.nbytes for a in wide] * (len(frames32) // len(wide))
+out['i32'] = G.decompress(frames32, caps32, _lib.CompressionOptions(True, 4, 1, 1))
+out['i32_paths'] = G.codec().decode_paths()
+out['zoo'] = G.zstd_decompress(zoo, zoo_n)
+out['zoo_paths'] = G.codec().decode_paths()
+out['bad'] = G.zstd_decompress(bad, bad_n)
+out['bad_paths'] = G.codec().decode_paths()
+for k in ('i16', 'i32', 'zoo', 'bad'):
+    out[k] = [o if isinstance(o, int) else o.tobytes() for o in out[k]]
+pickle.dump(out, open(sys.argv[2], 'wb'))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    frames16 = [O.compress(a, O.options(True, 2, level, 1)) for level in (1, 3, 9) for a in reads]
+    frames32 = [O.compress(a, O.options(True, 4, level, 1)) for level in (1, 3) for a in wide]
+    # the entropy stage alone on other content: text, periodic data (matches that overlap their output), control-byte look-alikes
+    zoo_src = [np.frombuffer(b"the quick brown fox jumps over the lazy dog " * 4000, np.uint8).copy(),
+               np.minimum(rng.geometric(0.3, 150000), 255).astype(np.uint8)]
+    for period in (1, 3, 8, 17, 80, 257, 5000):
+        unit = rng.integers(0, 256, period, dtype=np.uint8)
+        zoo_src.append(np.concatenate([rng.integers(0, 256, 41, dtype=np.uint8), np.tile(unit, 40000 // period + 2), unit[: period // 2]]))
+    z = np.zeros(120000, np.uint8)
+    for s0 in np.nonzero(rng.random(120000) < 0.004)[0]:
+        z[int(s0) : int(s0) + 5] = rng.integers(1, 86, len(z[int(s0) : int(s0) + 5]), dtype=np.uint8)
+    zoo_src.append(z)
+    zoo = [O.zstd_compress(c, level) for c in zoo_src for level in (1, 3, 9)]
+    zoo_n = [len(c) for c in zoo_src for _ in (1, 3, 9)]
+    # damage, mostly in the sequences sections (the last tenth of a block's bytes) of one- and two-block frames
+    bad, bad_n = [], []
+    for a in (reads[0], reads[1]):
+        s = O.svb_compress(a, 2, True, 0)
+        for level in (1, 3):
+            frame = O.zstd_compress(s, level)
+            bad += [frame[: len(frame) - 2].copy(), frame[: len(frame) // 2].copy()]
+            bad_n += [len(s)] * 2
+            for k in range(60):
+                f = frame.copy()
+                for _ in range(int(rng.integers(1, 3))):
+                    lo = int(len(f) * (0.9 if k % 3 else (0.40 if k % 2 else 0.0)))
+                    hi = len(f) if k % 3 else int(len(f) * (0.55 if k % 2 else 1.0))
+                    f[int(rng.integers(lo, hi))] ^= 1 << int(rng.integers(0, 8))
+                bad.append(f)
+                bad_n.append(len(s))
+    with tempfile.TemporaryDirectory() as td:
+        pickle.dump((reads, wide, frames16, frames32, zoo, zoo_n, bad, bad_n), open(os.path.join(td, "in.pkl"), "wb"))
+        outs = {}
+        for walk in ("1", "0"):
+            env = dict(os.environ, VBZ_HIP_REF_CHAINS=walk, VBZ_HIP_SEGMENTED="0", VBZ_HIP_ROUTING="0")
+            subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.pkl"), os.path.join(td, "out%s.pkl" % walk)], check=True, env=env)
+            outs[walk] = pickle.load(open(os.path.join(td, "out%s.pkl" % walk), "rb"))
+    on, off = outs["1"], outs["0"]
+    for k in ("i16", "i32", "zoo", "bad"):
+        assert len(on[k]) == len(off[k])
+        for i, (a, b) in enumerate(zip(on[k], off[k])):
+            assert a == b, (k, i)
+        assert off[k + "_paths"][2] == 0
+    for i, f in enumerate(frames16):
+        assert on["i16"][i] == reads[i % len(reads)].tobytes(), i
+    for i, f in enumerate(frames32):
+        assert on["i32"][i] == wide[i % len(wide)].tobytes(), i
+    for i, (c, lv) in enumerate((c, lv) for c in zoo_src for lv in (1, 3, 9)):
+        assert on["zoo"][i] == c.tobytes(), i
+    refused = 0
+    for f, n, g in zip(bad, bad_n, on["bad"]):
+        mine = O.zstd_restate_decompress(f, n)
+        if mine is None:
+            refused += 1
+            assert isinstance(g, int) and g == 0xFFFFFFFF
+        else:
+            assert g == mine.tobytes()
+    assert refused > 40
+    # which frames were walked: every level-1 frame of a read with sequences and at most four blocks of them
+    n16, _, w16 = on["i16_paths"]
+    print('paths', on['i16_paths'], on['i32_paths'], on['zoo_paths'], on['bad_paths'])
+    assert n16 == len(frames16) and w16 >= 3 * 13, on["i16_paths"]      # (not: the empty read, zeros, noise, 1 sample, > 4 blocks)
+    assert on["i32_paths"][2] >= len(frames32) - 2, on["i32_paths"]
+    assert on["zoo_paths"][2] >= on["zoo_paths"][0] // 2, on["zoo_paths"]
+    assert 0 < on["bad_paths"][2] < len(bad), on["bad_paths"]

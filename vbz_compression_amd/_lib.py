@@ -79,6 +79,7 @@ GPU_API = [
     "vbz_gpu_profile_enable",
     "vbz_gpu_profile_read",
     "vbz_gpu_profile_reset",
+    "vbz_gpu_decode_paths",
     "vbz_gpu_version",
 ]
 
@@ -147,6 +148,8 @@ def load():
     L.vbz_gpu_profile_reset.argtypes = [vp]
     L.vbz_gpu_profile_read.restype = ctypes.c_int
     L.vbz_gpu_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
+    L.vbz_gpu_decode_paths.restype = ctypes.c_int
+    L.vbz_gpu_decode_paths.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
     L.vbz_gpu_version.restype = ctypes.c_char_p
     L.vbz_gpu_version.argtypes = []
     _lib = L

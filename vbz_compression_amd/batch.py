@@ -176,6 +176,14 @@ class GpuCodec:
         k = self.L.vbz_gpu_profile_read(self.ctx, names, launches, ms, cap)
         return {names[i].decode(): (int(launches[i]), float(ms[i])) for i in range(min(k, cap))}
 
+    def decode_paths(self):
+        """(frames, batched, walked) of the last decompress launch group: include/vbz_gpu.h, vbz_gpu_decode_paths."""
+        b, w = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        n = self.L.vbz_gpu_decode_paths(self.ctx, ctypes.byref(b), ctypes.byref(w))
+        if n < 0:
+            raise RuntimeError("vbz_gpu_decode_paths failed")
+        return n, int(b.value), int(w.value)
+
     def synchronize(self):
         self._rc(self.L.vbz_gpu_synchronize(self.ctx), "synchronize")
 

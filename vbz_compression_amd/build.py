@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
-SOURCES = ["svb_kernels.hip", "zstd_encode.hip", "zstd_decode.hip", "zstd_decode_fast.hip", "helpers.hip", "vbz_api.hip"]
+SOURCES = ["svb_kernels.hip", "zstd_encode.hip", "zstd_decode.hip", "zstd_decode_fast.hip", "zstd_decode_ref.hip", "helpers.hip", "vbz_api.hip"]
 HEADERS = ["vbz_kernels.h", "zstd_entropy.h", "svb_wave.h", "zstd_runs.h", "../../include/vbz.h", "../../include/vbz_gpu.h", "../../include/vbz_hdf_plugin.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

@@ -12,6 +12,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <map>
 #include <vector>
 
 #include "../../include/vbz.h"
@@ -67,6 +68,9 @@ struct vbz_gpu_ctx
     bool staged_encode = true;  // VBZ_HIP_STAGED_ENCODE=0: the fused encoder kernel for every read
     DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
     bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
+    DevBuf refpre, reftab, refrecs;  // frames the reference wrote: per-frame hand-over, the lanes' tables, the records (zstd_decode_ref.hip)
+    bool ref_chains = true;    // VBZ_HIP_REF_CHAINS=0: their sequence chains are walked by the one-wavefront decoder itself
+    uint32_t last_frames = 0;  // vbz_gpu_decode_paths: the frames of the last zstd_frames call (0: none, or not on the batched path)
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
@@ -449,6 +453,34 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     return 0;
 }
 
+// The frames of a launch group on the one-workgroup path (not the large-read path): frames of this library's shape on the batched
+// decoder, the sequence chains of frames the reference wrote walked one lane per frame, everything else -- and every error verdict --
+// from the one-wavefront decoder.  content_bytes bounds the frames' content in all.
+int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint64_t content_bytes, unsigned long long* dbg)
+{
+    const uint32_t n = z.n_reads;
+    hipStream_t s = c->stream;
+    Timed t(c, "zstd_decode");
+    c->last_frames = 0;
+    if (!c->fast_decode || dbg) {
+        HIPCHK(c, launch_zstd_decode(z, toosmall_code, dbg, c->seqdtab.p, s), "zstd_decode launch");
+        return 0;
+    }
+    if (!ensure(c, c->fastmeta, zstd_fast_meta_bytes(n))) return -1;
+    // records of walked chains: 16 bytes per sequence; a frame may claim as many bytes as it has content (zstd_decode_ref.hip), so a
+    // workspace of the content's size always has room -- capped at 1 GiB (~9 000 sequences for each of 65 536 reads; libzstd
+    // on nanopore signal writes ~1 100 per read); a frame that finds no room is decoded as before
+    const uint64_t recs_bytes = c->ref_chains ? std::min<uint64_t>((content_bytes + 4096) & ~15ull, 1ull << 30) : 0;
+    if (c->ref_chains &&
+        (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes()) || !ensure(c, c->refrecs, recs_bytes)))
+        return -1;
+    HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, c->refpre.p, c->ref_chains ? c->reftab.p : nullptr, c->refrecs.p,
+                                      recs_bytes / 16, s),
+           "zstd_decode (batched) launch");
+    c->last_frames = n;
+    return 0;
+}
+
 // One launch group of a decompress call: the reads of rb_in (dst_cap = the exact decoded byte counts; those whose gate is closed
 // left alone), on the one-workgroup path or on the large-read path.  dst_bytes: extent of the decoded bytes of the group.
 int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes, const CompressionOptions* o, bool segmented)
@@ -485,9 +517,12 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
         return 0;
     }
     if (o->integer_size == 0) {  // vbz.cpp:259-262: content larger than the destination -> DESTINATION_SIZE
-        Timed t(c, "zstd_decode");
-        HIPCHK(c, launch_zstd_decode(rb, E_DESTINATION_SIZE, nullptr, c->seqdtab.p, s), "zstd_decode launch");
-        return 0;
+        if (segmented) {
+            Timed t(c, "zstd_decode");
+            HIPCHK(c, launch_zstd_decode(rb, E_DESTINATION_SIZE, nullptr, c->seqdtab.p, s), "zstd_decode launch");
+            return 0;
+        }
+        return zstd_frames(c, rb, E_DESTINATION_SIZE, dst_bytes, nullptr);
     }
     // entropy stage into scratch (sized for the largest svb stream the expected output can have),
     // then svb decode into dst (vbz.cpp:234-299)
@@ -534,14 +569,7 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
     } else {
         // a frame whose content cannot be a valid svb stream of the expected size: the reference would
         // decode it and then fail in the svb stage with a stream error
-        if (c->fast_decode && !dbg) {
-            if (!ensure(c, c->fastmeta, zstd_fast_meta_bytes(n))) return -1;
-            Timed t(c, "zstd_decode");
-            HIPCHK(c, launch_zstd_decode_fast(z, E_STREAM, c->seqdtab.p, c->fastmeta.p, s), "zstd_decode (batched) launch");
-        } else {
-            Timed t(c, "zstd_decode");
-            HIPCHK(c, launch_zstd_decode(z, E_STREAM, dbg, c->seqdtab.p, s), "zstd_decode launch");
-        }
+        if (zstd_frames(c, z, E_STREAM, dst_bytes, dbg) != 0) return -1;
     }
     dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable header queue | general sequences: flush tables records literals matches", dbg);
     ReadBatch d = rb;
@@ -675,6 +703,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
 int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
 {
     const uint32_t n = bt->n_reads;
+    c->last_frames = 0;
     if (n == 0) return 0;
     hipStream_t s = c->stream;
     ReadBatch rb = to_rb(bt);
@@ -752,6 +781,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);
     if (const char* e = getenv("VBZ_HIP_FUSE_SVB")) c->fuse_svb = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_FAST_DECODE")) c->fast_decode = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_REF_CHAINS")) c->ref_chains = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_STAGED_ENCODE")) c->staged_encode = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e);
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
@@ -798,7 +828,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -878,9 +908,7 @@ int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
 {
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
-    Timed t(c, "zstd_decode");
-    HIPCHK(c, launch_zstd_decode(to_rb(bt), E_ZSTD, nullptr, c->seqdtab.p, c->stream), "zstd_decode launch");
-    return 0;
+    return zstd_frames(c, to_rb(bt), E_ZSTD, bt->dst_bytes, nullptr);
 }
 
 int vbz_gpu_synth_lengths(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n, uint32_t* out_len)
@@ -913,6 +941,36 @@ void vbz_gpu_profile_enable(vbz_gpu_ctx* c, int enable)
     if (!c) return;
     if (!enable) drain_profile(c);
     c->profiling = enable != 0;
+}
+
+int vbz_gpu_decode_paths(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)
+{
+    if (!c) return -1;
+    DeviceGuard guard(c->device);
+    if (batched) *batched = 0;
+    if (walked) *walked = 0;
+    const uint32_t n = c->last_frames;
+    if (n == 0) return 0;
+    std::vector<uint32_t> redo(n);
+    std::vector<RefPre> pre(c->ref_chains ? n : 0);
+    if (hipMemcpyAsync(redo.data(), zstd_fast_redo(c->fastmeta.p, n), 4ull * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (!pre.empty() && hipMemcpyAsync(pre.data(), zstd_ref_pre(c->refpre.p), sizeof(RefPre) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    uint32_t nb = 0, nw = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        nb += redo[i] == 0;
+        if (!pre.empty()) nw += pre[i].ok != 0;
+    }
+    if (c->trace && !pre.empty()) {  // why frames of other writers were left to the one-wavefront decoder (zstd_decode_ref.hip: BAIL)
+        std::map<uint32_t, uint32_t> why;
+        for (uint32_t i = 0; i < n; ++i)
+            if (redo[i] && !pre[i].ok) ++why[pre[i].pad[0]];
+        for (auto& e : why) fprintf(stderr, "vbz_hip: chains not walked: reason %u, %u frame(s)\n", e.first, e.second);
+    }
+    if (batched) *batched = nb;
+    if (walked) *walked = nw;
+    return (int)n;
 }
 
 void vbz_gpu_profile_reset(vbz_gpu_ctx* c)

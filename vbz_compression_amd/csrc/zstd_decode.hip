@@ -248,21 +248,6 @@ __device__ int fse_build(uint32_t* tab, int nsym, int log)
     return 0;
 }
 
-__device__ const int16_t LL_DEFAULT[36] = { 4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
-                                            2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1 };
-__device__ const int16_t ML_DEFAULT[53] = { 1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
-                                            1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1 };
-__device__ const int16_t OF_DEFAULT[29] = { 1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1 };
-__device__ const uint32_t LL_BASE[36] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18,
-                                          20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536 };
-__device__ const uint8_t LL_BITS[36] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1,
-                                         1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
-__device__ const uint32_t ML_BASE[53] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20,
-                                          21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41,
-                                          43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539 };
-__device__ const uint8_t ML_BITS[53] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
-                                         0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16 };
-
 // one sequence-table definition (lane 0): mode 0 predefined, 1 RLE, 2 FSE, 3 repeat.
 // returns bytes consumed from p, or -1
 __device__ __noinline__ int seq_table(uint32_t* tab, int* log_io, bool* have, int mode, const uint8_t* p, int n,
@@ -1513,7 +1498,7 @@ struct SvbFuse
 template <bool TIMED, bool FUSED>
 __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs,
                                                                       const DecSpan* dspans, const uint32_t* dspan_count, uint32_t* dspan_status,
-                                                                      const uint32_t* only, SvbFuse fuse)
+                                                                      const uint32_t* only, SvbFuse fuse, RefChains chains)
 {
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
@@ -1648,6 +1633,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             }
         }
     }
+    // a frame whose sequence chains are already walked (zstd_decode_ref.hip): its records are taken, nothing else changes
+    const RefPre* mypre = (chains.pre != nullptr && !dspans && chains.pre[r].ok) ? chains.pre + r : nullptr;
     const uint32_t first_block = partial ? sp.src_pos : pos;
     const uint32_t first_opos = partial ? sp.dst_pos : 0u;
     uint32_t opos = 0, ntask = 0;
@@ -1657,6 +1644,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     // attempt 0 lets the stream decoders' rings reuse the LDS of FSE tables that are (normally) dead; if a later
     // block turns out to repeat such a table, the frame is decoded again with the tables kept (attempt 1)
     bool restart = false;
+    const bool use_pre = mypre != nullptr && attempt == 0;  // (anything unexpected about them: the frame again, without)
+    uint32_t pre_k = 0;
     pos = first_block;
     opos = first_opos;
     ntask = 0;
@@ -1857,7 +1846,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             // slot), and the runs are placed in parallel after the next flush.
             bool defer = false, fast_tabs = false;
             uint32_t ws_lit = 0, ws_pairs = 0, ns_fast = 0, used_fast = 0;
-            if (has_seq && attempt == 0) {
+            if (has_seq && attempt == 0 && !use_pre) {
                 if (d_active) FLUSH();
                 uint32_t go = 0;
                 if (lane == 0 && sqn >= 4) {
@@ -1898,7 +1887,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 const uint32_t ns_hdr = nseq < 128 ? nseq : (nseq < 255 ? ((nseq - 128) << 8) + SQB(1) : SQB(1) + (SQB(2) << 8) + 0x7F00);
                 ws_plit = (fcs + 15u) & ~15u;
                 ws_seq = ws_plit + (ltype >= 2 ? ((regen + 15u) & ~15u) : 0u);
-                par = (uint64_t)ws_seq + 16ull * ns_hdr + 16 <= cap;
+                par = (uint64_t)ws_seq + (use_pre ? 0ull : 16ull * ns_hdr) + 16 <= cap;  // (walked chains: the records are elsewhere)
             }
             const uint32_t lit_dst = !has_seq ? opos : (defer ? ws_lit : (par ? ws_plit : fcs - regen));
             const uint8_t* lit_src = blk + lh;  // raw literals are read in place
@@ -2071,8 +2060,21 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 PHASE(0);
                 FLUSH();
                 PHASE(8);
+                // the block's chain may have been walked ahead of this launch (zstd_decode_ref.hip): then its records, its sequence
+                // count and the repeat offsets behind it are taken from there, no tables are built and no bit stream is read here
+                const RefBlock* pb = nullptr;
+                if (use_pre) {
+                    if (!par || pre_k >= mypre->nblk || mypre->blk[pre_k].pos != pos - 3) {
+                        restart = true;
+                        break;
+                    }
+                    pb = &mypre->blk[pre_k++];
+                }
                 // (this block's own Huffman literals were queued above, so they were decoded with the ring too)
                 if (!fse_live && tables_built) tables_lost = true;  // the ring shares its LDS with the FSE tables
+                if (pb) {
+                    nseq = uni(pb->nseq);
+                } else {
                 stage_bytes(L.u.p.hbuf, sq, sqn < HBUF ? sqn : HBUF, lane);
                 if (lane == 0) {
                     uint32_t err = 0, used = 1, ns = nseq;
@@ -2120,16 +2122,17 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 nseq = L.ctl[C_I];
                 sq_used = L.ctl[C_J];
                 tables_built = true;
+                }
                 PHASE(9);
                 const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
                 const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
                 const uint8_t* bs = sq + sq_used;
                 const uint32_t bsn = sqn - sq_used;
-                fse_live = true;  // libzstd-style frame: keep the FSE tables across the flushes of later blocks
+                if (!pb) fse_live = true;  // libzstd-style frame: keep the FSE tables across the flushes of later blocks
                 BitReader br;
                 uint32_t sl = 0, so = 0, sm = 0;
                 uint32_t err = 0;
-                if (lane == 0) {
+                if (lane == 0 && !pb) {
                     if (!br.init(bs, bsn)) err = 1;
                     if (!err) {
                         sl = br.read(log_ll);
@@ -2143,8 +2146,14 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 const uint32_t block_start = opos;
                 if (par) {
                     // ---- (A) the three state machines are walked once, the sequences only recorded, fully checked
-                    uint4* seqbuf = reinterpret_cast<uint4*>(dst + ws_seq);
-                    {
+                    const uint4* seqbuf = pb ? reinterpret_cast<const uint4*>(chains.recs) + (((uint64_t)uni(pb->rec_hi) << 32) | uni(pb->rec_lo))
+                                             : reinterpret_cast<const uint4*>(dst + ws_seq);
+                    if (pb) {
+                        rep0 = uni(pb->rep[0]);
+                        rep1 = uni(pb->rep[1]);
+                        rep2 = uni(pb->rep[2]);
+                    } else {
+                        uint4* seqbuf = reinterpret_cast<uint4*>(dst + ws_seq);
                         uint32_t reps[3] = { rep0, rep1, rep2 };
 #ifdef VBZ_SEQ_CHAIN_SCALAR
                         const bool good = general_sequence_records(bs, bsn, seqbuf, nseq, (uint32_t)__shfl(log_ll, 0, 64), (uint32_t)__shfl(log_of, 0, 64),
@@ -2588,19 +2597,20 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
     const SvbFuse none = { nullptr, nullptr, nullptr };
     if (dbg)
         hipLaunchKernelGGL((zstd_decode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none);
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none, RefChains());
     else
         hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none);
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none, RefChains());
     return hipGetLastError();
 }
 
-hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, const uint32_t* only, hipStream_t s)
+hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, const uint32_t* only, RefChains chains,
+                                   hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     const SvbFuse none = { nullptr, nullptr, nullptr };
     hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
-                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none);
+                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none, chains);
     return hipGetLastError();
 }
 
@@ -2610,7 +2620,7 @@ hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_co
     if (b.n_reads == 0) return hipSuccess;
     const SvbFuse fuse = { out, out_off, out_size };
     hipLaunchKernelGGL((zstd_decode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
-                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, fuse);
+                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, fuse, RefChains());
     return hipGetLastError();
 }
 
@@ -2632,9 +2642,9 @@ hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, 
     hipLaunchKernelGGL(zstd_dspan_plan_kernel, dim3(1), dim3(1024), 0, s, b, max_spans, spans, dspan_first, dspan_count, dspan_status);
     const SvbFuse none = { nullptr, nullptr, nullptr };
     hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, spans, dspan_count, dspan_status,
-                       nullptr, none);
+                       nullptr, none, RefChains());
     hipLaunchKernelGGL(zstd_dspan_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, spans, dspan_first, max_spans, dspan_status, redo);
-    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, nullptr, nullptr, nullptr, redo, none);
+    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, nullptr, nullptr, nullptr, redo, none, RefChains());
     return hipGetLastError();
 }
 
