@@ -68,7 +68,7 @@ struct vbz_gpu_ctx
     bool staged_encode = true;  // VBZ_HIP_STAGED_ENCODE=0: the fused encoder kernel for every read
     DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
     bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
-    DevBuf refpre, reftab, refrecs;  // frames the reference wrote: per-frame hand-over, the lanes' tables, the records (zstd_decode_ref.hip)
+    DevBuf refpre, reftab, refrecs;  // frames the reference wrote: per-frame hand-over, tables (large batches), records (zstd_decode_ref.hip)
     bool ref_chains = true;    // VBZ_HIP_REF_CHAINS=0: their sequence chains are walked by the one-wavefront decoder itself
     uint32_t last_frames = 0;  // vbz_gpu_decode_paths: the frames of the last zstd_frames call (0: none, or not on the batched path)
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
@@ -472,9 +472,9 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
     // on nanopore signal writes ~1 100 per read); a frame that finds no room is decoded as before
     const uint64_t recs_bytes = c->ref_chains ? std::min<uint64_t>((content_bytes + 4096) & ~15ull, 1ull << 30) : 0;
     if (c->ref_chains &&
-        (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes()) || !ensure(c, c->refrecs, recs_bytes)))
+        (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
         return -1;
-    HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, c->refpre.p, c->ref_chains ? c->reftab.p : nullptr, c->refrecs.p,
+    HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, c->ref_chains ? c->refpre.p : nullptr, c->reftab.p, c->refrecs.p,
                                       recs_bytes / 16, s),
            "zstd_decode (batched) launch");
     c->last_frames = n;
@@ -967,6 +967,10 @@ int vbz_gpu_decode_paths(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)
         for (uint32_t i = 0; i < n; ++i)
             if (redo[i] && !pre[i].ok) ++why[pre[i].pad[0]];
         for (auto& e : why) fprintf(stderr, "vbz_hip: chains not walked: reason %u, %u frame(s)\n", e.first, e.second);
+        double tb = 0, ch = 0, ns = 0;
+        for (uint32_t i = 0; i < n; ++i)
+            if (pre[i].ok) tb += pre[i].pad[1], ch += pre[i].pad[2], ns += pre[i].pad[3];
+        if (nw) fprintf(stderr, "vbz_hip: walked chains: %u frames, last block: %.0f cycles for the tables, %.0f for the chain, %.0f sequences\n", nw, tb / nw, ch / nw, ns / nw);
     }
     if (batched) *batched = nb;
     if (walked) *walked = nw;

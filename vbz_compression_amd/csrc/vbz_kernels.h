@@ -107,7 +107,7 @@ hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_co
                                         const uint32_t* out_size, hipStream_t s);
 // Frames the reference wrote (libzstd: blocks of general sequences): the sequence chains of the reads with redo[i] != 0 walked one
 // lane per frame ahead of the one-wavefront decoder (zstd_decode_ref.hip), which takes a frame's records when RefPre.ok says so.
-constexpr uint32_t REF_MAXBLK = 4, REF_SLOTS = 16384;
+constexpr uint32_t REF_MAXBLK = 4;
 struct RefBlock
 {
     uint32_t pos;             // where the block's header stands in the frame
@@ -127,11 +127,11 @@ struct RefChains  // what launch_zstd_decode_only needs of them (pre == nullptr:
     const void* recs = nullptr;
 };
 size_t zstd_ref_pre_bytes(uint32_t n_reads);
-size_t zstd_ref_table_bytes();
 const RefPre* zstd_ref_pre(const void* pre_meta);  // the per-frame hand-overs inside pre_meta
-// pre_meta: zstd_ref_pre_bytes(n_reads); tables: zstd_ref_table_bytes(); recs: recs_cap records of 16 bytes.  *out: for the decoder.
-hipError_t launch_zstd_ref_chain(const ReadBatch& b, const uint32_t* redo, void* pre_meta, void* tables, void* recs, uint64_t recs_cap,
-                                 RefChains* out, hipStream_t s);
+size_t zstd_ref_table_bytes(uint32_t n_reads);     // 0: a batch of this size keeps its tables in LDS
+// pre_meta: zstd_ref_pre_bytes(n_reads); tables: zstd_ref_table_bytes(n_reads); recs: recs_cap records of 16 bytes.  *out: for the decoder.
+hipError_t launch_zstd_ref_chain(const ReadBatch& b, const uint32_t* redo, void* pre_meta, void* tables, void* recs, uint64_t recs_cap, RefChains* out,
+                                 hipStream_t s);
 // The one-wavefront decoder for the reads with only[i] != 0 (the others are left alone).
 hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, const uint32_t* only, RefChains chains,
                                    hipStream_t s);
@@ -139,7 +139,7 @@ hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, c
 // per tree description, one wavefront per frame for nothing but the streams, one for the zero-run block); every frame that is not of
 // that shape or fails a check, and every error verdict, goes through launch_zstd_decode_only at the end.  Same results as
 // launch_zstd_decode.  meta: zstd_fast_meta_bytes(n_reads) bytes of device scratch.
-// ref_*: scratch of launch_zstd_ref_chain (ref_tables == nullptr: frames of other writers go to the one-wavefront decoder as they are).
+// ref_*: scratch of launch_zstd_ref_chain (ref_pre == nullptr: frames of other writers go to the one-wavefront decoder as they are).
 size_t zstd_fast_meta_bytes(uint32_t n_reads);
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads);  // after the call: redo[i] == 0 <=> frame i was decoded by the batched decoder
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,

@@ -784,7 +784,7 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
     hipLaunchKernelGGL(fast_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, frames, tasks, redo);
     // what the scan does not recognise may be a frame the reference wrote: its sequence chains, one lane per frame
     RefChains chains;
-    if (ref_tables) {
+    if (ref_pre) {
         const hipError_t e0 = launch_zstd_ref_chain(b, redo, ref_pre, ref_tables, ref_recs, ref_recs_cap, &chains, s);
         if (e0 != hipSuccess) return e0;
     }

@@ -5,19 +5,25 @@
 // lengths, match lengths and offsets come from three FSE state machines reading ONE backward bit stream (RFC 8878 3.1.1.3.2): a
 // dependent chain of ~1 100 table look-ups that no wavefront can spread over its lanes.  zstd_decode_kernel walks it on three lanes of
 // its one wavefront (~760 cycles per sequence with the other 61 lanes idle: 0.84 M of the 2.2 M cycles it spends on such a frame).
-// Here the chain of a frame is ONE LANE's work, and a wavefront walks 64 frames' chains at once:
+// Here the chain of a frame is ONE LANE's work, and what bounds a lane is the round trip to its tables, so the tables live in LDS:
 //
-//   ref_chain_kernel   lane per frame: frame header, every block header, the literals section header (only its sizes), the sequences
-//                      section header, the three table descriptions (RFC 8878 4.1.1) built into the lane's own tables in memory, the
-//                      chain -> 16-byte records {literal length, match length, offset} in a workspace the call owns.
+//   ref_chain_kernel   lane per frame, REF_FPW frames per wavefront, four wavefronts per CU (the LDS holds 36 frames' tables):
+//                      frame header, every block header, the literals section header (only its sizes), the sequences section
+//                      header, the three table descriptions (RFC 8878 4.1.1) built into the lane's tables in LDS (3 bytes per state),
+//                      the bit stream through a 256-byte ring per lane that is refilled half a ring ahead of its use, the chain ->
+//                      16-byte records {literal length, match length, offset} in a workspace the call owns.
+//                      (The first version kept the tables in memory, 10 KB per lane: ~1 us per sequence -- a memory round trip --
+//                      whatever the number of frames per wavefront; LDS: see DESIGN.md 4.4.)
 //
 // zstd_decode_kernel then finds `RefPre.ok` for the frame and takes the records instead of building tables and walking the chain
 // itself (its phases B and C -- literals from prefix sums, matches in dependency rounds -- and every other check stay where they are).
 // Nothing is trusted and nothing is decided here: a frame that fails ANY check on the way -- or whose shape this kernel does not
-// handle (more than REF_MAXBLK blocks with sequences, the zero-run blocks of zstd_encode.hip, a sequences
-// header longer than REF_HDR bytes, no room in the workspace) -- is left with ok = 0 and the one-wavefront decoder treats it exactly
-// as before, which is also what produces every error verdict.  The accept conditions are those of general_sequence_records
+// handle (more than REF_MAXBLK blocks with sequences, the zero-run blocks of zstd_encode.hip, a sequences header longer than REF_HDR
+// bytes, more sequences than its share of the workspace) -- is left with ok = 0 and the one-wavefront decoder treats it exactly as
+// before, which is also what produces every error verdict.  The accept conditions are those of general_sequence_records
 // (zstd_decode.hip) and of read_ncount / fse_build / seq_table there, restated per lane.
+#include <cstdlib>
+
 #include "vbz_kernels.h"
 #include "zstd_runs.h"
 
@@ -25,8 +31,14 @@ namespace vbzhip {
 
 namespace {
 
-constexpr int REF_HDR = 192;  // staged bytes of a sequences section header (count, modes, three table descriptions)
-constexpr uint32_t T_LL = 0, T_OF = 512, T_ML = 768, T_ALL = 1280;  // the lane's tables: entries of {baseline, base | nb << 16 | extra bits << 24}
+constexpr int REF_FPW = 9;     // tables in LDS: frames per wavefront
+constexpr int REF_GRID = 1024; //   wavefronts: four per CU, as many as the LDS takes
+constexpr int REF_FPW_MEM = 64;              // tables in memory: frames per wavefront
+constexpr uint32_t REF_MEM_WAVES_MAX = 1024; //   at most 65 536 frames in flight (a lane takes several frames beyond that)
+constexpr uint32_t REF_TAB_BYTES = 3840;     //   a lane's tables: 1 280 states x (2 + 1) bytes
+constexpr int REF_HDR = 160;   // staged bytes of a sequences section header (count, modes, three table descriptions)
+constexpr int REF_RING = 64;   // dwords of bit stream per lane
+constexpr uint32_t T_LL = 0, T_OF = 512, T_ML = 768, T_ALL = 1280;  // the lane's three tables, one entry per state
 
 __device__ __forceinline__ uint32_t rld32(const uint8_t* p)
 {
@@ -41,32 +53,89 @@ __device__ __forceinline__ uint64_t rld64(const uint8_t* p)
     return v;
 }
 
+// [index][lane]: a wavefront's lanes reading the same index of their own arrays hit different banks.
+// A state's entry is 3 bytes: bn = new-state base (9 bits) | state bits to read << 9 (4) | extra bits, low 3 << 13;
+// cx = code (6 bits) | extra bits, high 2 << 6.  The tables live in LDS (INLDS: 36 frames per CU, a sequence costs an LDS round
+// trip) or in memory (any number of frames in flight, a sequence costs a memory round trip; LDS then only holds the symbols of the
+// table under construction -- building it in memory would be a dependent memory round trip per state).
+template <int FPW, bool INLDS>
+struct RefTabs;
 template <int FPW>
-struct RefLds  // [index][lane]: a wavefront's lanes reading the same index of their own arrays hit FPW different banks
+struct RefTabs<FPW, true>
 {
-    int16_t norm[64][FPW];
-    uint16_t symnext[64][FPW];
-    uint32_t hdr[REF_HDR / 4 + 2][FPW];
+    uint16_t bn[T_ALL][FPW];
+    uint8_t cx[T_ALL][FPW];
 };
+template <int FPW>
+struct RefTabs<FPW, false>
+{
+    uint8_t spread[512][FPW];
+};
+struct RefGlobal  // the lane's tables in memory (!INLDS)
+{
+    __attribute__((address_space(1))) uint16_t* bn;
+    __attribute__((address_space(1))) uint8_t* cx;
+};
+template <int FPW, bool INLDS>
+struct RefLds
+{
+    RefTabs<FPW, INLDS> t;
+    union
+    {
+        uint32_t ring[REF_RING + 4][FPW];  // the chain: dword j of the stream (counted from its end) in slot j % 64; slots 64.. mirror 0..
+        struct                              // the tables' descriptions
+        {
+            uint32_t hdr[REF_HDR / 4 + 2][FPW];
+            int16_t norm[64][FPW];
+            uint16_t symnext[64][FPW];
+        } p;
+    } u;
+    uint32_t llb[36], mlb[53];  // code -> baseline
+};
+template <int FPW, bool INLDS>
+__device__ __forceinline__ uint32_t get_bn(const RefLds<FPW, INLDS>& S, RefGlobal G, int l, uint32_t at)
+{
+    if constexpr (INLDS) return S.t.bn[at][l];
+    else return G.bn[at];
+}
+template <int FPW, bool INLDS>
+__device__ __forceinline__ uint32_t get_cx(const RefLds<FPW, INLDS>& S, RefGlobal G, int l, uint32_t at)
+{
+    if constexpr (INLDS) return S.t.cx[at][l];
+    else return G.cx[at];
+}
+// the symbol of state u of the table under construction at t0
+template <int FPW, bool INLDS>
+__device__ __forceinline__ void sp_put(RefLds<FPW, INLDS>& S, int l, uint32_t t0, uint32_t u, uint32_t sym)
+{
+    if constexpr (INLDS) S.t.cx[t0 + u][l] = (uint8_t)sym;
+    else S.t.spread[u][l] = (uint8_t)sym;
+}
+template <int FPW, bool INLDS>
+__device__ __forceinline__ uint32_t sp_get(const RefLds<FPW, INLDS>& S, int l, uint32_t t0, uint32_t u)
+{
+    if constexpr (INLDS) return S.t.cx[t0 + u][l];
+    else return S.t.spread[u][l];
+}
 
 // bits [bitpos, bitpos + k) of the lane's staged header bytes, k <= 17 (little-endian bit order: RFC 8878 4.1.1)
-template <int FPW>
-__device__ __forceinline__ uint32_t hdr_bits(const RefLds<FPW>& S, int l, uint32_t bitpos, int k)
+template <int FPW, bool INLDS>
+__device__ __forceinline__ uint32_t hdr_bits(const RefLds<FPW, INLDS>& S, int l, uint32_t bitpos, int k)
 {
     const uint32_t w = bitpos >> 5;
-    const uint64_t two = (uint64_t)S.hdr[w][l] | ((uint64_t)S.hdr[w + 1][l] << 32);
+    const uint64_t two = (uint64_t)S.u.p.hdr[w][l] | ((uint64_t)S.u.p.hdr[w + 1][l] << 32);
     return (uint32_t)(two >> (bitpos & 31u)) & ((1u << k) - 1u);
 }
-template <int FPW>
-__device__ __forceinline__ uint32_t hdr_byte(const RefLds<FPW>& S, int l, uint32_t i)
+template <int FPW, bool INLDS>
+__device__ __forceinline__ uint32_t hdr_byte(const RefLds<FPW, INLDS>& S, int l, uint32_t i)
 {
-    return (S.hdr[i >> 2][l] >> (8u * (i & 3u))) & 0xFFu;
+    return (S.u.p.hdr[i >> 2][l] >> (8u * (i & 3u))) & 0xFFu;
 }
 
 // read_ncount of zstd_decode.hip for one lane: the description starts at byte `at` of the staged header, n bytes are there.
 // Returns bytes consumed or -1; fills the lane's norm[0..nsym).
-template <int FPW>
-__device__ int ref_read_ncount(RefLds<FPW>& S, int l, uint32_t at, int n, int max_symbol, int max_log, int* out_log, int* out_nsym)
+template <int FPW, bool INLDS>
+__device__ int ref_read_ncount(RefLds<FPW, INLDS>& S, int l, uint32_t at, int n, int max_symbol, int max_log, int* out_log, int* out_nsym)
 {
     if (n < 1) return -1;
     auto bits = [&](uint32_t bitpos, int k) -> uint32_t {  // bytes beyond n read as zero
@@ -89,7 +158,7 @@ __device__ int ref_read_ncount(RefLds<FPW>& S, int l, uint32_t at, int n, int ma
                 bitpos += 2;
                 for (uint32_t k = 0; k < rr; ++k) {
                     if (sym > max_symbol) return -1;
-                    S.norm[sym++][l] = 0;
+                    S.u.p.norm[sym++][l] = 0;
                 }
                 if (rr != 3) break;
                 if (bitpos > 8u * (uint32_t)n + 32u) return -1;
@@ -111,7 +180,7 @@ __device__ int ref_read_ncount(RefLds<FPW>& S, int l, uint32_t at, int n, int ma
         }
         count--;
         remaining -= count < 0 ? -count : count;
-        S.norm[sym++][l] = (int16_t)count;
+        S.u.p.norm[sym++][l] = (int16_t)count;
         prev0 = (count == 0);
         while (remaining < threshold) {
             nbits--;
@@ -127,35 +196,45 @@ __device__ int ref_read_ncount(RefLds<FPW>& S, int l, uint32_t at, int n, int ma
     return used;
 }
 
-// what a code stands for: kind 0 literal lengths, 1 offsets, 2 match lengths -> {baseline, extra bits}
-__device__ __forceinline__ uint2 code_value(int kind, uint32_t code)
+// extra bits of a code: kind 0 literal lengths, 1 offsets, 2 match lengths
+__device__ __forceinline__ uint32_t code_bits(int kind, uint32_t code) { return kind == 1 ? code : (kind == 0 ? LL_BITS[code] : ML_BITS[code]); }
+
+template <int FPW, bool INLDS>
+__device__ __forceinline__ void put_entry(RefLds<FPW, INLDS>& S, RefGlobal G, int l, uint32_t at, uint32_t code, uint32_t nb, uint32_t base, int kind)
 {
-    if (kind == 1) return make_uint2(1u << (code & 31u), code);
-    if (kind == 0) return make_uint2(LL_BASE[code], LL_BITS[code]);
-    return make_uint2(ML_BASE[code], ML_BITS[code]);
+    const uint32_t x = code_bits(kind, code);
+    const uint16_t bn = (uint16_t)(base | (nb << 9) | ((x & 7u) << 13));
+    const uint8_t cx = (uint8_t)(code | ((x >> 3) << 6));
+    if constexpr (INLDS) {
+        S.t.bn[at][l] = bn;
+        S.t.cx[at][l] = cx;
+    } else {
+        G.bn[at] = bn;
+        G.cx[at] = cx;
+    }
 }
 
-// fse_build of zstd_decode.hip for one lane, into the lane's table in memory (RFC 8878 4.1.1); entries as described at T_LL
-template <int FPW>
-__device__ bool ref_fse_build(RefLds<FPW>& S, int l, uint2* tab, int nsym, int log, int kind)
+// fse_build of zstd_decode.hip for one lane (RFC 8878 4.1.1), in place in the lane's table at `t0`
+template <int FPW, bool INLDS>
+__device__ bool ref_fse_build(RefLds<FPW, INLDS>& S, RefGlobal G, int l, uint32_t t0, int nsym, int log, int kind)
 {
     const int size = 1 << log;
     int high = size - 1;
     for (int s = 0; s < nsym; ++s) {
-        const int c = S.norm[s][l];
+        const int c = S.u.p.norm[s][l];
         if (c == -1) {
-            tab[high--].x = (uint32_t)s;
-            S.symnext[s][l] = 1;
+            sp_put(S, l, t0, (uint32_t)high--, (uint32_t)s);
+            S.u.p.symnext[s][l] = 1;
         } else {
-            S.symnext[s][l] = (uint16_t)c;
+            S.u.p.symnext[s][l] = (uint16_t)c;
         }
     }
     const int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
     int pos = 0;
     for (int s = 0; s < nsym; ++s) {
-        const int c = S.norm[s][l];
+        const int c = S.u.p.norm[s][l];
         for (int i = 0; i < c; ++i) {
-            tab[pos].x = (uint32_t)s;
+            sp_put(S, l, t0, (uint32_t)pos, (uint32_t)s);
             do {
                 pos = (pos + step) & mask;
             } while (pos > high);
@@ -163,26 +242,25 @@ __device__ bool ref_fse_build(RefLds<FPW>& S, int l, uint2* tab, int nsym, int l
     }
     if (pos != 0) return false;
     for (int u = 0; u < size; ++u) {
-        const uint32_t s = tab[u].x & 0xFFu;
-        const uint32_t ns = S.symnext[s][l];
-        S.symnext[s][l] = (uint16_t)(ns + 1);
+        const uint32_t s = sp_get(S, l, t0, (uint32_t)u);
+        const uint32_t ns = S.u.p.symnext[s][l];
+        S.u.p.symnext[s][l] = (uint16_t)(ns + 1);
         const int nb = log - hbit(ns);
-        const uint2 cv = code_value(kind, s);
-        tab[u] = make_uint2(cv.x, ((((ns << nb) - (uint32_t)size) & 0xFFFFu)) | ((uint32_t)nb << 16) | (cv.y << 24));
+        put_entry(S, G, l, t0 + (uint32_t)u, s, (uint32_t)nb, ((ns << nb) - (uint32_t)size) & 0x1FFu, kind);
     }
     return true;
 }
 
 // seq_table of zstd_decode.hip for one lane.  Returns bytes consumed from the staged header at `at`, or -1.
-template <int FPW>
-__device__ int ref_seq_table(RefLds<FPW>& S, int l, uint2* tab, int* log_io, bool* have, int mode, uint32_t at, int n, int kind)
+template <int FPW, bool INLDS>
+__device__ int ref_seq_table(RefLds<FPW, INLDS>& S, RefGlobal G, int l, uint32_t t0, int* log_io, bool* have, int mode, uint32_t at, int n, int kind)
 {
     const int16_t* def = kind == 0 ? LL_DEFAULT : (kind == 1 ? OF_DEFAULT : ML_DEFAULT);
     const int def_n = kind == 0 ? 36 : (kind == 1 ? 29 : 53), def_log = kind == 1 ? 5 : 6;
     const int max_sym = kind == 0 ? 35 : (kind == 1 ? 31 : 52), max_log = kind == 1 ? 8 : 9;
     if (mode == 0) {
-        for (int i = 0; i < def_n; ++i) S.norm[i][l] = def[i];
-        if (!ref_fse_build(S, l, tab, def_n, def_log, kind)) return -1;
+        for (int i = 0; i < def_n; ++i) S.u.p.norm[i][l] = def[i];
+        if (!ref_fse_build(S, G, l, t0, def_n, def_log, kind)) return -1;
         *log_io = def_log;
         *have = true;
         return 0;
@@ -191,8 +269,7 @@ __device__ int ref_seq_table(RefLds<FPW>& S, int l, uint2* tab, int* log_io, boo
         if (n < 1) return -1;
         const uint32_t code = hdr_byte(S, l, at);
         if (code > (uint32_t)max_sym) return -1;
-        const uint2 cv = code_value(kind, code);
-        tab[0] = make_uint2(cv.x, cv.y << 24);
+        put_entry(S, G, l, t0, code, 0u, 0u, kind);
         *log_io = 0;
         *have = true;
         return 1;
@@ -201,7 +278,7 @@ __device__ int ref_seq_table(RefLds<FPW>& S, int l, uint2* tab, int* log_io, boo
         int log, nsym;
         const int used = ref_read_ncount(S, l, at, n, max_sym, max_log, &log, &nsym);
         if (used < 0) return -1;
-        if (!ref_fse_build(S, l, tab, nsym, log, kind)) return -1;
+        if (!ref_fse_build(S, G, l, t0, nsym, log, kind)) return -1;
         *log_io = log;
         *have = true;
         return used;
@@ -209,7 +286,7 @@ __device__ int ref_seq_table(RefLds<FPW>& S, int l, uint2* tab, int* log_io, boo
     return *have ? 0 : -1;
 }
 
-// The 64 bits that follow bit s (counted from the top) of the 128-bit value hi:lo, s <= 127
+// The 64 bits that follow bit s (counted from the top, s <= 127) of the 128-bit value hi:lo
 __device__ __forceinline__ uint64_t top64(uint64_t hi, uint64_t lo, uint32_t s)
 {
     const uint64_t a = (s & 64u) ? lo : hi, c = (s & 64u) ? 0ull : lo;
@@ -217,40 +294,76 @@ __device__ __forceinline__ uint64_t top64(uint64_t hi, uint64_t lo, uint32_t s)
     return (a << t) | (t ? c >> (64u - t) : 0ull);
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// (explicitly global: a FLAT access counts on the LDS counter as well, and the chain waits on that counter once per sequence)
+typedef __attribute__((address_space(1), aligned(1))) const u32x4 ref_gld16;
+typedef __attribute__((address_space(1))) u32x4 ref_gst16;
+typedef __attribute__((address_space(1))) const uint8_t ref_gcu8;
+
 // The chain of one sequences section for one lane: general_sequence_records of zstd_decode.hip, the same accept conditions.
-// Returns 0, or why not (a diagnostic).  bs / bsn: the bit stream; arena_lo: how many bytes below bs may be read (they belong to the arena).  rep: in and out.
-// *out_end: output position behind the block's last match (the literals behind it are the caller's).
-__device__ uint32_t ref_chain(const uint8_t* bs, uint32_t bsn, uint64_t arena_lo, const uint2* tab, uint32_t log_ll, uint32_t log_of, uint32_t log_ml,
-                          uint4* rec, uint32_t nseq, uint32_t regen, uint32_t opos0, uint32_t fcs, uint32_t (&rep)[3], uint64_t* out_end)
+// Returns 0, or why not (a diagnostic).  bs / bsn: the bit stream; arena_lo: how many bytes below bs may be read (they belong to
+// the arena).  rep: in and out.  *out_end: output position behind the block (its trailing literals included).
+// Per sequence ONE dependent LDS round trip: the entries of the next states and the four dwords of bit stream at the next position
+// are requested as soon as both are known; the repeat-offset rules and the record's store run behind the request.
+template <int FPW, bool INLDS>
+__device__ uint32_t ref_chain(RefLds<FPW, INLDS>& S, RefGlobal G, int l, const uint8_t* bs, uint32_t bsn, uint64_t arena_lo, uint32_t log_ll, uint32_t log_of,
+                              uint32_t log_ml, uint4* rec, uint32_t nseq, uint32_t regen, uint32_t opos0, uint32_t fcs, uint32_t (&rep)[3],
+                              uint64_t* out_end)
 {
     if (bsn == 0) return 101u;
-    const uint32_t top = bs[bsn - 1];
+    const uint32_t top = ((ref_gcu8*)bs)[bsn - 1];
     if (top == 0) return 102u;
+    ref_gst16* grec = (ref_gst16*)rec;
     const uint32_t total_bits = 8u * bsn;
-    uint32_t pos = 8u - (uint32_t)hbit(top);  // bits consumed, counted from the end of the stream
-    // the 16 bytes that end with the byte the next unread bit is in: hi = the upper eight (little-endian), lo = the lower eight
-    auto window = [&](uint32_t p, uint64_t& hi, uint64_t& lo) {
-        const uint32_t e = bsn - (p >> 3);  // bytes [e - 16, e) of the stream; p <= total_bits: e >= 0
-        if ((uint64_t)e + arena_lo >= 16) {
-            lo = rld64(bs + (int64_t)e - 16);
-            hi = rld64(bs + (int64_t)e - 8);
-        } else {  // the first bytes of the arena: assemble what is there
-            hi = lo = 0;
-            for (uint32_t k = 0; k < 16; ++k) {
-                const int64_t at = (int64_t)e - 1 - (int64_t)k;  // byte k from the top
-                if (at + (int64_t)arena_lo < 0) break;
-                const uint64_t v = bs[at];
-                if (k < 8) hi |= v << (56 - 8 * k);
-                else lo |= v << (56 - 8 * (k - 8));
+    // dwords k .. k + 3 of the stream, counted from its end: dword k = bytes [bsn - 4 (k + 1), bsn - 4 k), little-endian, so that its
+    // top bit is the first of them to be read (.w = dword k).  Bytes below the stream's first belong to the arena (or, below the
+    // arena, read as zero) and are never consumed: a walk that reaches them has left the stream and stops.
+    auto quad = [&](uint32_t k) -> u32x4 {
+        const int64_t at = (int64_t)bsn - 4 * (int64_t)k - 16;
+        u32x4 v = { 0u, 0u, 0u, 0u };
+        if (at + (int64_t)arena_lo >= 0) {
+            v = *(ref_gld16*)(bs + at);
+        } else {  // the first bytes of the arena: whatever of the 16 bytes is there
+            for (int j = 0; j < 16; ++j) {
+                if (at + j + (int64_t)arena_lo < 0) continue;
+                const uint32_t byte = (uint32_t)((ref_gcu8*)bs)[at + j] << (8 * (j & 3));
+                v.x |= (j >> 2) == 0 ? byte : 0u;
+                v.y |= (j >> 2) == 1 ? byte : 0u;
+                v.z |= (j >> 2) == 2 ? byte : 0u;
+                v.w |= (j >> 2) == 3 ? byte : 0u;
             }
         }
+        return v;
     };
-    uint64_t hi, lo;
-    window(pos, hi, lo);
+    auto ring_put = [&](uint32_t k, u32x4 v) {  // dwords k .. k + 3 (k % 4 == 0) into their slots
+        const uint32_t s0 = k & (uint32_t)(REF_RING - 1);
+        S.u.ring[s0][l] = v.w;
+        S.u.ring[s0 + 1][l] = v.z;
+        S.u.ring[s0 + 2][l] = v.y;
+        S.u.ring[s0 + 3][l] = v.x;
+        if (s0 == 0) {  // (a read of four consecutive slots may start at slot 63)
+            S.u.ring[REF_RING][l] = v.w;
+            S.u.ring[REF_RING + 1][l] = v.z;
+            S.u.ring[REF_RING + 2][l] = v.y;
+            S.u.ring[REF_RING + 3][l] = v.x;
+        }
+    };
+    // the ring holds dwords [base, base + 64); pend = dwords [base + 64, base + 96), on their way
+    u32x4 pend[8];
+    for (uint32_t h = 0; h < 64u; h += 32u) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pend[q] = quad(h + 4u * (uint32_t)q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ring_put(h + 4u * (uint32_t)q, pend[q]);
+    }
+    uint32_t base = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pend[q] = quad(64u + 4u * (uint32_t)q);
+    uint32_t pos = 8u - (uint32_t)hbit(top);  // bits of the stream that are consumed
+    uint32_t d0 = S.u.ring[0][l], d1 = S.u.ring[1][l], d2 = S.u.ring[2][l], d3 = S.u.ring[3][l];
     uint32_t sl, so, sm;
     {
-        const uint32_t sh = pos & 7u;
-        const uint64_t w = top64(hi, lo, sh);  // log_ll + log_of + log_ml <= 26 bits
+        const uint64_t w = top64(((uint64_t)d0 << 32) | d1, ((uint64_t)d2 << 32) | d3, pos);  // log_ll + log_of + log_ml <= 26 bits
         const uint32_t all = log_ll + log_of + log_ml;
         const uint32_t v = all ? (uint32_t)(w >> (64u - all)) : 0u;
         sl = log_ll ? v >> (log_of + log_ml) : 0u;
@@ -262,41 +375,77 @@ __device__ uint32_t ref_chain(const uint8_t* bs, uint32_t bsn, uint64_t arena_lo
     uint32_t rep0 = rep[0], rep1 = rep[1], rep2 = rep[2];
     uint64_t sum_ll = 0, outp = opos0;
     bool astray = false;
+    uint32_t bl = get_bn(S, G, l, T_LL + sl), bo = get_bn(S, G, l, T_OF + so), bm = get_bn(S, G, l, T_ML + sm);
+    uint32_t cl = get_cx(S, G, l, T_LL + sl), co = get_cx(S, G, l, T_OF + so), cm = get_cx(S, G, l, T_ML + sm);
+    {
+        const uint32_t j = pos >> 5;
+        d0 = S.u.ring[j][l];
+        d1 = S.u.ring[j + 1][l];
+        d2 = S.u.ring[j + 2][l];
+        d3 = S.u.ring[j + 3][l];
+    }
     for (uint32_t i = 0; i < nseq; ++i) {
-        const uint2 el = tab[T_LL + sl], eo = tab[T_OF + so], em = tab[T_ML + sm];
-        window(pos, hi, lo);
-        const uint32_t xl = el.y >> 24, xo = eo.y >> 24, xm = em.y >> 24;
+        const uint32_t xl = (bl >> 13) | ((cl >> 6) << 3), xo = (bo >> 13) | ((co >> 6) << 3), xm = (bm >> 13) | ((cm >> 6) << 3);
         const uint32_t xt = xo + xm + xl;  // <= 31 + 16 + 16: offset bits first, then match length, then literal length
-        const uint32_t sh = pos & 7u;
-        const uint64_t wx = top64(hi, lo, sh);
-        const uint64_t X = xt ? wx >> (64u - xt) : 0ull;
-        const uint32_t ofv = eo.x + (uint32_t)(X >> (xm + xl));
-        const uint32_t mlen = em.x + ((uint32_t)(X >> xl) & ((1u << xm) - 1u));
-        const uint32_t llen = el.x + ((uint32_t)X & ((1u << xl) - 1u));
         const bool lastseq = i + 1 == nseq;
-        const uint32_t nl = lastseq ? 0u : (el.y >> 16) & 0xFFu, nm = lastseq ? 0u : (em.y >> 16) & 0xFFu, no = lastseq ? 0u : (eo.y >> 16) & 0xFFu;
+        const uint32_t nl = lastseq ? 0u : (bl >> 9) & 15u, nm = lastseq ? 0u : (bm >> 9) & 15u, no = lastseq ? 0u : (bo >> 9) & 15u;
         const uint32_t nt = nl + nm + no;  // <= 26: the states move on in the order LL, ML, OF
-        const uint64_t ws = top64(hi, lo, sh + xt);
+        const uint64_t A = ((uint64_t)d0 << 32) | d1, B = ((uint64_t)d2 << 32) | d3;
+        const uint32_t sh = pos & 31u;
+        const uint64_t ws = top64(A, B, sh + xt);  // sh + xt < 95
         const uint32_t v = nt ? (uint32_t)(ws >> (64u - nt)) : 0u;
-        sl = (el.y & 0xFFFFu) + (v >> (nm + no));
-        sm = (em.y & 0xFFFFu) + ((v >> no) & ((1u << nm) - 1u));
-        so = (eo.y & 0xFFFFu) + (v & ((1u << no) - 1u));
-        pos += xt + nt;
-        if (pos > total_bits) return 104u;
+        sl = (bl & 511u) + (v >> (nm + no));
+        sm = (bm & 511u) + ((v >> no) & ((1u << nm) - 1u));
+        so = (bo & 511u) + (v & ((1u << no) - 1u));
+        pos += xt + nt;  // (a walk that leaves the stream goes on over whatever lies below it -- the ring and the loads stay inside
+                         // the arena, the records inside the claim -- and is refused behind the loop: pos only grows)
+        const uint32_t j = pos >> 5;
+        if (j >= base + 32u) {  // half the ring is behind: what was requested when the walk entered the other half takes its place
+            const uint32_t k0 = base + 64u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ring_put(k0 + 4u * (uint32_t)q, pend[q]);
+            base += 32u;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pend[q] = quad(base + 64u + 4u * (uint32_t)q);
+        }
+        const uint32_t kl = cl & 63u, ko = co & 63u, km = cm & 63u;
+        // the next sequence's entries and bits: on their way while this one is finished
+        bl = get_bn(S, G, l, T_LL + sl);
+        bo = get_bn(S, G, l, T_OF + so);
+        bm = get_bn(S, G, l, T_ML + sm);
+        cl = get_cx(S, G, l, T_LL + sl);
+        co = get_cx(S, G, l, T_OF + so);
+        cm = get_cx(S, G, l, T_ML + sm);
+        const uint32_t js = j & (uint32_t)(REF_RING - 1);
+        d0 = S.u.ring[js][l];
+        d1 = S.u.ring[js + 1][l];
+        d2 = S.u.ring[js + 2][l];
+        d3 = S.u.ring[js + 3][l];
+        const uint64_t wx = top64(A, B, sh);
+        const uint64_t X = xt ? wx >> (64u - xt) : 0ull;
+        const uint32_t ofv = (1u << (ko & 31u)) + (uint32_t)(X >> (xm + xl));
+        const uint32_t mlen = S.mlb[km] + ((uint32_t)(X >> xl) & ((1u << xm) - 1u));
+        const uint32_t llen = S.llb[kl] + ((uint32_t)X & ((1u << xl) - 1u));
         // repeat offsets (RFC 8878 3.1.1.5): idx 0 = rep0 as it is, 1 = rep1, 2 = rep2, 3 = rep0 - 1
-        const bool isrep = ofv <= 3;
-        const uint32_t idx = ofv - 1 + (llen == 0 ? 1u : 0u);
-        uint32_t cand = idx == 1 ? rep1 : (idx == 2 ? rep2 : rep0 - (idx == 3 ? 1u : 0u));
-        cand = cand ? cand : 1u;  // libzstd forces an invalid 0 to 1
-        const uint32_t offset = isrep ? cand : ofv - 3;
-        rep2 = (isrep && idx <= 1) ? rep2 : rep1;
-        rep1 = (isrep && idx == 0) ? rep1 : rep0;
+        // (written with masks, not with conditions: as conditions they come out as a chain of branches)
+        const uint32_t isrep = 0u - (uint32_t)(ofv <= 3);  // all ones / zero
+        const uint32_t idx = ofv - 1 + (uint32_t)(llen == 0);
+        const uint32_t is1 = 0u - (uint32_t)(idx == 1), is2 = 0u - (uint32_t)(idx == 2);
+        uint32_t cand = ((rep1 & is1) | (rep2 & is2) | (rep0 & ~(is1 | is2))) - (uint32_t)(idx == 3);
+        cand += (uint32_t)(cand == 0);  // libzstd forces an invalid 0 to 1
+        const uint32_t offset = (cand & isrep) | ((ofv - 3) & ~isrep);
+        const uint32_t keep2 = isrep & (0u - (uint32_t)(idx <= 1)), keep1 = isrep & (0u - (uint32_t)(idx == 0));
+        rep2 = (rep2 & keep2) | (rep1 & ~keep2);
+        rep1 = (rep1 & keep1) | (rep0 & ~keep1);
         rep0 = offset;
         sum_ll += llen;
         outp += llen;
-        astray = astray || offset > outp;
+        astray = astray | (offset > outp);
         outp += mlen;
-        rec[i] = make_uint4(llen, mlen, offset, 0u);
+        {
+            u32x4 rv = { llen, mlen, offset, 0u };
+            grec[i] = rv;
+        }
     }
     if (astray) return 105u;
     if (sum_ll > regen || outp > fcs || outp - opos0 > BLOCK_MAX) return 106u;
@@ -308,11 +457,10 @@ __device__ uint32_t ref_chain(const uint8_t* bs, uint32_t bsn, uint64_t arena_lo
     return 0u;
 }
 
-// One frame, one lane.  Returns true when every block with sequences of the frame has its records in the workspace.
 // (why a frame was left alone: RefPre.pad[0], a diagnostic that vbz_gpu_decode_paths prints under VBZ_HIP_TRACE)
 #define BAIL(k) do { P->pad[0] = (k); return false; } while (0)
-template <int FPW>
-__device__ bool ref_frame(RefLds<FPW>& S, int l, const ReadBatch& b, uint32_t r, RefPre* P, uint2* tab, uint4* recs, uint64_t recs_cap,
+template <int FPW, bool INLDS>
+__device__ bool ref_frame(RefLds<FPW, INLDS>& S, RefGlobal G, int l, const ReadBatch& b, uint32_t r, RefPre* P, uint4* recs, uint64_t recs_cap,
                           unsigned long long* recs_used)
 {
     if (b.gate && b.gate[r] >= GATE_SKIP) BAIL(1);
@@ -394,14 +542,15 @@ __device__ bool ref_frame(RefLds<FPW>& S, int l, const ReadBatch& b, uint32_t r,
                 opos += regen;
             } else {
                 if (nblk == REF_MAXBLK) BAIL(17);
+                const unsigned long long t0 = __builtin_readcyclecounter();
                 // stage the header of the sequences section: 16 bytes per load, all of them in flight at once
                 const uint32_t hn = sqn < (uint32_t)REF_HDR ? sqn : (uint32_t)REF_HDR;
                 for (uint32_t k = 0; 16 * k < hn; ++k) {
                     const uint64_t a = rld64(sq + 16 * k), c = rld64(sq + 16 * k + 8);
-                    S.hdr[4 * k][l] = (uint32_t)a;
-                    S.hdr[4 * k + 1][l] = (uint32_t)(a >> 32);
-                    S.hdr[4 * k + 2][l] = (uint32_t)c;
-                    S.hdr[4 * k + 3][l] = (uint32_t)(c >> 32);
+                    S.u.p.hdr[4 * k][l] = (uint32_t)a;
+                    S.u.p.hdr[4 * k + 1][l] = (uint32_t)(a >> 32);
+                    S.u.p.hdr[4 * k + 2][l] = (uint32_t)c;
+                    S.u.p.hdr[4 * k + 3][l] = (uint32_t)(c >> 32);
                 }
                 uint32_t ns = hdr_byte(S, l, 0), used = 1;
                 if (ns >= 128) {
@@ -418,7 +567,7 @@ __device__ bool ref_frame(RefLds<FPW>& S, int l, const ReadBatch& b, uint32_t r,
                 if (used >= hn) BAIL(20);
                 const uint32_t modes = hdr_byte(S, l, used++);
                 if (modes & 3) BAIL(21);
-                int u = ref_seq_table(S, l, tab + T_LL, &log_ll, &have_ll, (modes >> 6) & 3, used, (int)(hn - used), 0);
+                int u = ref_seq_table(S, G, l, T_LL, &log_ll, &have_ll, (modes >> 6) & 3, used, (int)(hn - used), 0);
                 if (u < 0) BAIL(23);
                 used += (uint32_t)u;
                 // predefined length tables and offsets that are all "repeat offset 1" (an RLE table of code 0): what zstd_encode.hip
@@ -427,12 +576,13 @@ __device__ bool ref_frame(RefLds<FPW>& S, int l, const ReadBatch& b, uint32_t r,
                 // (libzstd's frames of nanopore signal have the same offsets -- its matches are the zero runs of the control bytes --
                 // but FSE-coded length tables of 9 bits, which that path does not take: they are walked here)
                 if (modes == 0x10u && used < hn && hdr_byte(S, l, used) == 0) BAIL(22);
-                u = ref_seq_table(S, l, tab + T_OF, &log_of, &have_of, (modes >> 4) & 3, used, (int)(hn - used), 1);
+                u = ref_seq_table(S, G, l, T_OF, &log_of, &have_of, (modes >> 4) & 3, used, (int)(hn - used), 1);
                 if (u < 0) BAIL(24);
                 used += (uint32_t)u;
-                u = ref_seq_table(S, l, tab + T_ML, &log_ml, &have_ml, (modes >> 2) & 3, used, (int)(hn - used), 2);
+                u = ref_seq_table(S, G, l, T_ML, &log_ml, &have_ml, (modes >> 2) & 3, used, (int)(hn - used), 2);
                 if (u < 0) BAIL(25);
                 used += (uint32_t)u;
+                const unsigned long long t1 = __builtin_readcyclecounter();
                 if (used >= hn) BAIL(26);  // (hn < sqn: a header longer than the staged bytes is left to the careful decoder)
                 // a frame may claim 16 bytes of records per 16 bytes of its content (libzstd on nanopore signal: one sequence per ~110
                 // bytes): the claims of a call then fit a workspace of the size of the call's content whatever the frames are
@@ -441,9 +591,13 @@ __device__ bool ref_frame(RefLds<FPW>& S, int l, const ReadBatch& b, uint32_t r,
                 const unsigned long long first = atomicAdd(recs_used, (unsigned long long)ns);
                 if (first + ns > recs_cap) BAIL(27);  // (a workspace capped below the content: nothing behind this claim fits either)
                 uint64_t end = 0;
-                const uint32_t why = ref_chain(sq + used, sqn - used, src_off + pos + lit_end + used, tab, (uint32_t)log_ll, (uint32_t)log_of,
+                const uint32_t why = ref_chain(S, G, l, sq + used, sqn - used, src_off + pos + lit_end + used, (uint32_t)log_ll, (uint32_t)log_of,
                                                (uint32_t)log_ml, recs + first, ns, regen, opos, fcs, rep, &end);
                 if (why) BAIL(why);
+                const unsigned long long t2 = __builtin_readcyclecounter();
+                P->pad[1] = (uint32_t)(t1 - t0);   // (diagnostics: cycles of the tables and of the chain of the frame's last block)
+                P->pad[2] = (uint32_t)(t2 - t1);
+                P->pad[3] = ns;
                 if (end > fcs || end - opos > BLOCK_MAX || end - opos > block_max) BAIL(29);
                 RefBlock& B = P->blk[nblk++];
                 B.pos = block_at;
@@ -467,37 +621,57 @@ __device__ bool ref_frame(RefLds<FPW>& S, int l, const ReadBatch& b, uint32_t r,
 
 #undef BAIL
 
-// REF_SLOTS lanes in all (FPW of a wavefront's 64 carry a frame: fewer frames per wavefront = fewer scattered requests per
-// instruction, more wavefronts); lane `slot` takes frames slot, slot + REF_SLOTS, ... and owns table area `slot`.
-template <int FPW>
-__global__ __launch_bounds__(WAVE) void ref_chain_kernel(ReadBatch b, const uint32_t* redo, RefPre* pre, uint2* tables, uint4* recs,
-                                                         uint64_t recs_cap, unsigned long long* recs_used)
+// Lane `slot` takes frames slot, slot + slots, ...; INLDS: REF_GRID wavefronts of REF_FPW frames, tables in LDS; else wavefronts of
+// REF_FPW_MEM frames with the lane's tables at tables + slot * REF_TAB_BYTES.
+template <int FPW, bool INLDS>
+__global__ __launch_bounds__(WAVE) void ref_chain_kernel(ReadBatch b, const uint32_t* redo, RefPre* pre, uint4* recs, uint64_t recs_cap,
+                                                         unsigned long long* recs_used, uint8_t* tables)
 {
-    __shared__ RefLds<FPW> S;
+    __shared__ RefLds<FPW, INLDS> S;
     const int l = threadIdx.x;
+    if (l < 36) S.llb[l] = LL_BASE[l];
+    if (l < 53) S.mlb[l] = ML_BASE[l];
+    __syncthreads();
     if (l >= FPW) return;
-    const uint32_t slot = blockIdx.x * (uint32_t)FPW + (uint32_t)l;
-    uint2* tab = tables + (size_t)slot * T_ALL;
-    for (uint32_t r = slot; r < b.n_reads; r += REF_SLOTS) {
+    const uint32_t slots = gridDim.x * (uint32_t)FPW, slot = blockIdx.x * (uint32_t)FPW + (uint32_t)l;
+    RefGlobal G = { nullptr, nullptr };
+    if constexpr (!INLDS) {
+        uint8_t* t = tables + (size_t)slot * REF_TAB_BYTES;
+        G.bn = (__attribute__((address_space(1))) uint16_t*)t;
+        G.cx = (__attribute__((address_space(1))) uint8_t*)(t + 2 * T_ALL);
+    }
+    for (uint32_t r = slot; r < b.n_reads; r += slots) {
         RefPre* P = pre + r;
         bool ok = false;
-        if (redo[r]) ok = ref_frame<FPW>(S, l, b, r, P, tab, recs, recs_cap, recs_used);
+        if (redo[r]) ok = ref_frame<FPW, INLDS>(S, G, l, b, r, P, recs, recs_cap, recs_used);
         P->ok = ok ? 1u : 0u;
     }
+}
+
+// which way a call goes: a batch that fits one round of the LDS kernel takes it (a round = the chain's latency with an LDS round
+// trip per sequence); a larger batch keeps its tables in memory, every frame in flight at once
+__host__ bool ref_in_lds(uint32_t n_reads)
+{
+    static const int force = [] {
+        const char* e = getenv("VBZ_HIP_REF_TABLES");  // lds | mem (measurements)
+        return e ? (e[0] == 'l' ? 1 : (e[0] == 'm' ? 2 : 0)) : 0;
+    }();
+    return force ? force == 1 : n_reads <= (uint32_t)(REF_GRID * REF_FPW);
+}
+__host__ uint32_t ref_mem_waves(uint32_t n_reads)
+{
+    const uint32_t w = (n_reads + REF_FPW_MEM - 1) / REF_FPW_MEM;
+    return w < REF_MEM_WAVES_MAX ? w : REF_MEM_WAVES_MAX;
 }
 
 }  // namespace
 
 size_t zstd_ref_pre_bytes(uint32_t n_reads) { return (size_t)n_reads * sizeof(RefPre) + 64; }
 const RefPre* zstd_ref_pre(const void* pre_meta) { return reinterpret_cast<const RefPre*>(reinterpret_cast<const uint8_t*>(pre_meta) + 64); }
-size_t zstd_ref_table_bytes() { return (size_t)REF_SLOTS * T_ALL * sizeof(uint2); }
+size_t zstd_ref_table_bytes(uint32_t n_reads) { return ref_in_lds(n_reads) ? 0 : (size_t)ref_mem_waves(n_reads) * REF_FPW_MEM * REF_TAB_BYTES; }
 
-#ifndef VBZ_REF_FPW
-#define VBZ_REF_FPW 64
-#endif
-
-hipError_t launch_zstd_ref_chain(const ReadBatch& b, const uint32_t* redo, void* pre_meta, void* tables, void* recs, uint64_t recs_cap,
-                                 RefChains* out, hipStream_t s)
+hipError_t launch_zstd_ref_chain(const ReadBatch& b, const uint32_t* redo, void* pre_meta, void* tables, void* recs, uint64_t recs_cap, RefChains* out,
+                                 hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     uint8_t* m = reinterpret_cast<uint8_t*>(pre_meta);
@@ -507,9 +681,13 @@ hipError_t launch_zstd_ref_chain(const ReadBatch& b, const uint32_t* redo, void*
     out->recs = recs;
     hipError_t e = hipMemsetAsync(used, 0, 8, s);
     if (e != hipSuccess) return e;
-    constexpr int FPW = VBZ_REF_FPW;
-    hipLaunchKernelGGL(ref_chain_kernel<FPW>, dim3(REF_SLOTS / FPW), dim3(WAVE), 0, s, b, redo, pre, reinterpret_cast<uint2*>(tables),
-                       reinterpret_cast<uint4*>(recs), recs_cap, used);
+    static_assert(sizeof(RefLds<REF_FPW, true>) * 4 <= 160 * 1024, "four wavefronts' tables per CU");
+    if (ref_in_lds(b.n_reads))
+        hipLaunchKernelGGL((ref_chain_kernel<REF_FPW, true>), dim3(REF_GRID), dim3(WAVE), 0, s, b, redo, pre, reinterpret_cast<uint4*>(recs), recs_cap, used,
+                           (uint8_t*)nullptr);
+    else
+        hipLaunchKernelGGL((ref_chain_kernel<REF_FPW_MEM, false>), dim3(ref_mem_waves(b.n_reads)), dim3(WAVE), 0, s, b, redo, pre,
+                           reinterpret_cast<uint4*>(recs), recs_cap, used, reinterpret_cast<uint8_t*>(tables));
     return hipGetLastError();
 }
 
