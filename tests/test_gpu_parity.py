@@ -1437,16 +1437,18 @@ pickle.dump(out, open(sys.argv[2], 'wb'))
     with tempfile.TemporaryDirectory() as td:
         pickle.dump((reads, wide, frames16, frames32, zoo, zoo_n, bad, bad_n), open(os.path.join(td, "in.pkl"), "wb"))
         outs = {}
-        for walk in ("1", "0"):
-            env = dict(os.environ, VBZ_HIP_REF_CHAINS=walk, VBZ_HIP_SEGMENTED="0", VBZ_HIP_ROUTING="0")
-            subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.pkl"), os.path.join(td, "out%s.pkl" % walk)], check=True, env=env)
-            outs[walk] = pickle.load(open(os.path.join(td, "out%s.pkl" % walk), "rb"))
-    on, off = outs["1"], outs["0"]
+        # walked with the tables in LDS (what a batch of this size gets), walked with the tables in memory (what a batch of more
+        # than 9216 frames gets), not walked
+        for walk, tables in (("1", "lds"), ("1", "mem"), ("0", "lds")):
+            env = dict(os.environ, VBZ_HIP_REF_CHAINS=walk, VBZ_HIP_REF_TABLES=tables, VBZ_HIP_SEGMENTED="0", VBZ_HIP_ROUTING="0")
+            subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.pkl"), os.path.join(td, "out.pkl")], check=True, env=env)
+            outs[walk + tables] = pickle.load(open(os.path.join(td, "out.pkl"), "rb"))
+    on, mem, off = outs["1lds"], outs["1mem"], outs["0lds"]
     for k in ("i16", "i32", "zoo", "bad"):
-        assert len(on[k]) == len(off[k])
-        for i, (a, b) in enumerate(zip(on[k], off[k])):
-            assert a == b, (k, i)
-        assert off[k + "_paths"][2] == 0
+        assert len(on[k]) == len(off[k]) == len(mem[k])
+        for i, (a, b, c) in enumerate(zip(on[k], off[k], mem[k])):
+            assert a == b and a == c, (k, i)
+        assert off[k + "_paths"][2] == 0 and mem[k + "_paths"] == on[k + "_paths"]
     for i, f in enumerate(frames16):
         assert on["i16"][i] == reads[i % len(reads)].tobytes(), i
     for i, f in enumerate(frames32):
@@ -1464,7 +1466,6 @@ pickle.dump(out, open(sys.argv[2], 'wb'))
     assert refused > 40
     # which frames were walked: every level-1 frame of a read with sequences and at most four blocks of them
     n16, _, w16 = on["i16_paths"]
-    print('paths', on['i16_paths'], on['i32_paths'], on['zoo_paths'], on['bad_paths'])
     assert n16 == len(frames16) and w16 >= 3 * 13, on["i16_paths"]      # (not: the empty read, zeros, noise, 1 sample, > 4 blocks)
     assert on["i32_paths"][2] >= len(frames32) - 2, on["i32_paths"]
     assert on["zoo_paths"][2] >= on["zoo_paths"][0] // 2, on["zoo_paths"]

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per-phase shader-clock cycles of the two entropy kernels for ONE read on an otherwise idle GPU (a lone wavefront):
 
-    VBZ_HIP_PHASE_TIMING=1 VBZ_HIP_SEGMENTED=0 python tools/phase_timing.py [samples ...]
+    VBZ_HIP_PHASE_TIMING=1 VBZ_HIP_SEGMENTED=0 python tools/phase_timing.py [--reference] [samples ...]
+
+--reference: the frame is written by the oracle (the reference path + libzstd) instead of the device encoder.
 
 The library prints the phase lines on stderr (see dbg_end in vbz_api.hip).  The kernels are latency-bound per wavefront
 (a lone wavefront issues about one instruction every ten cycles), so these numbers track what a change does to a frame's
@@ -18,8 +20,11 @@ import gpu_util as G  # noqa: E402
 from vbz_compression_amd import _lib  # noqa: E402
 
 opts = _lib.CompressionOptions(True, 2, 1, 1)
-for n in [int(x) for x in sys.argv[1:]] or [100000, 100000]:
+args = sys.argv[1:]
+reference = "--reference" in args
+args = [x for x in args if x != "--reference"]
+for n in [int(x) for x in args] or [100000, 100000]:
     a = O.synth_signal(5, 1, n)
-    f = G.compress([a], opts)
+    f = [O.compress(a, O.options(True, 2, 1, 1))] if reference else G.compress([a], opts)
     b = G.decompress(f, [a.nbytes], opts)
     assert b[0].tobytes() == a.tobytes()

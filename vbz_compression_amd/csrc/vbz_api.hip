@@ -462,7 +462,7 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
     hipStream_t s = c->stream;
     Timed t(c, "zstd_decode");
     c->last_frames = 0;
-    if (!c->fast_decode || dbg) {
+    if (!c->fast_decode) {
         HIPCHK(c, launch_zstd_decode(z, toosmall_code, dbg, c->seqdtab.p, s), "zstd_decode launch");
         return 0;
     }
@@ -475,9 +475,9 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
         (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
         return -1;
     HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, c->ref_chains ? c->refpre.p : nullptr, c->reftab.p, c->refrecs.p,
-                                      recs_bytes / 16, s),
+                                      recs_bytes / 16, dbg, s),
            "zstd_decode (batched) launch");
-    c->last_frames = n;
+    c->last_frames = dbg ? 0 : n;
     return 0;
 }
 

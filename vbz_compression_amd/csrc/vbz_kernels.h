@@ -132,18 +132,19 @@ size_t zstd_ref_table_bytes(uint32_t n_reads);     // 0: a batch of this size ke
 // pre_meta: zstd_ref_pre_bytes(n_reads); tables: zstd_ref_table_bytes(n_reads); recs: recs_cap records of 16 bytes.  *out: for the decoder.
 hipError_t launch_zstd_ref_chain(const ReadBatch& b, const uint32_t* redo, void* pre_meta, void* tables, void* recs, uint64_t recs_cap, RefChains* out,
                                  hipStream_t s);
-// The one-wavefront decoder for the reads with only[i] != 0 (the others are left alone).
+// The one-wavefront decoder for the reads with only[i] != 0 (the others are left alone); dbg: phase cycle counters (nullable).
 hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, const uint32_t* only, RefChains chains,
-                                   hipStream_t s);
+                                   unsigned long long* dbg, hipStream_t s);
 // Batched decoder for frames of the shape zstd_encode.hip writes (zstd_decode_fast.hip: one lane per frame for the headers, one lane
 // per tree description, one wavefront per frame for nothing but the streams, one for the zero-run block); every frame that is not of
 // that shape or fails a check, and every error verdict, goes through launch_zstd_decode_only at the end.  Same results as
 // launch_zstd_decode.  meta: zstd_fast_meta_bytes(n_reads) bytes of device scratch.
 // ref_*: scratch of launch_zstd_ref_chain (ref_pre == nullptr: frames of other writers go to the one-wavefront decoder as they are).
+// dbg (nullable): phase cycle counters of the one-wavefront decoder, which then decodes EVERY frame (walked chains included).
 size_t zstd_fast_meta_bytes(uint32_t n_reads);
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads);  // after the call: redo[i] == 0 <=> frame i was decoded by the batched decoder
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
-                                   void* ref_recs, uint64_t ref_recs_cap, hipStream_t s);
+                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, hipStream_t s);
 size_t seq_dtables_bytes();
 void seq_dtables_build(void* host_buffer);
 // The same for batches of few, large reads: frames that carry the encoder's span index are decoded one span per wavefront

@@ -2605,12 +2605,16 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
 }
 
 hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, const uint32_t* only, RefChains chains,
-                                   hipStream_t s)
+                                   unsigned long long* dbg, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     const SvbFuse none = { nullptr, nullptr, nullptr };
-    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
-                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none, chains);
+    if (dbg)
+        hipLaunchKernelGGL((zstd_decode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none, chains);
+    else
+        hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
+                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none, chains);
     return hipGetLastError();
 }
 

@@ -769,7 +769,7 @@ const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads)
 }
 
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
-                                   void* ref_recs, uint64_t ref_recs_cap, hipStream_t s)
+                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, hipStream_t s)
 {
     const uint32_t n = b.n_reads;
     if (n == 0) return hipSuccess;
@@ -781,19 +781,26 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
     uint8_t* weights = m;
     m += (size_t)n * 512;
     uint32_t* redo = reinterpret_cast<uint32_t*>(m);
-    hipLaunchKernelGGL(fast_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, frames, tasks, redo);
+    if (dbg) {  // phase timing: every frame to the one-wavefront decoder
+        const hipError_t e1 = hipMemsetAsync(redo, 1, 4ull * n, s);
+        if (e1 != hipSuccess) return e1;
+    } else {
+        hipLaunchKernelGGL(fast_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, frames, tasks, redo);
+    }
     // what the scan does not recognise may be a frame the reference wrote: its sequence chains, one lane per frame
     RefChains chains;
     if (ref_pre) {
         const hipError_t e0 = launch_zstd_ref_chain(b, redo, ref_pre, ref_tables, ref_recs, ref_recs_cap, &chains, s);
         if (e0 != hipSuccess) return e0;
     }
+    if (!dbg) {
     hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo);
     hipLaunchKernelGGL(fast_streams_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, tasks, weights, redo);
     hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    return launch_zstd_decode_only(b, toosmall_code, seq_dtables, redo, chains, s);  // whatever is not of the shape, and every error verdict
+    return launch_zstd_decode_only(b, toosmall_code, seq_dtables, redo, chains, dbg, s);  // whatever is not of the shape, and every error verdict
 }
 
 }  // namespace vbzhip
