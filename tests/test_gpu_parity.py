@@ -1362,7 +1362,7 @@ pickle.dump([o if isinstance(o, int) else o.tobytes() for o in out], open(sys.ar
 def test_walked_chains_of_reference_frames():
     """zstd_decode_ref.hip walks the sequence chains of frames the reference wrote (libzstd: FSE-coded sequences, Repeat_Mode tables,
     several blocks) one lane per frame and hands the records to the one-wavefront decoder.  The call must give exactly what it gives
-    with VBZ_HIP_REF_CHAINS=0 -- same bytes, same verdicts, damaged frames included -- the walked frames must be the ones expected
+    with VBZ_HIP_REF_CHAINS=0 (2 = walk whatever the size of the call; by default calls of 2 560 reads and more do) -- same bytes, same verdicts, damaged frames included -- the walked frames must be the ones expected
     (vbz_gpu_decode_paths), and the bytes must be the reference's."""
     import pickle
     import subprocess
@@ -1393,6 +1393,13 @@ out = {}
 caps16 = [a.nbytes for a in reads] * (len(frames16) // len(reads))
 out['i16'] = G.decompress(frames16, caps16, _lib.CompressionOptions(True, 2, 1, 1))
 out['i16_paths'] = G.codec().decode_paths()
+# both kinds of frame in one call: the walk runs beside the batched decoder's launches for this library's frames
+own = G.compress(reads, _lib.CompressionOptions(True, 2, 1, 1))
+mix, mixcaps = [], []
+for a, f, g in zip(reads, own, frames16[: len(reads)]):
+    mix += [f, g]; mixcaps += [a.nbytes, a.nbytes]
+out['mix'] = G.decompress(mix, mixcaps, _lib.CompressionOptions(True, 2, 1, 1))
+out['mix_paths'] = G.codec().decode_paths()
 caps32 = [a.nbytes for a in wide] * (len(frames32) // len(wide))
 out['i32'] = G.decompress(frames32, caps32, _lib.CompressionOptions(True, 4, 1, 1))
 out['i32_paths'] = G.codec().decode_paths()
@@ -1400,7 +1407,7 @@ out['zoo'] = G.zstd_decompress(zoo, zoo_n)
 out['zoo_paths'] = G.codec().decode_paths()
 out['bad'] = G.zstd_decompress(bad, bad_n)
 out['bad_paths'] = G.codec().decode_paths()
-for k in ('i16', 'i32', 'zoo', 'bad'):
+for k in ('i16', 'mix', 'i32', 'zoo', 'bad'):
     out[k] = [o if isinstance(o, int) else o.tobytes() for o in out[k]]
 pickle.dump(out, open(sys.argv[2], 'wb'))
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
@@ -1439,18 +1446,22 @@ pickle.dump(out, open(sys.argv[2], 'wb'))
         outs = {}
         # walked with the tables in LDS (what a batch of this size gets), walked with the tables in memory (what a batch of more
         # than 9216 frames gets), not walked
-        for walk, tables in (("1", "lds"), ("1", "mem"), ("0", "lds")):
+        for walk, tables in (("2", "lds"), ("2", "mem"), ("0", "lds")):
             env = dict(os.environ, VBZ_HIP_REF_CHAINS=walk, VBZ_HIP_REF_TABLES=tables, VBZ_HIP_SEGMENTED="0", VBZ_HIP_ROUTING="0")
             subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.pkl"), os.path.join(td, "out.pkl")], check=True, env=env)
             outs[walk + tables] = pickle.load(open(os.path.join(td, "out.pkl"), "rb"))
-    on, mem, off = outs["1lds"], outs["1mem"], outs["0lds"]
-    for k in ("i16", "i32", "zoo", "bad"):
+    on, mem, off = outs["2lds"], outs["2mem"], outs["0lds"]
+    for k in ("i16", "mix", "i32", "zoo", "bad"):
         assert len(on[k]) == len(off[k]) == len(mem[k])
         for i, (a, b, c) in enumerate(zip(on[k], off[k], mem[k])):
             assert a == b and a == c, (k, i)
         assert off[k + "_paths"][2] == 0 and mem[k + "_paths"] == on[k + "_paths"]
     for i, f in enumerate(frames16):
         assert on["i16"][i] == reads[i % len(reads)].tobytes(), i
+    for i in range(2 * len(reads)):
+        assert on["mix"][i] == reads[i // 2].tobytes(), i
+    nmix, bmix, wmix = on["mix_paths"]
+    assert nmix == 2 * len(reads) and bmix >= 5 and wmix >= 13, on["mix_paths"]   # (own frames batched, reference frames walked)
     for i, f in enumerate(frames32):
         assert on["i32"][i] == wide[i % len(wide)].tobytes(), i
     for i, (c, lv) in enumerate((c, lv) for c in zoo_src for lv in (1, 3, 9)):

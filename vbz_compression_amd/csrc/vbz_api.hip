@@ -69,7 +69,10 @@ struct vbz_gpu_ctx
     DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
     bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
     DevBuf refpre, reftab, refrecs;  // frames the reference wrote: per-frame hand-over, tables (large batches), records (zstd_decode_ref.hip)
-    bool ref_chains = true;    // VBZ_HIP_REF_CHAINS=0: their sequence chains are walked by the one-wavefront decoder itself
+    int ref_chains = 1;        // VBZ_HIP_REF_CHAINS: 0 their sequence chains are walked by the one-wavefront decoder itself, 1 walked ahead of
+                               // it in calls of REF_MIN_READS reads and more, 2 in every call
+    FastSide side;             // the walk's own stream (beside the launches for this library's frames)
+    bool last_walked = false;
     uint32_t last_frames = 0;  // vbz_gpu_decode_paths: the frames of the last zstd_frames call (0: none, or not on the batched path)
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
@@ -453,6 +456,8 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     return 0;
 }
 
+constexpr uint32_t REF_MIN_READS = 2560;   // calls of fewer reads: the one-wavefront decoder walks reference-written chains itself
+
 // The frames of a launch group on the one-workgroup path (not the large-read path): frames of this library's shape on the batched
 // decoder, the sequence chains of frames the reference wrote walked one lane per frame, everything else -- and every error verdict --
 // from the one-wavefront decoder.  content_bytes bounds the frames' content in all.
@@ -467,16 +472,27 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
         return 0;
     }
     if (!ensure(c, c->fastmeta, zstd_fast_meta_bytes(n))) return -1;
-    // records of walked chains: 16 bytes per sequence; a frame may claim as many bytes as it has content (zstd_decode_ref.hip), so a
+    // Frames the reference wrote: their chains are walked ahead of the one-wavefront decoder when the call is large enough for that to
+    // pay (the walk is a launch of its own whose duration is one chain's latency, ~0.7 ms: measured break-even 2 500 such frames).
+    // Records of walked chains: 16 bytes per sequence; a frame may claim as many bytes as it has content (zstd_decode_ref.hip), so a
     // workspace of the content's size always has room -- capped at 1 GiB (~9 000 sequences for each of 65 536 reads; libzstd
     // on nanopore signal writes ~1 100 per read); a frame that finds no room is decoded as before
-    const uint64_t recs_bytes = c->ref_chains ? std::min<uint64_t>((content_bytes + 4096) & ~15ull, 1ull << 30) : 0;
-    if (c->ref_chains &&
-        (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
+    const bool walk = c->ref_chains >= 2 || (c->ref_chains == 1 && n >= REF_MIN_READS);
+    const uint64_t recs_bytes = walk ? std::min<uint64_t>((content_bytes + 4096) & ~15ull, 1ull << 30) : 0;
+    if (walk && (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
         return -1;
-    HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, c->ref_chains ? c->refpre.p : nullptr, c->reftab.p, c->refrecs.p,
-                                      recs_bytes / 16, dbg, s),
+    if (walk && !c->side.stream && !dbg) {
+        if (hipStreamCreateWithFlags(&c->side.stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->side.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->side.join, hipEventDisableTiming) != hipSuccess) {
+            set_error(c, "second stream for the chain walk: %s", hipGetErrorString(hipGetLastError()));
+            return -1;
+        }
+    }
+    HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, walk ? c->refpre.p : nullptr, c->reftab.p, c->refrecs.p,
+                                      recs_bytes / 16, dbg, c->side, s),
            "zstd_decode (batched) launch");
+    c->last_walked = walk;
     c->last_frames = dbg ? 0 : n;
     return 0;
 }
@@ -781,7 +797,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);
     if (const char* e = getenv("VBZ_HIP_FUSE_SVB")) c->fuse_svb = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_FAST_DECODE")) c->fast_decode = atoi(e) != 0;
-    if (const char* e = getenv("VBZ_HIP_REF_CHAINS")) c->ref_chains = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_REF_CHAINS")) c->ref_chains = atoi(e);
     if (const char* e = getenv("VBZ_HIP_STAGED_ENCODE")) c->staged_encode = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e);
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
@@ -831,6 +847,9 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
     for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
+    if (c->side.fork) (void)hipEventDestroy(c->side.fork);
+    if (c->side.join) (void)hipEventDestroy(c->side.join);
+    if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->pinned) (void)hipHostFree(c->pinned);
@@ -952,7 +971,7 @@ int vbz_gpu_decode_paths(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)
     const uint32_t n = c->last_frames;
     if (n == 0) return 0;
     std::vector<uint32_t> redo(n);
-    std::vector<RefPre> pre(c->ref_chains ? n : 0);
+    std::vector<RefPre> pre(c->last_walked ? n : 0);
     if (hipMemcpyAsync(redo.data(), zstd_fast_redo(c->fastmeta.p, n), 4ull * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
     if (!pre.empty() && hipMemcpyAsync(pre.data(), zstd_ref_pre(c->refpre.p), sizeof(RefPre) * (size_t)n, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
         return -1;

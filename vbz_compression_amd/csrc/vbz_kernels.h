@@ -141,10 +141,15 @@ hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, c
 // launch_zstd_decode.  meta: zstd_fast_meta_bytes(n_reads) bytes of device scratch.
 // ref_*: scratch of launch_zstd_ref_chain (ref_pre == nullptr: frames of other writers go to the one-wavefront decoder as they are).
 // dbg (nullable): phase cycle counters of the one-wavefront decoder, which then decodes EVERY frame (walked chains included).
+struct FastSide  // a second stream (and two events) on which the chain walk runs beside the launches for own frames; stream == nullptr: none
+{
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
 size_t zstd_fast_meta_bytes(uint32_t n_reads);
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads);  // after the call: redo[i] == 0 <=> frame i was decoded by the batched decoder
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
-                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, hipStream_t s);
+                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, FastSide side, hipStream_t s);
 size_t seq_dtables_bytes();
 void seq_dtables_build(void* host_buffer);
 // The same for batches of few, large reads: frames that carry the encoder's span index are decoded one span per wavefront

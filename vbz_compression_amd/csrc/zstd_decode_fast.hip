@@ -760,7 +760,7 @@ __global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const Fast
 
 size_t zstd_fast_meta_bytes(uint32_t n_reads)
 {
-    return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4) + 1024;
+    return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4 + 4) + 1024;
 }
 
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads)
@@ -769,7 +769,7 @@ const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads)
 }
 
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
-                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, hipStream_t s)
+                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, FastSide side, hipStream_t s)
 {
     const uint32_t n = b.n_reads;
     if (n == 0) return hipSuccess;
@@ -781,24 +781,46 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
     uint8_t* weights = m;
     m += (size_t)n * 512;
     uint32_t* redo = reinterpret_cast<uint32_t*>(m);
+    m += (size_t)n * 4;
+    uint32_t* scanned = reinterpret_cast<uint32_t*>(m);  // redo[] as the scan left it: what the chain walk goes by
+    hipError_t e = hipSuccess;
     if (dbg) {  // phase timing: every frame to the one-wavefront decoder
-        const hipError_t e1 = hipMemsetAsync(redo, 1, 4ull * n, s);
-        if (e1 != hipSuccess) return e1;
+        e = hipMemsetAsync(redo, 1, 4ull * n, s);
+        if (e != hipSuccess) return e;
     } else {
         hipLaunchKernelGGL(fast_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, frames, tasks, redo);
     }
-    // what the scan does not recognise may be a frame the reference wrote: its sequence chains, one lane per frame
+    // What the scan does not recognise may be a frame the reference wrote: its sequence chains, one lane per frame -- beside the
+    // launches for this library's own frames when the caller has a second stream for it (the walk is a few hundred wavefronts
+    // bound by latency; a batch of both kinds of frame would otherwise wait for it).  From the fork on nothing returns before
+    // the join is queued.
     RefChains chains;
+    const bool beside = ref_pre && side.stream && !dbg;
     if (ref_pre) {
-        const hipError_t e0 = launch_zstd_ref_chain(b, redo, ref_pre, ref_tables, ref_recs, ref_recs_cap, &chains, s);
-        if (e0 != hipSuccess) return e0;
+        e = hipMemcpyAsync(scanned, redo, 4ull * n, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return e;
+        if (beside) {
+            e = hipEventRecord(side.fork, s);
+            if (e != hipSuccess) return e;
+            e = hipStreamWaitEvent(side.stream, side.fork, 0);
+            if (e != hipSuccess) return e;
+        }
+        e = launch_zstd_ref_chain(b, scanned, ref_pre, ref_tables, ref_recs, ref_recs_cap, &chains, beside ? side.stream : s);
+        if (beside) {
+            const hipError_t e1 = hipEventRecord(side.join, side.stream);
+            if (e == hipSuccess) e = e1;
+        }
     }
-    if (!dbg) {
-    hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo);
-    hipLaunchKernelGGL(fast_streams_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, tasks, weights, redo);
-    hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
+    if (!dbg && e == hipSuccess) {
+        hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo);
+        hipLaunchKernelGGL(fast_streams_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, tasks, weights, redo);
+        hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
+        e = hipGetLastError();
     }
-    hipError_t e = hipGetLastError();
+    if (beside) {
+        const hipError_t e1 = hipStreamWaitEvent(s, side.join, 0);
+        if (e == hipSuccess) e = e1;
+    }
     if (e != hipSuccess) return e;
     return launch_zstd_decode_only(b, toosmall_code, seq_dtables, redo, chains, dbg, s);  // whatever is not of the shape, and every error verdict
 }
