@@ -28,7 +28,8 @@
  *     call is still one unit of work in stream order;
  *   - a read whose bytes repeat at one distance (a cycled template) gets that distance coded as zstd matches
  *     at every zstd_compression_level (the reference passes its level to libzstd, whose matcher is on at all
- *     of them); reads of half a megabyte and more do not.
+ *     of them), whatever its length: a long read that has such a distance is coded by one wavefront with the matcher
+ *     instead of as spans (15-60 x smaller, at one wavefront's speed).
  * Descriptor tables are untrusted like the data: before any other kernel runs, one thread per read checks
  * src_off + src_size <= src_bytes and dst_off + dst_cap <= dst_bytes (64-bit arithmetic); a read that fails gets
  * VBZ_INPUT_SIZE_ERROR or VBZ_DESTINATION_SIZE_ERROR and none of its addresses is ever formed

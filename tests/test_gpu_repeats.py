@@ -28,7 +28,7 @@ def _cycled(n, phase=0):
 
 def test_template_cycling_reads_compress_like_libzstd():
     rng = np.random.default_rng(12)
-    lengths = [30000, 47011, 65536, 100000, 123457, 200000]
+    lengths = [30000, 47011, 65536, 100000, 123457, 200000, 300000, 400000, 500000, 1000000]   # (the last four: the large-read path)
     reads = [_cycled(n, int(rng.integers(0, 15643))) for n in lengths]
     reads.append(O.synth_signal(5, 3, 100000))                       # nothing periodic: must not get worse
     reads.append(np.tile(O.synth_signal(5, 4, 5000), 20)[:99999])    # a short period (5 000 samples)
@@ -43,9 +43,14 @@ def test_template_cycling_reads_compress_like_libzstd():
             assert O.decompress(f, a.nbytes, oo).tobytes() == a.tobytes()                # ... and so does the reference's decoder
             ref = O.compress(a, oo)                                                      # libzstd at the SAME level
             r, rr = a.nbytes / len(f), a.nbytes / len(ref)
-            if i < len(lengths):
+            if i < len(lengths) and len(a) > 524288:
+                # more control bytes than one block holds: they are Huffman coded, without the runs;
+                # round 3 coded such a read as spans, 2.4 x
+                assert r > 40 and r > 0.25 * rr, (level, i, r, rr)
+                print("cycled read of %d samples, level %d: %.2f, libzstd %.2f" % (len(a), level, r, rr))
+            elif i < len(lengths):
                 # same options, same input: about what libzstd gets (T2; round 2 asserted r < 3 here at level 1)
-                assert r > 0.8 * rr, (level, i, r, rr)
+                assert r > (0.8 if len(a) <= 400000 else 0.75) * rr, (level, i, r, rr)
                 print("cycled read of %d samples, level %d: %.2f, libzstd %.2f" % (len(a), level, r, rr))
             elif i == len(lengths):
                 assert abs(r / rr - 1) < (0.01 if level == 1 else 0.02), (level, r, rr)  # plain signal: the +-1 % contract (level 1)
@@ -81,6 +86,6 @@ def test_matcher_on_every_dtype_and_shape():
                     assert not isinstance(f, int) and not isinstance(b, int), (len(a), size, zz, sized)
                     assert b.tobytes() == a.tobytes()
                     assert O.decompress(f, a.nbytes, oo, sized=sized).tobytes() == a.tobytes()
-                    if len(a) >= 32768 and len(a) <= 150000 and a.nbytes < 512 * 1024:   # (half a megabyte and more: the large-read path, no matcher)
+                    if len(a) >= 32768:   # (half a megabyte and more take the large-read path: the matcher runs in front of it)
                         ref = O.compress(a, oo, sized=sized)      # libzstd at the same level
                         assert len(f) <= 1.6 * len(ref) + 64 or len(f) <= 0.45 * a.nbytes, (len(a), size, zz, len(f), len(ref))

@@ -21,10 +21,12 @@ from vbz_compression_amd import _lib  # noqa: E402
 
 opts = _lib.CompressionOptions(True, 2, 1, 1)
 args = sys.argv[1:]
+a_seen = []   # (a different read of the generator each time)
 reference = "--reference" in args
 args = [x for x in args if x != "--reference"]
 for n in [int(x) for x in args] or [100000, 100000]:
-    a = O.synth_signal(5, 1, n)
+    a = O.synth_signal(5, 1 + len(a_seen), n)
+    a_seen.append(n)
     f = [O.compress(a, O.options(True, 2, 1, 1))] if reference else G.compress([a], opts)
     b = G.decompress(f, [a.nbytes], opts)
     assert b[0].tobytes() == a.tobytes()

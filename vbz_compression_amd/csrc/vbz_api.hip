@@ -422,13 +422,15 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         uint32_t* span_trail = sm.take<uint32_t>(max_spans);
         uint32_t* span_dst = sm.take<uint32_t>(max_spans);
         z.gate = gate;
-        if (c->zero_run_sequences && c->long_repeats && o->integer_size != 0 && src_bytes / n < SEGMENTED_MIN_AVG) {
-            // a batch that is here because it is small, not because its reads are large: reads that repeat at one distance go
-            // to the one-wavefront matcher after all (reads below the routing threshold: the same reads that get the matcher
-            // in a batch of thousands)
+        if (c->zero_run_sequences && c->long_repeats && o->integer_size != 0) {
+            // reads that repeat at one distance go to the one-wavefront matcher after all, whatever their length: a read that
+            // cycles a template (the reference's own perf generator: vbz/perf/test_data_generator.h:61-67) is 15-30 x smaller as
+            // matches than as spans of Huffman blocks, which is worth one wavefront's time on it (libzstd, the reference's
+            // coder, finds those matches at every level and every length: vbz/vbz.cpp:194-207).  The probe looks at the head of
+            // a long read's data bytes only (PROBE_WINDOW in zstd_encode.hip): a few microseconds for a read that has no period.
             uint32_t* gate2 = mc.take<uint32_t>(n);
             Timed t(c, "zstd_encode_matcher");
-            HIPCHK(c, launch_zstd_encode_matcher(z, bt->src_size, o->integer_size, hdr, svb_cap, c->seqtab.p, c->trailers, (uint32_t)SEGMENTED_MIN_AVG,
+            HIPCHK(c, launch_zstd_encode_matcher(z, bt->src_size, o->integer_size, hdr, svb_cap, c->seqtab.p, c->trailers, 0xFFFFFFFFu,
                                                  deep_d, gate, gate2, s),
                    "zstd_encode (matcher) launch");
             z.gate = gate2;

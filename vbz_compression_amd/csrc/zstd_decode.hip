@@ -67,6 +67,9 @@ struct DecLds
 // one wave per workgroup: the frame's LDS state.  At namespace scope so that functions that are real calls
 // (not inlined, to keep the kernel's register footprint down) still address it as LDS.
 __shared__ __attribute__((aligned(16))) DecLds L;
+#ifdef VBZ_SPLIT_DEBUG
+__shared__ uint32_t split_dbg[2];  // (measurements: passes over the pieces of split streams, lanes walking in them)
+#endif
 
 // ctl slots
 enum { C_ERR = 0, C_A, C_B, C_C, C_D, C_E, C_F, C_G, C_H, C_I, C_J, C_K };
@@ -1028,6 +1031,15 @@ __device__ __noinline__ bool huf_split_plan(const uint8_t* src, uint32_t& ntask,
     bool need = act;
     for (int round = 0; round < 18; ++round) {
         if (!__any(need)) break;
+#ifdef VBZ_SPLIT_DEBUG
+        {
+            const uint32_t nn = (uint32_t)__popcll(__ballot(need));
+            if (lane == 0) {
+                split_dbg[0] += 1;
+                split_dbg[1] += nn;
+            }
+        }
+#endif
         const uint2 r = huf_dry_walk(p, nbytes, need, s_bit, c_hi, tab, lane);
         if (__any(need && r.x == 0xFFFFFFFFu)) return false;
         if (need) {
@@ -1548,6 +1560,9 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         return;                                                         \
     } while (0)
 
+#ifdef VBZ_SPLIT_DEBUG
+    if (lane == 0) split_dbg[0] = split_dbg[1] = 0;
+#endif
     // ---- frame header (RFC 8878 3.1.1.1)
     stage_bytes(L.u.p.hbuf, src, n < 32 ? n : 32, lane);
     if (lane == 0) {
@@ -2413,6 +2428,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     } else if (lane == 0) {
         b.result[r] = fcs;
     }
+#ifdef VBZ_SPLIT_DEBUG
+    tph[2] = split_dbg[0];
+    tph[3] = split_dbg[1];
+#endif
     if (TIMED && lane == 0 && !dspans)
         for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
 #undef SQB
