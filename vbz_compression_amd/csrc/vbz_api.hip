@@ -427,7 +427,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
             // cycles a template (the reference's own perf generator: vbz/perf/test_data_generator.h:61-67) is 15-30 x smaller as
             // matches than as spans of Huffman blocks, which is worth one wavefront's time on it (libzstd, the reference's
             // coder, finds those matches at every level and every length: vbz/vbz.cpp:194-207).  The probe looks at the head of
-            // a long read's data bytes only (PROBE_WINDOW in zstd_encode.hip): a few microseconds for a read that has no period.
+            // a long read's data bytes only (PROBE_WINDOW in zstd_encode.hip): two short launches for a read that has no period.
             uint32_t* gate2 = mc.take<uint32_t>(n);
             Timed t(c, "zstd_encode_matcher");
             HIPCHK(c, launch_zstd_encode_matcher(z, bt->src_size, o->integer_size, hdr, svb_cap, c->seqtab.p, c->trailers, 0xFFFFFFFFu,

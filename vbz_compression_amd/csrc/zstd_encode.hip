@@ -2364,7 +2364,7 @@ __global__ __launch_bounds__(256) void zstd_span_compact_kernel(ReadBatch b, con
 //     Its first wavefront then makes the check zstd_encode_kernel<.., false> makes at its top (period_holds, deep_layout):
 //     deep_d[r] = the distance or 0, gate_out[r] = GATE_SKIP for the reads the matcher takes.
 constexpr uint32_t PP_TABLE = 512, PP_P0 = 256, PP_TRIES = 4, PP_SHIFT = 80;
-constexpr uint32_t PROBE_WINDOW = 512u << 10;   // data bytes of a read that the separate probe pass looks at
+constexpr uint32_t PROBE_WINDOW = 128u << 10;   // data bytes of a read that the separate probe pass looks at (distances up to ~127 KB)
 __device__ __forceinline__ uint32_t pp_hash(uint32_t w) { return (w * 0x9E3779B1u) >> 23; }
 
 __device__ __forceinline__ uint32_t matcher_region(const ReadBatch& b, uint32_t r, const uint32_t* orig_size, uint32_t key_elem, uint32_t max_raw,
@@ -2428,9 +2428,7 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
         // (a long read: the head of its data bytes is looked at -- a period shows there or the read is not periodic; period_holds
         // below asks eight places spread over ALL of it)
         const uint32_t nchunk = (SD < PROBE_WINDOW ? SD : PROBE_WINDOW) >> 4;
-        for (uint32_t c = tid; c < nchunk; c += 256) {
-            const uint32_t at = 16u * c;
-            const uint32_t w = dword_at(at);
+        auto look_up = [&](uint32_t at, uint32_t w) {
             const uint32_t h = pp_hash(w);
             if (val[h] == w) {   // rare: compare the chunk with the 16 bytes behind that probe
                 const uint32_t from = p0 + idx[h];
@@ -2440,6 +2438,16 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
                     if (same) atomicMin(&best, at - from);
                 }
             }
+        };
+        // four chunks per thread and trip, their loads in flight together (the pass is a chain of memory round trips otherwise)
+        for (uint32_t c = tid; c < nchunk; c += 4 * 256) {
+            uint32_t w[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c + 256u * q < nchunk) __builtin_memcpy(&w[q], data + 16u * (c + 256u * q), 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (c + 256u * q < nchunk) look_up(16u * (c + 256u * q), w[q]);
         }
     }
     __syncthreads();
