@@ -21,9 +21,10 @@ def _run(tool, seconds, seed, env=None):
     return r.stdout
 
 
-@pytest.mark.parametrize("seed,env", [(3, {}), (20260902, {"VBZ_HIP_SEGMENTED": "0"}), (7, {"VBZ_HIP_SEGMENTED": "1"})])
+# (the second slice: the one-wavefront / batched kernels forced, and every reference-written frame's sequence chain walked ahead)
+@pytest.mark.parametrize("seed,env", [(3, {}), (20260902, {"VBZ_HIP_SEGMENTED": "0", "VBZ_HIP_REF_CHAINS": "2"}), (7, {"VBZ_HIP_SEGMENTED": "1"})])
 def test_soak_slice(seed, env):
-    out = _run("soak.py", 18, seed, env)
+    out = _run("soak.py", 13, seed, env)
     assert "reads" in out
 
 
