@@ -762,7 +762,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
 // ------------------------------------------------------------------------------------------------
 extern "C" {
 
-const char* vbz_gpu_version(void) { return "vbz_hip 0.3.0 gfx950"; }
+const char* vbz_gpu_version(void) { return "vbz_hip 0.4.0 gfx950"; }
 
 vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
 {
