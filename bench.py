@@ -172,6 +172,7 @@ def decode_reference_frames(codec, n_reads=16384, launches=5):
     torch.cuda.synchronize()
     codec.profile(False)
     prof = codec.profile_read()
+    paths = codec.decode_paths()   # (frames, decoded by the batched own-frame decoder, sequence chains walked ahead) of the last call
     ms = e0.elapsed_time(e1) / launches
     raw = int(sizes.sum())
     per = {k: round(v[1] / max(v[0], 1), 4) for k, v in prof.items()}
@@ -182,6 +183,7 @@ def decode_reference_frames(codec, n_reads=16384, launches=5):
         "entropy_stage_ms_per_2048_reads": round(per.get("zstd_decode", 0.0) * 2048 / n_reads, 4),
         "hbm_frac": round((2 + c) * (raw / 2) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
         "ratio": round(raw / float(fsizes.sum()), 4), "verified": ok,
+        "chains_walked_ahead": paths[2],   # frames whose sequence chains zstd_decode_ref.hip walked (one lane per frame)
         "frames": "written by the oracle: the reference path restated + libzstd %s level 1 (one 128 KB block per read, general sequences, "
                   "no decoder hints), %d host threads, %.1f s" % ((O.lib().vbo_zstd_version() or b"?").decode(), usable_cpus()[0], t_make),
         "note": "decode only, inputs resident in HBM; never `value`",
