@@ -79,7 +79,7 @@ struct vbz_gpu_ctx
     bool zero_run_sequences = true;
     bool fuse_svb = false;     // VBZ_HIP_FUSE_SVB=1: the frame's wavefront decodes the svb stream too (measured slower: DESIGN.md 4.4)
     int long_repeats = 1;  // VBZ_HIP_LONG_REPEATS=0: no search for a repeat distance (experiments: 2 = probe only, 3 = second launch only)
-    bool phase_timing = false;
+    int phase_timing = 0;      // VBZ_HIP_PHASE_TIMING: 1 phase counters of the entropy kernels (one launch per frame), 2 of the encoder's planning launch (staged, under load)
     bool trace = false;        // VBZ_HIP_TRACE=1: synchronise after every launch group and name it on stderr (to find a faulting kernel)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -446,7 +446,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     {
         Timed t(c, "zstd_encode");
         void* plan = nullptr;
-        if (c->staged_encode && !dbg && c->zero_run_sequences) {
+        if (c->staged_encode && (!dbg || c->phase_timing == 2) && c->zero_run_sequences) {
             if (!ensure(c, c->encplan, zstd_encode_plan_bytes(n))) return -1;
             plan = c->encplan.p;
         }
@@ -454,7 +454,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
                                      c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, plan, s),
                "zstd_encode launch");
     }
-    dbg_end(c, n, "zstd_encode: setup hist plan size hdr encode", dbg);
+    dbg_end(c, n, c->phase_timing == 2 ? "zstd_encode planning launch: setup hist plan - store+sequences - | plan: sort merge lengths codes weights tree" : "zstd_encode: setup hist plan size hdr encode", dbg);
     return 0;
 }
 
@@ -793,7 +793,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     }
     vbz_gpu_ctx* c = new vbz_gpu_ctx();
     c->device = device;
-    if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e);
     if (const char* e = getenv("VBZ_HIP_TRACE")) c->trace = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ZERO_RUN_SEQUENCES")) c->zero_run_sequences = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);

@@ -1479,6 +1479,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 }
             }
             wave_lds_sync();
+            PHASE(4);
             goto region_done;
         }
         if (STAGE == 0 && seqmode && mode != 2) {
@@ -1790,6 +1791,8 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     }
     if (STAGE == 1) {   // both regions planned
         if (lane == 0) redo[r] = 0;
+        if (TIMED && lane == 0)
+            for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
         return;
     }
     const uint32_t main_bytes = opos;
@@ -2476,7 +2479,7 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
     const uint32_t tr = trailers ? 1u : 0u;
     if (b.n_reads == 0) return hipSuccess;
     const SeqCTables* st = reinterpret_cast<const SeqCTables*>(seq_tables);
-    if (dbg) {
+    if (dbg && !plan_meta) {   // phase counters of the whole frame in one launch
         hipLaunchKernelGGL((zstd_encode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                            src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, nullptr, nullptr, nullptr);
         return hipGetLastError();
@@ -2485,16 +2488,20 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
     uint32_t* redo = plans ? reinterpret_cast<uint32_t*>(plans + b.n_reads) : nullptr;
     if (plans && src_cap && st) {
         // the ordinary read in two launches (plan, pack at twice the occupancy); whatever they leave in redo[] in the fused form
+        if (dbg)   // VBZ_HIP_PHASE_TIMING=2: the planning launch with its phase counters, under load (the other launches as they are)
+            hipLaunchKernelGGL((zstd_encode_kernel<true, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+                               src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
+        else
         hipLaunchKernelGGL((zstd_encode_kernel<false, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                            src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
         hipLaunchKernelGGL(zstd_pack_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo);
     } else {
         redo = nullptr;
     }
-    hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+    hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, nullptr,
                        src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, redo);
     if (deep_d)  // the reads in which the first launch found a repeat distance (it wrote deep_d[] for every read)
-        hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+        hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, nullptr,
                            src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, nullptr, nullptr);
     return hipGetLastError();
 }
