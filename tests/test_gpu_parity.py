@@ -1481,3 +1481,34 @@ pickle.dump(out, open(sys.argv[2], 'wb'))
     assert on["i32_paths"][2] >= len(frames32) - 2, on["i32_paths"]
     assert on["zoo_paths"][2] >= on["zoo_paths"][0] // 2, on["zoo_paths"]
     assert 0 < on["bad_paths"][2] < len(bad), on["bad_paths"]
+
+
+def test_walked_chains_in_calls_large_enough_to_walk_by_default():
+    """Calls of 2 560 reads and more walk the chains of reference-written frames without being told to: tables in LDS up to 9 216
+    reads, in memory beyond, the walk on the context's second stream beside the batched decoder's launches for this library's own
+    frames.  Short reads keep this a test: 3 000 reference frames; 5 000 + 5 000 frames of both writers interleaved (> 9 216)."""
+    import gpu_util as G
+
+    if O.lib().vbo_zstd_version() is None:
+        pytest.skip("no libzstd on this box")
+    rng = np.random.default_rng(99)
+    opts, oo = G.codec().options(True, 2, 1, 1), O.options(True, 2, 1, 1)
+    reads = [O.synth_signal(5, 5000 + i, int(rng.integers(1500, 4000))) for i in range(5000)]
+    ref = [O.compress(a, oo) for a in reads]
+    # (a) reference frames only, tables in LDS
+    back = G.decompress(ref[:3000], [a.nbytes for a in reads[:3000]], opts)
+    n, batched, walked = G.codec().decode_paths()
+    assert n == 3000 and batched == 0 and walked >= 2900, (n, batched, walked)
+    for a, b in zip(reads, back):
+        assert not isinstance(b, int) and b.tobytes() == a.tobytes()
+    # (b) both writers in one call of 10 000 frames, tables in memory
+    own = G.compress(reads, opts)
+    mix, caps = [], []
+    for a, f, g in zip(reads, own, ref):
+        mix += [f, g]
+        caps += [a.nbytes, a.nbytes]
+    back = G.decompress(mix, caps, opts)
+    n, batched, walked = G.codec().decode_paths()
+    assert n == 10000 and walked >= 4800, (n, batched, walked)
+    for i, b in enumerate(back):
+        assert not isinstance(b, int) and b.tobytes() == reads[i // 2].tobytes(), i
