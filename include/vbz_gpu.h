@@ -15,9 +15,9 @@
  * in batch->result in stream order.
  *
  * How a batch is laid onto the device is the library's business and never changes the DECODED data.  The compressed bytes
- * (and so result[i] of a compress call) may depend on it: reads on the large-read path are coded as spans and get no
- * long-repeat matcher, a batch too small to fill the device is coded as spans too, and the matcher is used only where
- * dst_cap[i] leaves room for its workspace above the worst-case frame.  The library may write anywhere inside a read's
+ * (and so result[i] of a compress call) may depend on it: reads on the large-read path are coded as spans (unless they
+ * repeat at one distance, below), a batch too small to fill the device is coded as spans too, and the matcher is used only
+ * where dst_cap[i] leaves room for its workspace above the worst-case frame.  The library may write anywhere inside a read's
  * destination slot [dst_off[i], dst_off[i] + dst_cap[i]) (workspace, staging), not only the result[i] bytes it reports.
  *   - the shape rule: a batch whose average read is half a megabyte or more (a 10 M-element buffer), or which is too
  *     small to fill the device with one wavefront per read (up to 96 MB of reads of 64 KB and more: one HDF5 chunk per
@@ -29,7 +29,12 @@
  *   - a read whose bytes repeat at one distance (a cycled template) gets that distance coded as zstd matches
  *     at every zstd_compression_level (the reference passes its level to libzstd, whose matcher is on at all
  *     of them), whatever its length: a long read that has such a distance is coded by one wavefront with the matcher
- *     instead of as spans (15-60 x smaller, at one wavefront's speed).
+ *     instead of as spans (15-60 x smaller, at one wavefront's speed);
+ *   - decompress: frames of this library's shape are decoded by a batched decoder, any other conforming zstd frame by the
+ *     general one in the same call; in calls of 2 560 reads and more the sequence chains of frames libzstd wrote (the
+ *     reference's files) are walked ahead of the general decoder, one lane per frame, on a second stream of the context
+ *     that is forked from and joined to the context's stream inside the call.  Bytes and verdicts never depend on it
+ *     (vbz_gpu_decode_paths tells which frames went which way).
  * Descriptor tables are untrusted like the data: before any other kernel runs, one thread per read checks
  * src_off + src_size <= src_bytes and dst_off + dst_cap <= dst_bytes (64-bit arithmetic); a read that fails gets
  * VBZ_INPUT_SIZE_ERROR or VBZ_DESTINATION_SIZE_ERROR and none of its addresses is ever formed
