@@ -730,9 +730,11 @@ __device__ __forceinline__ uint64_t dilate_left(uint64_t w, uint32_t r)  // bit 
 // word per 16 positions); a run of RPER or more such positions is one match, none of its bytes stays a literal.
 constexpr uint32_t RPER = 16;
 // COUNT_ONLY: nothing is written or moved; nrec is all that is wanted.
-template <bool PERIOD, bool COUNT_ONLY = false>
-__device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit, uint32_t& nrec, const uint16_t* mask16, int lane)
+template <bool PERIOD, bool COUNT_ONLY = false, bool TSUB = false>
+__device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit, uint32_t& nrec, const uint16_t* mask16, int lane,
+                              unsigned long long* tsub_ = nullptr, unsigned long long* tl = nullptr)
 {
+    unsigned long long* const tsub = TSUB ? tsub_ : nullptr;   // (sub-phase timers: the timed build of the planning launch only)
     uint32_t lit_total = 0, rec_total = 0;
     uint32_t carry60 = 0, carry61 = 0;  // masks of the 32 positions in front of the payload
     uint32_t carryw = 0;                // the dword that ends in front of the payload (its top byte precedes position pb)
@@ -770,6 +772,7 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
             const int64_t lb = (int64_t)pb + 16 * ((int64_t)lane - 2);
             zm = lb >= 0 ? (uint32_t)mask16[(uint32_t)lb >> 4] : 0u;
         }
+        SUB(3);   // (timed build: the trip's load and the equal-neighbour mask)
         uint32_t m1 = (uint32_t)__shfl_up((int)zm, 1, 64), m2 = (uint32_t)__shfl_up((int)zm, 2, 64);
         uint32_t p1 = (uint32_t)__shfl_down((int)zm, 1, 64), p2 = (uint32_t)__shfl_down((int)zm, 2, 64);
         if (lane < 1) m1 = 0;
@@ -793,6 +796,7 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
         // with RMIN <= 8 two qualifying runs can end inside one lane's 16 positions (never three)
         const uint32_t second = end16 & (end16 - 1);
         const uint64_t endmask1 = __ballot(end16 != 0), endmask2 = __ballot(second != 0);
+        SUB(5);   // (the window, the runs, the scan and the ballots)
         if (!COUNT_ONLY && end16) {
             const uint32_t idx = rec_total + (uint32_t)__popcll(endmask1 & below) + (uint32_t)__popcll(endmask2 & below);
             const uint32_t i = (uint32_t)__ffs((int)end16) - 1u;
@@ -808,6 +812,7 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
             for (int i = 0; i < 16; ++i)
                 if ((kept16 >> i) & 1u) k[off++] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
         }
+        SUB(2);   // (the records and the literals' stores)
         rec_total += (uint32_t)__popcll(endmask1) + (uint32_t)__popcll(endmask2);
         lit_total += tot;
         carry60 = (uint32_t)__shfl((int)zm, 60, 64);
@@ -1381,7 +1386,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                     nrec = plans[r].tok_nrec;
                     Lit = plans[r].tok_lit;
                 } else {
-                    tokenise_runs<false>(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, nullptr, lane);
+                    tokenise_runs<false, false, TIMED>(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, nullptr, lane, tph, &tlast);
                     __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
                     if (STAGE == 1 && lane == 0) {
                         plans[r].tok_nrec = nrec;
