@@ -79,7 +79,7 @@ struct vbz_gpu_ctx
     bool zero_run_sequences = true;
     bool fuse_svb = false;     // VBZ_HIP_FUSE_SVB=1: the frame's wavefront decodes the svb stream too (measured slower: DESIGN.md 4.4)
     int long_repeats = 1;  // VBZ_HIP_LONG_REPEATS=0: no search for a repeat distance (experiments: 2 = probe only, 3 = second launch only)
-    int phase_timing = 0;      // VBZ_HIP_PHASE_TIMING: 1 phase counters of the entropy kernels (one launch per frame), 2 of the encoder's planning launch (staged, under load)
+    int phase_timing = 0;      // VBZ_HIP_PHASE_TIMING: 1 phase counters of the entropy kernels (one launch per frame), 2 / 3 of the encoder's planning / packing launch (staged, under load)
     bool trace = false;        // VBZ_HIP_TRACE=1: synchronise after every launch group and name it on stderr (to find a faulting kernel)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -363,7 +363,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, nullptr, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
@@ -446,15 +446,21 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     {
         Timed t(c, "zstd_encode");
         void* plan = nullptr;
-        if (c->staged_encode && (!dbg || c->phase_timing == 2) && c->zero_run_sequences) {
+        if (c->staged_encode && (!dbg || c->phase_timing >= 2) && c->zero_run_sequences) {
             if (!ensure(c, c->encplan, zstd_encode_plan_bytes(n))) return -1;
             plan = c->encplan.p;
         }
-        HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, dbg, c->zero_run_sequences ? svb_cap : nullptr,
-                                     c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers, (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, plan, s),
+        // (phase timing 2: the planning launch's counters, 3: the packing launch's; both under load, the other launches as they are)
+        HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, c->phase_timing == 3 ? nullptr : dbg,
+                                     c->zero_run_sequences ? svb_cap : nullptr, c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers,
+                                     (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, plan, c->phase_timing == 3 ? dbg : nullptr, s),
                "zstd_encode launch");
     }
-    dbg_end(c, n, c->phase_timing == 2 ? "zstd_encode planning launch: setup hist plan - store+sequences - | plan: sort merge lengths codes weights tree" : "zstd_encode: setup hist plan size hdr encode", dbg);
+    dbg_end(c, n,
+            c->phase_timing == 3   ? "zstd_pack: setup region lookups+scan bits quads ends+headers sequences trailer"
+            : c->phase_timing == 2 ? "zstd_encode planning launch: setup hist plan - store+sequences - | plan: sort merge lengths codes weights tree"
+                                   : "zstd_encode: setup hist plan size hdr encode",
+            dbg);
     return 0;
 }
 
@@ -921,7 +927,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, nullptr, c->stream), "zstd_encode launch");
     return 0;
 }
 

@@ -74,7 +74,7 @@ hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigz
 // either way.
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              uint32_t* deep_d, void* plan_meta, hipStream_t s);
+                              uint32_t* deep_d, void* plan_meta, unsigned long long* pack_dbg, hipStream_t s);
 size_t zstd_encode_plan_bytes(uint32_t n_reads);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);

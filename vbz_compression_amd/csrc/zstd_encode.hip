@@ -1845,10 +1845,19 @@ struct PackLds
     uint32_t obuf[OBUF_WORDS];
 };
 
+// TIMED (VBZ_HIP_PHASE_TIMING=3, a separate instantiation): shader-clock counters per frame -- 0 set-up, 1 a region's table and
+// stream geometry, 2 the packing steps' table look-ups and prefix sum, 3 their bits into the LDS buffer, 4 the buffer's quads to
+// memory, 5 stream ends and block headers, 6 the sequences section moved into place, 7 trailer and result.
+__device__ unsigned long long* g_pack_dbg = nullptr;
+template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                                                                              uint32_t hdr, uint32_t trailers, const EncPlan* plans, uint32_t* redo)
 {
+    unsigned long long* const dbg = TIMED ? g_pack_dbg : nullptr;   // (not a parameter: the product instantiation stays as it was)
     __shared__ __attribute__((aligned(16))) PackLds L;
+    unsigned long long tph[PHASE_SLOTS] = {};
+    unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
+#define PPHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const int lane = threadIdx.x;
     const uint32_t r = blockIdx.x;
     if (redo[r]) return;
@@ -1881,6 +1890,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
         else { p[4] = 0xA0; put_le(p + 5, N, 4); }
     }
     opos = hdr + 5 + (N < 256 ? 1 : (N < 65536 + 256 ? 2 : 4));
+    PPHASE(0);
     for (int region = 0; region < 2; ++region) {
         if (region == 1 && K == 0) break;
         const uint32_t r0 = region == 0 ? 0u : K;
@@ -1980,6 +1990,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
         uint32_t spos = 0;           // where the current stream starts
         uint32_t curblk = 0xFFFFFFFFu;
         if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
+        PPHASE(1);
         uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
         uint32_t flushed = 0;     // bytes of the stream already written to memory
         while (st < 4 * nb) {
@@ -2019,6 +2030,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
             const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
             const uint32_t fq = allbits >> 7;             // complete 16-byte quads
             if ((uint64_t)spos + flushed + 16ull * fq + 24 > limit) REDO();
+            PPHASE(2);
             {
                 const uint32_t pos = base_bits + incl - Tb;
                 uint32_t word = pos >> 5;
@@ -2042,6 +2054,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
                 if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
             }
             wave_lds_sync();
+            PPHASE(3);
             {   // complete quads leave as 16-byte stores and are cleared on the way; the rest moves to the front
                 uint4* obq = reinterpret_cast<uint4*>(L.obuf);
                 for (uint32_t q = lane; q < fq; q += WAVE) {
@@ -2061,6 +2074,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
             flushed += 16u * fq;
             base_bits = allbits & 127u;
             wave_lds_sync();
+            PPHASE(4);
             if (nst != st) {
                 // stream finished: end mark and the bits still in quad 0 (lane k writes byte k)
                 const uint32_t nbytes = (base_bits + 1 + 7) >> 3;  // <= 16
@@ -2097,6 +2111,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
 #endif
             st = nst;
             done = ndone;
+            PPHASE(5);
         }
         if (seqmode && curblk != 0xFFFFFFFFu) {
             // the block with the run sequences: its sequences section, coded by the planning launch above the frame, moves behind
@@ -2118,6 +2133,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
         }
         opos = ocur;
         if (Sh != S && opos - opos_region > S + (S >> 6) + 256u) REDO();   // a sample that misled: coded again from the exact histogram
+        PPHASE(6);
     }
     if (FP->cpCount != 0 && (trailers & 1u)) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
         const uint32_t count = FP->cpCount, tb = 8u + 4u + 4u * count + 4u;
@@ -2135,6 +2151,10 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
         }
     }
     if (lane == 0) b.result[r] = opos;
+    PPHASE(7);
+    if (TIMED && lane == 0)
+        for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
+#undef PPHASE
 #undef REDO
 }
 
@@ -2479,7 +2499,7 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              uint32_t* deep_d, void* plan_meta, hipStream_t s)
+                              uint32_t* deep_d, void* plan_meta, unsigned long long* pack_dbg, hipStream_t s)
 {
     const uint32_t tr = trailers ? 1u : 0u;
     if (b.n_reads == 0) return hipSuccess;
@@ -2499,7 +2519,12 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
         else
         hipLaunchKernelGGL((zstd_encode_kernel<false, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                            src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
-        hipLaunchKernelGGL(zstd_pack_kernel, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo);
+        if (pack_dbg) {
+            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pack_dbg), &pack_dbg, sizeof(pack_dbg), 0, hipMemcpyHostToDevice, s);
+            hipLaunchKernelGGL(zstd_pack_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo);
+        } else {
+            hipLaunchKernelGGL(zstd_pack_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo);
+        }
     } else {
         redo = nullptr;
     }
