@@ -1842,7 +1842,9 @@ struct PackLds
     uint32_t ctable[256];   // code | length << 16
     uint32_t tree[34];
     uint32_t ssize[WAVE], sbeg[WAVE], scnt[WAVE];
-    uint32_t obuf[OBUF_WORDS];
+    // Two bit buffers, used in turn: a step's complete quads stay in its buffer and are stored at the top of the NEXT step, in front
+    // of the request for the step after that -- the wait for a step's input then never covers a store (one in-order counter)
+    uint32_t obuf[2][OBUF_WORDS];
 };
 
 // TIMED (VBZ_HIP_PHASE_TIMING=3, a separate instantiation): shader-clock counters per frame -- 0 set-up, 1 a region's table and
@@ -1926,7 +1928,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
             L.scnt[lane] = cnt;
             L.ssize[lane] = 0;
         }
-        for (int i = lane; i < OBUF_WORDS; i += WAVE) L.obuf[i] = 0;
+        for (int i = lane; i < 2 * OBUF_WORDS; i += WAVE) (&L.obuf[0][0])[i] = 0;
         wave_lds_sync();
         const uint32_t nb = nblk;
         uint32_t st = 0;
@@ -1992,7 +1994,19 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
         if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
         PPHASE(1);
         uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
-        uint32_t flushed = 0;     // bytes of the stream already written to memory
+        uint32_t flushed = 0;     // bytes of the stream already written to memory (or waiting in the other buffer for it)
+        uint32_t cb = 0;          // the buffer this step fills
+        uint32_t pend_fq = 0;     // quads of the step before that wait in the other buffer ...
+        uint8_t* pend_dst = nullptr;  // ... for this address
+        auto flush_pending = [&]() {
+            uint4* pq = reinterpret_cast<uint4*>(L.obuf[cb ^ 1u]);
+            for (uint32_t q = lane; q < pend_fq; q += WAVE) {
+                const uint4 v = pq[q];
+                pq[q] = make_uint4(0u, 0u, 0u, 0u);
+                __builtin_memcpy(pend_dst + 16u * q, &v, 16);
+            }
+            pend_fq = 0;
+        };
         while (st < 4 * nb) {
             if ((st >> 2) != curblk) {  // first stream of a block: reserve its headers, place the tree
                 curblk = st >> 2;
@@ -2010,6 +2024,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
                 ++nst;
                 while (nst < 4 * nb && L.scnt[nst] == 0) ++nst;
             }
+            flush_pending();   // (the step before: its quads, in front of the request below)
 #if VBZ_PACK_PREFETCH
             if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, nxt);
 #endif
@@ -2045,31 +2060,27 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
                     acc |= pair << accbits;
                     accbits += l1 + l0;
                     if (accbits >= 32) {
-                        atomicOr(&L.obuf[word], (uint32_t)acc);
+                        atomicOr(&L.obuf[cb][word], (uint32_t)acc);
                         acc >>= 32;
                         accbits -= 32;
                         ++word;
                     }
                 }
-                if (acc) atomicOr(&L.obuf[word], (uint32_t)acc);
+                if (acc) atomicOr(&L.obuf[cb][word], (uint32_t)acc);
             }
             wave_lds_sync();
             PPHASE(3);
-            {   // complete quads leave as 16-byte stores and are cleared on the way; the rest moves to the front
-                uint4* obq = reinterpret_cast<uint4*>(L.obuf);
-                for (uint32_t q = lane; q < fq; q += WAVE) {
-                    const uint4 v = obq[q];
-                    obq[q] = make_uint4(0u, 0u, 0u, 0u);
-                    __builtin_memcpy(sop + flushed + 16u * q, &v, 16);
-                }
-                if (fq) {
+            {   // complete quads wait in this buffer for the top of the next step; the rest moves to the front of the other buffer
+                uint4* obq = reinterpret_cast<uint4*>(L.obuf[cb]);
+                uint4* nbq = reinterpret_cast<uint4*>(L.obuf[cb ^ 1u]);   // (stored and cleared at the top of this step)
+                if (lane == 0) {
                     const uint4 c = obq[fq];
-                    wave_lds_sync();
-                    if (lane == 0) {
-                        obq[fq] = make_uint4(0u, 0u, 0u, 0u);
-                        obq[0] = c;
-                    }
+                    obq[fq] = make_uint4(0u, 0u, 0u, 0u);
+                    nbq[0] = c;
                 }
+                pend_fq = fq;
+                pend_dst = sop + flushed;
+                cb ^= 1u;
             }
             flushed += 16u * fq;
             base_bits = allbits & 127u;
@@ -2079,7 +2090,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
                 // stream finished: end mark and the bits still in quad 0 (lane k writes byte k)
                 const uint32_t nbytes = (base_bits + 1 + 7) >> 3;  // <= 16
                 {
-                    uint4* obq = reinterpret_cast<uint4*>(L.obuf);
+                    uint4* obq = reinterpret_cast<uint4*>(L.obuf[cb]);
                     const uint4 c = obq[0];
                     const uint32_t cw[4] = { c.x, c.y, c.z, c.w };
                     uint32_t mine = cw[(lane >> 2) & 3];
@@ -2113,6 +2124,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
             done = ndone;
             PPHASE(5);
         }
+        flush_pending();
         if (seqmode && curblk != 0xFFFFFFFFu) {
             // the block with the run sequences: its sequences section, coded by the planning launch above the frame, moves behind
             // the literals (upwards in memory never: the frame has stayed below it)
