@@ -1513,3 +1513,4 @@ def test_walked_chains_in_calls_large_enough_to_walk_by_default():
     assert forced or (n == 10000 and walked >= 4800), (n, batched, walked)
     for i, b in enumerate(back):
         assert not isinstance(b, int) and b.tobytes() == reads[i // 2].tobytes(), i
+

@@ -46,3 +46,29 @@ def test_config5_workload_at_one_gpu():
     assert d["config"]["distinct_reads"] == 20000 and d["steps"] == 5   # 20 000 reads in batches of 4 096
     assert d["config"]["workload"].startswith("configs[4]: a FIXED job of 20000 reads")
     assert 2.3 < d["ratio"] < 2.5
+
+
+def test_phase_timing_builds_write_the_same_frames():
+    """VBZ_HIP_PHASE_TIMING selects timed instantiations of the entropy kernels (2 / 3: the encoder's planning / packing launch
+    under load): measurement aids, but they must code and decode what the product kernels do."""
+    code = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import gpu_util as G, oracle_lib as O
+from vbz_compression_amd import _lib
+reads = [O.synth_signal(5, 7000 + i, n) for i, n in enumerate([100000, 65536, 33333, 4096, 250000, 17, 0] * 2)]
+opts = _lib.CompressionOptions(True, 2, 1, 1)
+frames = G.compress(reads, opts)
+back = G.decompress(frames, [a.nbytes for a in reads], opts)
+for a, f, b in zip(reads, frames, back):
+    assert not isinstance(f, int) and not isinstance(b, int) and b.tobytes() == a.tobytes()
+    assert O.decompress(f, a.nbytes, O.options(True, 2, 1, 1)).tobytes() == a.tobytes()
+print("frames", sum(len(f) for f in frames))
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    sizes = {}
+    for lv in ("0", "2", "3"):
+        env = dict(os.environ, VBZ_HIP_PHASE_TIMING=lv, VBZ_HIP_SEGMENTED="0")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        sizes[lv] = [ln for ln in r.stdout.splitlines() if ln.startswith("frames")][-1]
+    assert sizes["0"] == sizes["2"] == sizes["3"]
