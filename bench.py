@@ -524,9 +524,8 @@ def run_rank(args):
     for B in batches:
         back.zero_()  # the arena is shared by batches with different layouts: clear the previous batch's bytes in the gaps
         step(B)
-        if not os.environ.get("VBZ_BENCH_KERNEL_EXPERIMENT"):  # set only to time deliberately broken kernel variants
-            assert bool((res[: B["n"]] == B["size"]).all()), "decode failed for some read"
-            assert torch.equal(B["raw"], back[: B["total"]]), "round trip mismatch"
+        assert bool((res[: B["n"]] == B["size"]).all()), "decode failed for some read"
+        assert torch.equal(B["raw"], back[: B["total"]]), "round trip mismatch"
         B["comp_bytes"] = int(B["csize"].to(torch.int64).sum())
         comp_bytes_all += B["comp_bytes"]
     for i in range(args.warmup):

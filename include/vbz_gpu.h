@@ -60,7 +60,12 @@ typedef struct vbz_gpu_batch
     uint32_t reserved;
     /* inputs: read i occupies src[src_off[i] .. src_off[i]+src_size[i]).  Offsets must not overlap,
      * should be 16-byte aligned (a slower path handles other alignments), and the arena must be
-     * readable for 16 bytes past the last input (the same slack streamvbyte asks for). */
+     * readable for 16 bytes past the last input (the same slack streamvbyte asks for).
+     * Decompression additionally reads whole ALIGNED 128-byte lines: device memory must be readable
+     * from the 128-byte line that holds the first input byte to the end of the line that holds the
+     * last one (+ 16).  Any arena that is an allocation of its own (hipMalloc: 256-byte aligned,
+     * page granular) satisfies this; an arena carved out of a larger buffer does as long as the
+     * enclosing buffer covers those lines. */
     const void* src;
     const uint64_t* src_off;
     const uint32_t* src_size;

@@ -202,19 +202,22 @@ def test_wave_svb_decoder_behind_the_entropy_stage():
     frames = [O.zstd_compress(st, 1) for st, _ in cases]
     want = [O.decompress(f, nb, oo) for f, (_, nb) in zip(frames, cases)]
     assert sum(1 for w in want if isinstance(w, int)) >= 40 and sum(1 for w in want if not isinstance(w, int)) >= 20
-    keep = G._codec
+    keep = G._codec, _lib._lib, _lib.LIB_PATH
     try:
-        for fuse in ("0", "1"):   # the separate svb_decode launch, and the frame's own wavefront (a context of its own each)
+        for fuse in ("0", "1"):   # the separate svb_decode launch (the product), and the frame's own wavefront (experiments build)
+            if fuse == "1":
+                _lib._lib, _lib.LIB_PATH = None, _lib.EXPERIMENTS_LIB_PATH
             os.environ["VBZ_HIP_FUSE_SVB"] = fuse
             try:
                 G._codec = batch.GpuCodec(0)
+                assert (b"+experiments" in G._codec.L.vbz_gpu_version()) == (fuse == "1")
             finally:
                 del os.environ["VBZ_HIP_FUSE_SVB"]
             got = G.decompress(frames, [nb for _, nb in cases], _lib.CompressionOptions(True, 2, 1, 1))
             for i, (w, g) in enumerate(zip(want, got)):
                 assert _same(g, w), (fuse, i, len(cases[i][0]), cases[i][1], g if isinstance(g, int) else "samples", w if isinstance(w, int) else "samples")
     finally:
-        G._codec = keep
+        G._codec, _lib._lib, _lib.LIB_PATH = keep
 
 
 # ------------------------------------------------------------------------------------------------

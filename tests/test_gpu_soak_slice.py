@@ -50,7 +50,8 @@ def test_config5_workload_at_one_gpu():
 
 def test_phase_timing_builds_write_the_same_frames():
     """VBZ_HIP_PHASE_TIMING selects timed instantiations of the entropy kernels (2 / 3: the encoder's planning / packing launch
-    under load): measurement aids, but they must code and decode what the product kernels do."""
+    under load) in the experiments build of the library (lib/libvbz_hip_x.so, -DVBZ_EXPERIMENTS; the shipped library has neither
+    the instantiations nor the knob): measurement aids, but they must code and decode what the product kernels do."""
     code = r"""
 import sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -63,12 +64,18 @@ back = G.decompress(frames, [a.nbytes for a in reads], opts)
 for a, f, b in zip(reads, frames, back):
     assert not isinstance(f, int) and not isinstance(b, int) and b.tobytes() == a.tobytes()
     assert O.decompress(f, a.nbytes, O.options(True, 2, 1, 1)).tobytes() == a.tobytes()
-print("frames", sum(len(f) for f in frames))
+import hashlib
+print("frames", sum(len(f) for f in frames), hashlib.sha256(b"".join(f.tobytes() for f in frames)).hexdigest(), G.codec().L.vbz_gpu_version().decode())
 """ % (ROOT, os.path.join(ROOT, "tests"))
+    from vbz_compression_amd import _lib
     sizes = {}
     for lv in ("0", "2", "3"):
         env = dict(os.environ, VBZ_HIP_PHASE_TIMING=lv, VBZ_HIP_SEGMENTED="0")
+        if lv != "0":
+            env["VBZ_HIP_LIB"] = _lib.EXPERIMENTS_LIB_PATH
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        sizes[lv] = [ln for ln in r.stdout.splitlines() if ln.startswith("frames")][-1]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("frames")][-1].split()
+        assert ("+experiments" in line) == (lv != "0"), line
+        sizes[lv] = line[1:3]   # total bytes and their sha256: byte for byte the product's frames
     assert sizes["0"] == sizes["2"] == sizes["3"]

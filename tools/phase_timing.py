@@ -3,6 +3,9 @@
 
     VBZ_HIP_PHASE_TIMING=1 VBZ_HIP_SEGMENTED=0 python tools/phase_timing.py [--reference] [samples ...]
 
+The timed kernel instantiations live in the experiments build of the library (lib/libvbz_hip_x.so, -DVBZ_EXPERIMENTS), which
+this tool selects itself (VBZ_HIP_LIB).
+
 --reference: the frame is written by the oracle (the reference path + libzstd) instead of the device encoder.
 
 The library prints the phase lines on stderr (see dbg_end in vbz_api.hip).  The kernels are latency-bound per wavefront
@@ -12,6 +15,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("VBZ_HIP_LIB", os.path.join(ROOT, "vbz_compression_amd", "lib", "libvbz_hip_x.so"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

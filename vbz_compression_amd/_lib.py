@@ -7,7 +7,10 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libvbz_hip.so")
+# VBZ_HIP_LIB: another build of the same library (tools/ab_libs.py; the experiments build lib/libvbz_hip_x.so that carries the
+# timed kernel instantiations and the known-slower variants for tools/ and the tests that keep them honest)
+LIB_PATH = os.environ.get("VBZ_HIP_LIB") or os.path.join(HERE, "lib", "libvbz_hip.so")
+EXPERIMENTS_LIB_PATH = os.path.join(HERE, "lib", "libvbz_hip_x.so")
 PLUGIN_PATH = os.path.join(HERE, "lib", "libvbz_hdf_plugin.so")
 
 VBZ_ZSTD_ERROR = 0xFFFFFFFF

@@ -28,9 +28,8 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    os.makedirs(LIBDIR, exist_ok=True)
-    objdir = os.path.join(LIBDIR, "obj")
+def _build_lib(name, objsub, extra, force, verbose):
+    objdir = os.path.join(LIBDIR, objsub)
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
@@ -40,19 +39,36 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
-    for name, p in procs:
+    for name_, p in procs:
         if p.wait() != 0:
-            raise RuntimeError("hipcc failed on %s" % name)
-    lib = os.path.join(LIBDIR, "libvbz_hip.so")
+            raise RuntimeError("hipcc failed on %s" % name_)
+    lib = os.path.join(LIBDIR, name)
     if force or _stale(lib, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    return lib
+
+
+def build_experiments(force=False, verbose=True):
+    """lib/libvbz_hip_x.so: the same sources with -DVBZ_EXPERIMENTS -- the timed kernel instantiations (VBZ_HIP_PHASE_TIMING) and the
+    measured-slower variants (VBZ_HIP_FUSE_SVB, VBZ_HIP_LONG_REPEATS=2|3, VBZ_HIP_ROUTING=2) for tools/ and for the tests that hold
+    them to the product's bytes.  Not linked by the plugin or the re-packer; select it with VBZ_HIP_LIB."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    return _build_lib("libvbz_hip_x.so", "obj_x", ["-DVBZ_EXPERIMENTS"], force, verbose)
+
+
+def build(force=False, verbose=True, experiments=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    lib = _build_lib("libvbz_hip.so", "obj", [], force, verbose)
+    if experiments:
+        build_experiments(force, verbose)
     plugin_src = os.path.join(CSRC, "vbz_plugin.cpp")
     plugin = os.path.join(LIBDIR, "libvbz_hdf_plugin.so")
     if os.path.exists(plugin_src) and (force or _stale(plugin, [plugin_src, lib] + hdrs)):
@@ -78,5 +94,5 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    build(force="--force" in sys.argv, experiments="--no-experiments" not in sys.argv)
     print("ok")

@@ -103,8 +103,11 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
 // The same, and the frame's content -- the svb stream of int16 zig-zag samples, b.dst = its slot in the library's scratch --
 // is decoded by the same wavefront straight away (svb_wave.h) into out + out_off[i] (out_size[i] bytes exactly): result[i]
 // gets what launch_svb_decode(2, zigzag) would have reported after launch_zstd_decode, and no svb_decode launch follows.
+// (experiments build only: measured slower than the two launches)
+#ifdef VBZ_EXPERIMENTS
 hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, uint8_t* out, const uint64_t* out_off,
                                         const uint32_t* out_size, hipStream_t s);
+#endif
 // Frames the reference wrote (libzstd: blocks of general sequences): the sequence chains of the reads with redo[i] != 0 walked one
 // lane per frame ahead of the one-wavefront decoder (zstd_decode_ref.hip), which takes a frame's records when RefPre.ok says so.
 constexpr uint32_t REF_MAXBLK = 4;

@@ -2614,12 +2614,16 @@ hipError_t launch_zstd_decode(const ReadBatch& b, uint32_t toosmall_code, unsign
 {
     if (b.n_reads == 0) return hipSuccess;
     const SvbFuse none = { nullptr, nullptr, nullptr };
-    if (dbg)
+#ifdef VBZ_EXPERIMENTS   // the timed instantiation (phase cycle counters) is part of the experiments build only
+    if (dbg) {
         hipLaunchKernelGGL((zstd_decode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
                            reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none, RefChains());
-    else
-        hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none, RefChains());
+        return hipGetLastError();
+    }
+#endif
+    (void)dbg;
+    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
+                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, none, RefChains());
     return hipGetLastError();
 }
 
@@ -2628,15 +2632,20 @@ hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, c
 {
     if (b.n_reads == 0) return hipSuccess;
     const SvbFuse none = { nullptr, nullptr, nullptr };
-    if (dbg)
+#ifdef VBZ_EXPERIMENTS
+    if (dbg) {
         hipLaunchKernelGGL((zstd_decode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, dbg,
                            reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none, chains);
-    else
-        hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
-                           reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none, chains);
+        return hipGetLastError();
+    }
+#endif
+    (void)dbg;
+    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr,
+                       reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, only, none, chains);
     return hipGetLastError();
 }
 
+#ifdef VBZ_EXPERIMENTS   // the svb decoder on the frame's wavefront: measured slower (profiles/r03_fused_svb_decode.md), kept for tools/ only
 hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, uint8_t* out, const uint64_t* out_off,
                                         const uint32_t* out_size, hipStream_t s)
 {
@@ -2646,6 +2655,7 @@ hipError_t launch_zstd_decode_svb_i16zz(const ReadBatch& b, uint32_t toosmall_co
                        reinterpret_cast<const SeqDTables*>(seq_dtables), nullptr, nullptr, nullptr, nullptr, fuse, RefChains());
     return hipGetLastError();
 }
+#endif
 
 // ---- span mode (few, large reads) ------------------------------------------------------------------------------------------
 size_t zstd_dspan_desc_bytes() { return sizeof(DecSpan); }

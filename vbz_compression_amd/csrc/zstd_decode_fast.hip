@@ -512,8 +512,9 @@ constexpr uint32_t TBL_BIG = 2048, TBL_SMALL = 512;  // entries: one table of up
 // The decoder of zstd_decode.hip's flush_tasks_ring (no bit buffer: the next 32 unread bits are one v_alignbit of two ring dwords held
 // in registers, two symbols per 32 fresh bits, the ring upside down with a mirror slot) around a different memory side:
 //  * a lane requests whole aligned 128-byte LINES, from the one that holds the stream's last byte down to the one that holds its
-//    first: never an address outside the lines the stream itself touches (so no assumption about the arena around it), and a line is
-//    fetched once.  Bit positions count from the top of the first line; the bytes between the stream's end and that top are consumed
+//    first: never an address outside the lines the stream itself touches -- which may begin up to 127 bytes below the arena's first
+//    input byte and end up to 127 bytes behind its last one: vbz_gpu.h asks callers for memory that is readable to those line
+//    boundaries (any arena that is its own allocation is) --, and a line is fetched once.  Bit positions count from the top of the first line; the bytes between the stream's end and that top are consumed
 //    before the first symbol;
 //  * request and commit of a batch are one stretch of straight-line code (request, decode a period, commit): the wait in front of
 //    the commit is a counted vmcnt, not the vmcnt(0) a loop-carried batch costs;

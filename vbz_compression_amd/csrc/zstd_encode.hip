@@ -1850,12 +1850,20 @@ struct PackLds
 // TIMED (VBZ_HIP_PHASE_TIMING=3, a separate instantiation): shader-clock counters per frame -- 0 set-up, 1 a region's table and
 // stream geometry, 2 the packing steps' table look-ups and prefix sum, 3 their bits into the LDS buffer, 4 the buffer's quads to
 // memory, 5 stream ends and block headers, 6 the sequences section moved into place, 7 trailer and result.
-__device__ unsigned long long* g_pack_dbg = nullptr;
+// (the counters' buffer travels in PackArgs: an argument of the launch, nothing shared between contexts)
+struct PackArgs
+{
+    const EncPlan* plans;
+    uint32_t* redo;
+    unsigned long long* dbg;   // TIMED only
+};
 template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                                                                             uint32_t hdr, uint32_t trailers, const EncPlan* plans, uint32_t* redo)
+                                                                             uint32_t hdr, uint32_t trailers, PackArgs pa)
 {
-    unsigned long long* const dbg = TIMED ? g_pack_dbg : nullptr;   // (not a parameter: the product instantiation stays as it was)
+    const EncPlan* const plans = pa.plans;
+    uint32_t* const redo = pa.redo;
+    unsigned long long* const dbg = TIMED ? pa.dbg : nullptr;
     __shared__ __attribute__((aligned(16))) PackLds L;
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
@@ -2516,27 +2524,35 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
     const uint32_t tr = trailers ? 1u : 0u;
     if (b.n_reads == 0) return hipSuccess;
     const SeqCTables* st = reinterpret_cast<const SeqCTables*>(seq_tables);
+#ifdef VBZ_EXPERIMENTS   // the timed instantiations (phase cycle counters) are part of the experiments build only
     if (dbg && !plan_meta) {   // phase counters of the whole frame in one launch
         hipLaunchKernelGGL((zstd_encode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                            src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, nullptr, nullptr, nullptr);
         return hipGetLastError();
     }
+#else
+    dbg = nullptr;
+    pack_dbg = nullptr;
+#endif
     EncPlan* plans = reinterpret_cast<EncPlan*>(plan_meta);
     uint32_t* redo = plans ? reinterpret_cast<uint32_t*>(plans + b.n_reads) : nullptr;
     if (plans && src_cap && st) {
         // the ordinary read in two launches (plan, pack at twice the occupancy); whatever they leave in redo[] in the fused form
+        const PackArgs pa = { plans, redo, pack_dbg };
+#ifdef VBZ_EXPERIMENTS
         if (dbg)   // VBZ_HIP_PHASE_TIMING=2: the planning launch with its phase counters, under load (the other launches as they are)
             hipLaunchKernelGGL((zstd_encode_kernel<true, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
                                src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
         else
-        hipLaunchKernelGGL((zstd_encode_kernel<false, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
+#endif
+        hipLaunchKernelGGL((zstd_encode_kernel<false, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, nullptr,
                            src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
-        if (pack_dbg) {
-            (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_pack_dbg), &pack_dbg, sizeof(pack_dbg), 0, hipMemcpyHostToDevice, s);
-            hipLaunchKernelGGL(zstd_pack_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo);
-        } else {
-            hipLaunchKernelGGL(zstd_pack_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo);
-        }
+#ifdef VBZ_EXPERIMENTS
+        if (pack_dbg)   // VBZ_HIP_PHASE_TIMING=3: the packing launch with its phase counters
+            hipLaunchKernelGGL(zstd_pack_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, pa);
+        else
+#endif
+        hipLaunchKernelGGL(zstd_pack_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, pa);
     } else {
         redo = nullptr;
     }
