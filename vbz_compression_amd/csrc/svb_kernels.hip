@@ -90,19 +90,55 @@ struct PeriodProbe
 };
 __device__ __forceinline__ uint32_t probe_hash(uint32_t w) { return (w * 0x9E3779B1u) >> 23; }
 
+// ---- the data bytes' histogram on the way (CNT; int16 zig-zag reads into library scratch) -------------------------------------------
+// The entropy stage builds the data-byte region's Huffman table from a histogram of one kilobyte in four (region_histogram of
+// zstd_encode.hip) -- a pass of its own over bytes this kernel has just had in LDS.  Here exactly that sample (the unaligned ends and
+// every fourth stripe of 64 aligned 16-byte chunks; everything, in two parts, for reads so short that the region may have to be counted
+// exactly) is counted by LDS atomics while the bytes are flushed, and left in the read's plan (EncPlan::hist_mode): the same counts, so
+// the frames are byte for byte what they were, and the entropy stage's planning never reads the data bytes.
+// Round 5 also moved the control bytes' TOKENISER in here, twice -- every wavefront deciding its own 128 control bytes per tile with
+// wave-uniform scalar arithmetic (a CU has ONE scalar unit: 2.3 x the kernel's time), then tokenise_runs' own arithmetic as "trips" of
+// one wavefront over an LDS ring of control bytes (bit-exact, and + 45 % on this kernel for - 11 % on the planning launch: a trip's
+// latency, ~5 000 cycles, sits on the workgroup's barrier-synchronised critical path) -- and took it out again: profiles/r05_experiments.md.
+constexpr uint32_t CNT_MIN_VALUES = 1640;            // n + ceil(n / 4) >= 2048: the entropy stage then cuts the stream into its two regions
+constexpr uint32_t CNT_HIST_SAMPLE_FROM = 32u << 10; // region_histogram samples regions of this size and more (HIST_SAMPLE_FROM)
+
+struct CntLds
+{
+    uint32_t hA[4][256];      // data bytes of the sample, one copy per wavefront (atomics on a shared bin serialise)
+    uint32_t hB[256];         // the other data bytes (hist_mode 2)
+};
+
+__device__ __forceinline__ void cnt_count16(uint32_t* h, const uint4& v)
+{
+    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&h[(w[k] >> (8 * j)) & 0xFFu], 1u);
+    }
+}
+
 // Values [first, end) of a read of n values (first a multiple of the tile size): control bytes to keys[first/4 ...),
 // data bytes to data[0 ...) -- `data` is where this range's data bytes start, any alignment; only bytes of the range
 // are touched.  COUNT_ONLY: nothing is written, the data byte count is all that is wanted.  Returns the data bytes
 // (workgroup-uniform).  All 256 threads.
 // PROBE (one-workgroup-per-read kernel only, data starts at first == 0): see PeriodProbe; *hint_out gets the distance.
-template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY, bool PROBE = false>
+// CNT (one-workgroup-per-read kernel, first == 0): hmode != 0 = the data bytes' sample is counted on the way into *CL (see CntLds;
+// hmode: EncPlan::hist_mode).
+template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY, bool PROBE = false, bool CNT = false>
 __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t first, uint32_t end, uint8_t* keys, uint8_t* data,
-                                                     uint8_t* stage, uint32_t* wsum, PeriodProbe* pp = nullptr, uint32_t* hint_out = nullptr)
+                                                     uint8_t* stage, uint32_t* wsum, PeriodProbe* pp = nullptr, uint32_t* hint_out = nullptr,
+                                                     CntLds* CL = nullptr, uint32_t hmode = 0)
 {
     constexpr int VPL = Vpl<ELEM>::value;
     constexpr int TILE = WG * VPL;
+    static_assert(!CNT || !COUNT_ONLY, "counting rides on the flush");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const bool cnt_on = CNT && hmode != 0;      // the data bytes' sample is counted on the way
+    (void)wv;
     const uint32_t A = (uint32_t)((uintptr_t)data & 15u);
     uint8_t* gal = data - A;  // 16-byte aligned address space of the data section
     const bool in_aligned = (((uintptr_t)in) & 15u) == 0;
@@ -292,9 +328,18 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
             uint8_t* g = gal + F + 16ull * c;
             if (F == 0 && c == 0 && A != 0) {
                 for (uint32_t j = A; j < 16; ++j) g[j] = stage[j];
+                if (CNT && cnt_on)   // the unaligned head of the data bytes is part of the sample
+                    for (uint32_t j = A; j < 16; ++j) atomicAdd(&CL->hA[wv][stage[j]], 1u);
             } else {
                 const uint4 v = *reinterpret_cast<const uint4*>(stage + 16u * c);
                 *reinterpret_cast<uint4*>(g) = v;
+                if (CNT && cnt_on) {
+                    // region_histogram's sample: 16-byte chunks are numbered from the first aligned one, 64 of them are a stripe, every
+                    // fourth stripe is counted (hist_mode 2: the others too, apart)
+                    const uint32_t cq = (uint32_t)(F >> 4) + c - (A ? 1u : 0u);
+                    if (((cq >> 6) & 3u) == 0u) cnt_count16(CL->hA[wv], v);
+                    else if (hmode == 2u) cnt_count16(CL->hB, v);
+                }
                 if (PROBE && probe_p0) {
                     const uint32_t h = probe_hash(v.x);
                     if (pp->val[h] == v.x) {   // rare: compare the chunk with the 16 bytes behind that probe
@@ -323,7 +368,10 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
     {   // tail: bytes [F, P) still in LDS
         const uint32_t rem = (uint32_t)(P - F);
         const uint32_t lo = (F == 0) ? A : 0u;
-        if ((uint32_t)tid >= lo && (uint32_t)tid < rem) gal[F + tid] = stage[tid];
+        if ((uint32_t)tid >= lo && (uint32_t)tid < rem) {
+            gal[F + tid] = stage[tid];
+            if (CNT && cnt_on) atomicAdd(&CL->hA[0][stage[tid]], 1u);   // (the unaligned end: part of the sample too)
+        }
     }
     return P - A;
 }
@@ -334,16 +382,21 @@ struct EncStage
     static constexpr int value = WG * Vpl<ELEM>::value * (I16ZZ ? 2 : 4) + 32;
 };
 
-template <int ELEM, bool ZZ, bool I16ZZ, bool PROBE>
-__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, uint32_t* period_hint)
+template <bool CNT> struct CntLdsOf { typedef CntLds type; };
+template <> struct CntLdsOf<false> { struct type { uint32_t none; }; };
+
+template <int ELEM, bool ZZ, bool I16ZZ, bool PROBE, bool CNT = false>
+__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, uint32_t* period_hint, EncPlan* pre)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[EncStage<ELEM, I16ZZ>::value];
     __shared__ uint32_t wsum[4];
     __shared__ PeriodProbe probe;   // (only the PROBE instantiations refer to it)
+    __shared__ __attribute__((aligned(16))) typename CntLdsOf<CNT>::type cntl[1];   // (only the CNT instantiations have one)
 
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
     if (PROBE && tid == 0) period_hint[r] = 0;
+    if (CNT && tid == 0) pre[r].hist_mode = 0;   // whatever becomes of the read, the entropy stage finds a verdict of this launch in its plan
     if (b.gate && b.gate[r] >= GATE_SKIP) {
         if (tid == 0 && b.gate[r] != GATE_SKIP) b.result[r] = b.gate[r];
         return;
@@ -362,9 +415,27 @@ __global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hd
         if (tid < 4) out[tid] = (uint8_t)(size >> (8 * tid));
         out += 4;
     }
-    const uint64_t bytes = svb_encode_range<ELEM, ZZ, I16ZZ, false, PROBE>(in, 0, n, out, out + keyLen, stage, wsum, PROBE ? &probe : nullptr,
-                                                                           PROBE ? period_hint + r : nullptr);
+    CntLds* const CL = reinterpret_cast<CntLds*>(&cntl[0]);
+    uint32_t hmode = 0;
+    if (CNT && hdr == 0 && n >= CNT_MIN_VALUES) {
+        // (a read of fewer values may give a stream the entropy stage does not cut into regions; a read of 32 K values and more has a
+        // data-byte region that is always sampled first: the other bytes are then not counted here -- if the sample turns out not to
+        // show enough byte values, the entropy stage counts the region itself)
+        hmode = n >= CNT_HIST_SAMPLE_FROM ? 1u : 2u;
+        uint32_t* z = &CL->hA[0][0];   // hA and hB are contiguous
+        for (uint32_t i = tid; i < 5u * 256u; i += WG) z[i] = 0;
+        // (the scan of the first tile holds the barrier that orders these writes)
+    }
+    const uint64_t bytes = svb_encode_range<ELEM, ZZ, I16ZZ, false, PROBE, CNT>(in, 0, n, out, out + keyLen, stage, wsum, PROBE ? &probe : nullptr,
+                                                                                PROBE ? period_hint + r : nullptr, CL, hmode);
     if (tid == 0) b.result[r] = hdr + keyLen + (uint32_t)bytes;
+    if (CNT && hmode) {
+        wg_lds_barrier();   // the tail's atomics
+        EncPlan* P = pre + r;
+        P->reg[1].ctable[tid] = CL->hA[0][tid] + CL->hA[1][tid] + CL->hA[2][tid] + CL->hA[3][tid];
+        if (hmode == 2u) P->histB[tid] = CL->hB[tid];
+        if (tid == 0) P->hist_mode = hmode;
+    }
 }
 
 // ---- one read on many workgroups ("segments"): for batches of few, large reads --------------------------------------
@@ -923,8 +994,10 @@ hipError_t launch1(K kernel, const ReadBatch& b, hipStream_t s)
 
 }  // namespace
 
+bool svb_encode_fills_plans(int integer_size, bool zigzag, bool half) { return integer_size == 2 && zigzag && !half; }
+
 hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, uint32_t* period_hint,
-                             hipStream_t s)
+                             void* plans, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     dim3 g(b.n_reads), t(WG);
@@ -936,9 +1009,17 @@ hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, 
         return hipGetLastError();
     }
     const uint32_t sc = strict_cap ? 1u : 0u;
-#define X(E, Z, I)                                                                                                    \
-    if (period_hint) hipLaunchKernelGGL((svb_encode_kernel<E, Z, I, true>), g, t, 0, s, b, hdr, sc, period_hint);     \
-    else hipLaunchKernelGGL((svb_encode_kernel<E, Z, I, false>), g, t, 0, s, b, hdr, sc, period_hint)
+    EncPlan* pre = zstd_encode_plans(plans);
+    if (pre && svb_encode_fills_plans(integer_size, zigzag, half) && hdr == 0 && !strict_cap) {
+        // the int16 zig-zag stream of a read on its way to the entropy stage: its data bytes' sample counted on the way
+        if (period_hint) hipLaunchKernelGGL((svb_encode_kernel<2, true, true, true, true>), g, t, 0, s, b, hdr, sc, period_hint, pre);
+        else hipLaunchKernelGGL((svb_encode_kernel<2, true, true, false, true>), g, t, 0, s, b, hdr, sc, period_hint, pre);
+        return hipGetLastError();
+    }
+    pre = nullptr;
+#define X(E, Z, I)                                                                                                         \
+    if (period_hint) hipLaunchKernelGGL((svb_encode_kernel<E, Z, I, true>), g, t, 0, s, b, hdr, sc, period_hint, pre);     \
+    else hipLaunchKernelGGL((svb_encode_kernel<E, Z, I, false>), g, t, 0, s, b, hdr, sc, period_hint, pre)
     if (integer_size == 2 && zigzag) { X(2, true, true); }
     else if (integer_size == 2) { X(2, false, false); }
     else if (integer_size == 4 && zigzag) { X(4, true, false); }

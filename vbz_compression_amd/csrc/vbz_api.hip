@@ -21,6 +21,7 @@
 
 using namespace vbzhip;
 
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -358,12 +359,12 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
             HIPCHK(c, launch_svb_encode_seg(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, seg.first, seg.max_segs, seg.val, seg.off, s),
                    "svb_encode (segmented) launch");
         else
-            HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, half_codec(o), nullptr, s), "svb_encode launch");
+            HIPCHK(c, launch_svb_encode(rb, (int)o->integer_size, o->perform_delta_zig_zag, hdr, true, half_codec(o), nullptr, nullptr, s), "svb_encode launch");
         return 0;
     }
     if (o->integer_size == 0) {  // zstd only
         Timed t(c, "zstd_encode");
-        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, nullptr, s), "zstd_encode launch");
+        HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, false, false, nullptr, s), "zstd_encode launch");
         return 0;
     }
     // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
@@ -392,13 +393,25 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     a.dst_cap = svb_cap;
     a.result = svb_size;
     a.gate = gate;
+    // the per-read plans of the entropy stage (one-wavefront path, staged encoder), in which the svb encoder leaves the data bytes'
+    // histogram of int16 zig-zag reads (svb_kernels.hip CNT)
+    unsigned long long* dbg = segmented ? nullptr : dbg_begin(c, n);
+    const bool staged = !segmented && c->staged_encode && (!dbg || c->phase_timing == 3) && c->zero_run_sequences;
+    const bool pre_filled = staged && svb_encode_fills_plans((int)o->integer_size, o->perform_delta_zig_zag, half_codec(o));
+    void* plan = nullptr;
+    if (staged) {
+        if (!ensure(c, c->encplan, zstd_encode_plan_bytes(n))) return -1;
+        plan = c->encplan.p;
+    }
     {
         Timed t(c, "svb_encode");
         if (segmented)
             HIPCHK(c, launch_svb_encode_seg(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, seg.first, seg.max_segs, seg.val, seg.off, s),
                    "svb_encode (segmented) launch");
         else
-            HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, half_codec(o), (matcher && c->long_repeats != 3) ? deep_d : nullptr, s), "svb_encode launch");
+            HIPCHK(c, launch_svb_encode(a, (int)o->integer_size, o->perform_delta_zig_zag, 0, false, half_codec(o), (matcher && c->long_repeats != 3) ? deep_d : nullptr,
+                                        pre_filled ? plan : nullptr, s),
+                   "svb_encode launch");
         if (matcher && c->long_repeats == 3) (void)hipMemsetAsync(deep_d, 0, 4ull * n, s);
     }
     ReadBatch z = rb;
@@ -442,18 +455,12 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
                "zstd_encode (spans) launch");
         return 0;
     }
-    unsigned long long* dbg = dbg_begin(c, n);
     {
         Timed t(c, "zstd_encode");
-        void* plan = nullptr;
-        if (c->staged_encode && (!dbg || c->phase_timing >= 2) && c->zero_run_sequences) {
-            if (!ensure(c, c->encplan, zstd_encode_plan_bytes(n))) return -1;
-            plan = c->encplan.p;
-        }
         // (phase timing 2: the planning launch's counters, 3: the packing launch's; both under load, the other launches as they are)
         HIPCHK(c, launch_zstd_encode(z, bt->src_size, o->integer_size, nullptr, hdr, c->phase_timing == 3 ? nullptr : dbg,
                                      c->zero_run_sequences ? svb_cap : nullptr, c->zero_run_sequences ? c->seqtab.p : nullptr, c->trailers,
-                                     (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, plan, c->phase_timing == 3 ? dbg : nullptr, s),
+                                     (matcher && !dbg && c->long_repeats != 2) ? deep_d : nullptr, plan, staged, pre_filled, c->phase_timing == 3 ? dbg : nullptr, s),
                "zstd_encode launch");
     }
     dbg_end(c, n,
@@ -930,7 +937,7 @@ int vbz_gpu_svb_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, int inte
     DeviceGuard dg(c->device);
     if ((integer_size != 1 && integer_size != 2 && integer_size != 4) || version > 1 || version < 0) return -2;
     Timed t(c, "svb_encode");
-    HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, version == 1 && integer_size == 1, nullptr, c->stream), "svb_encode launch");
+    HIPCHK(c, launch_svb_encode(to_rb(bt), integer_size, zigzag != 0, 0, true, version == 1 && integer_size == 1, nullptr, nullptr, c->stream), "svb_encode launch");
     return 0;
 }
 
@@ -949,7 +956,7 @@ int vbz_gpu_zstd_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const u
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
     Timed t(c, "zstd_encode");
-    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, nullptr, c->stream), "zstd_encode launch");
+    HIPCHK(c, launch_zstd_encode(to_rb(bt), bt->src_size, 0, key_bytes, 0, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, false, false, nullptr, c->stream), "zstd_encode launch");
     return 0;
 }
 
@@ -984,6 +991,49 @@ int vbz_gpu_synth_u32(vbz_gpu_ctx* c, uint64_t seed, uint64_t first, uint32_t n,
     HIPCHK(c, launch_synth_u32(seed, first, n, (uint8_t*)dst, off, len, c->stream), "synth_u32 launch");
     return 0;
 }
+
+#ifdef VBZ_EXPERIMENTS
+// Test aid (experiments build only): the first half of vbz_gpu_compress_batch for int16 zig-zag reads at level != 0 on the one-workgroup
+// path -- scratch slots, svb_encode with its hand-over to the entropy stage (svb_kernels.hip CNT) -- and nothing of the entropy stage.
+// Afterwards read i's svb stream stands at the bottom of its destination slot, result[i] = the stream's size, and plans_out (device,
+// n_reads * vbz_gpu_x_plan_bytes() bytes) holds the per-read plans.  tests/test_gpu_handover.py holds them to a numpy statement of
+// region_histogram's sample.
+VBZ_EXPORT size_t vbz_gpu_x_plan_bytes(void) { return sizeof(EncPlan); }
+VBZ_EXPORT int vbz_gpu_x_svb_handover(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, void* plans_out)
+{
+    if (!c || !bt || !plans_out) return -1;
+    DeviceGuard dg(c->device);
+    const uint32_t n = bt->n_reads;
+    if (n == 0) return 0;
+    hipStream_t s = c->stream;
+    ReadBatch rb = to_rb(bt);
+    uint32_t num, den;
+    svb_factor(2, true, &num, &den);
+    const size_t scratch_need = (size_t)(((unsigned __int128)bt->src_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
+    if (!ensure(c, c->scratch, scratch_need) || !ensure(c, c->meta, (size_t)n * 40 + 256) || !ensure(c, c->encplan, zstd_encode_plan_bytes(n))) return -1;
+    MetaCarver mc(c->meta.p);
+    uint64_t* svb_off = mc.take<uint64_t>(n);
+    uint32_t* svb_cap = mc.take<uint32_t>(n);
+    uint32_t* svb_size = mc.take<uint32_t>(n);
+    uint32_t* gate = mc.take<uint32_t>(n);
+    HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, false, s), "plan launch");
+    ReadBatch a = rb;
+    a.dst = (uint8_t*)c->scratch.p;
+    a.dst_off = svb_off;
+    a.dst_cap = svb_cap;
+    a.result = svb_size;
+    a.gate = gate;
+    HIPCHK(c, launch_svb_encode(a, 2, true, 0, false, false, nullptr, c->encplan.p, s), "svb_encode launch");
+    ReadBatch cp = rb;   // scratch slot -> bottom of the destination slot
+    cp.src = (const uint8_t*)c->scratch.p;
+    cp.src_off = svb_off;
+    cp.src_size = svb_size;
+    cp.gate = gate;
+    HIPCHK(c, launch_copy_bytes(cp, 0, s), "copy launch");
+    HIPCHK(c, hipMemcpyAsync(plans_out, c->encplan.p, (size_t)n * sizeof(EncPlan), hipMemcpyDeviceToDevice, s), "plan copy");
+    return 0;
+}
+#endif
 
 void vbz_gpu_profile_enable(vbz_gpu_ctx* c, int enable)
 {

@@ -37,6 +37,41 @@ struct ReadBatch
     const uint32_t* gate;
 };
 
+// ---- the per-read plans of the staged encoder (zstd_encode.hip), and what the svb encoder leaves in them ---------------------------
+// The entropy stage turns every run of >= RMIN equal control bytes into a zstd sequence and Huffman-codes what is left, each region from
+// its own byte histogram.  The one-wavefront path does that in stages that hand a read on through its EncPlan: the svb encoder counts
+// the data bytes' sample on the way (int16 zig-zag reads: svb_kernels.hip CNT), zstd_plan_kernel tokenises the control bytes, codes their
+// sequences section and builds both regions' tables (two wavefronts per read), zstd_pack_kernel packs.
+#ifndef VBZ_RMIN
+#define VBZ_RMIN 12
+#endif
+constexpr uint32_t RMIN = VBZ_RMIN;  // shortest run of equal bytes that becomes a match (break-even is ~13 bytes); >= 8, <= 24
+struct EncRegionPlan
+{
+    uint32_t S, nblk, nrec, seqmode, Sh, treeSize, huffLog, pad;
+    uint32_t ctable[256];   // code | length << 16.  (reg[1], before zstd_plan_kernel: the histogram the svb encoder left: EncPlan::hist_mode)
+    uint32_t tree[34];      // the tree description (136 bytes)
+};
+struct EncPlan
+{
+    EncRegionPlan reg[2];
+    uint32_t seqBytes, seqOff;      // the sequences section of region 0, coded by zstd_plan_kernel at the top of the destination slot
+    uint32_t cpCount, cpSpacing;    // its decoder checkpoints (CP_MAGIC trailer)
+    uint32_t cp[64];
+    // the control bytes are tokenised IN PLACE (their literals compacted to the front of the region, the run records at the tail of the
+    // scratch slot): whoever codes the read afterwards takes the result from here
+    uint32_t tok_done, tok_nrec, tok_lit;
+    // histogram of the data bytes the svb encoder left: 0 none; 1: reg[1].ctable = the data bytes region_histogram's sample counts (one
+    // kilobyte in four + the unaligned ends); 2: and histB = the data bytes the sample leaves out (reads so short that the region may be
+    // counted exactly)
+    uint32_t hist_mode;
+    uint32_t pad[8];
+    uint32_t histB[256];
+};
+constexpr uint32_t PLAN_OPEN = 1, PLAN_REG0 = 2, PLAN_REG1 = 4, PLAN_READY = 7;
+constexpr uint32_t ENC_TRAILERS = 1, ENC_PRE_FILLED = 2;   // bits of the entropy stage's `trailers` argument
+inline EncPlan* zstd_encode_plans(void* plan_meta) { return reinterpret_cast<EncPlan*>(plan_meta); }   // the plans inside plan_meta
+
 // ---- streamvbyte stage (svb_kernels.hip) -------------------------------------------------------
 // integer_size in {1,2,4}; zigzag.
 // hdr: 0, or 4 to prepend / skip the sized header (u32 LE original size) in front of the svb stream.
@@ -44,8 +79,11 @@ struct ReadBatch
 // half: the v1 nibble codec for 1-byte integers (vbz/v1/vbz_streamvbyte_impl.h)
 // period_hint (nullable, n_reads words): the encoder also looks for ONE long repeat distance in the data bytes it writes
 // (svb_kernels.hip: PeriodProbe) and leaves it there (0: none) for the entropy stage's long-repeat coder.
+// plans (nullable: the plan_meta of launch_zstd_encode; int16 zig-zag reads into library scratch only): every read's data bytes are
+// counted on the way and the histogram left in its plan (EncPlan::hist_mode, written for EVERY read of the launch).
 hipError_t launch_svb_encode(const ReadBatch& b, int integer_size, bool zigzag, uint32_t hdr, bool strict_cap, bool half, uint32_t* period_hint,
-                             hipStream_t s);
+                             void* plans, hipStream_t s);
+bool svb_encode_fills_plans(int integer_size, bool zigzag, bool half);   // does launch_svb_encode(plans) write every read's hist_mode?
 hipError_t launch_svb_decode(const ReadBatch& b, int integer_size, bool zigzag, bool half, hipStream_t s);
 // The same stage with one read spread over many workgroups ("segments" of svb_seg_unit_bytes raw bytes), for batches of few,
 // large reads (one 10 M-element buffer, one 400 k-sample read): seg_first[n_reads + 1] from launch_seg_plan; max_segs
@@ -69,12 +107,13 @@ hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigz
 // whose proposal holds are coded by a second launch with the long-repeat matcher (what libzstd's match finder gets out of
 // template-cycling signal, at every level); deep_d[r] is rewritten with the verdict.  The matcher's workspace is the top of
 // the destination slot (reads whose slot is too small for frame and workspace are coded without it).
-// plan_meta (nullable, zstd_encode_plan_bytes(n_reads) bytes of device scratch): the ordinary read is coded by two launches (tables,
-// then packing at twice the occupancy: zstd_encode.hip STAGE 1 / 2) and only what they leave over by the fused kernel.  Same frames
-// either way.
+// plan_meta (nullable, zstd_encode_plan_bytes(n_reads) bytes of device scratch): the per-read plans.  staged: the ordinary read is
+// coded by the staged launches (tokeniser + sequences section, tables, packing -- each at the occupancy its own footprint allows) and
+// only what they leave over by the one-launch kernel; same frames either way.  pre_filled: launch_svb_encode(plans) has left every
+// read's hist_mode (and histogram) in the plans.
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              uint32_t* deep_d, void* plan_meta, unsigned long long* pack_dbg, hipStream_t s);
+                              uint32_t* deep_d, void* plan_meta, bool staged, bool pre_filled, unsigned long long* pack_dbg, hipStream_t s);
 size_t zstd_encode_plan_bytes(uint32_t n_reads);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);

@@ -120,6 +120,38 @@ struct EncLds
     SeqCTables seq;             // encoding tables of the predefined LL / ML distributions
     uint32_t cp[64];            // decoder checkpoints of the sequences section (see CP_MAGIC)
     uint32_t cpCount, cpSpacing;
+    __device__ __forceinline__ void set_code(uint32_t s, uint32_t code, uint32_t nb) { ctable[s] = make_uint2(code, nb); }
+};
+
+// The staged encoder's planning launch (zstd_plan_kernel) works on the same functions with LDS of its own, two wavefronts per read:
+// a region's table -- histogram, code lengths, codes, tree description
+struct TableLds
+{
+    uint32_t hist[256];
+    uint32_t ctable[256];      // code | length << 16 (what the plan stores)
+    uint8_t nbBits[256];
+    uint8_t weights[260];
+    uint8_t tree[136];
+    int32_t treeSize;
+    uint32_t mode;      // 0 raw, 1 rle, 2 huffman
+    uint32_t huffLog;
+    uint32_t rankcnt[16];
+    union
+    {
+        HufPmWksp pm;
+        FseWeightWksp fw;
+    };
+    __device__ __forceinline__ void set_code(uint32_t s, uint32_t code, uint32_t nb) { ctable[s] = code | (nb << 16); }
+};
+// the control bytes' tokeniser (no LDS at all) and their sequences section
+struct TokSeqLds
+{
+    uint32_t obuf[128];         // bit buffer of the section
+    uint16_t seqcode[8 + 256];
+    uint32_t seqpiece[256];
+    SeqCTables seq;
+    uint32_t cp[64];
+    uint32_t cpCount, cpSpacing;
 };
 
 __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
@@ -163,7 +195,50 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // histogram is exact, as for the smaller regions.  Returns the number of bytes counted into L.hist.
 constexpr uint32_t HIST_SAMPLE_FROM = 32u << 10, HIST_SAMPLE_SEEN = 240;
 
-__device__ uint32_t region_histogram(EncLds& L, const uint8_t* in, uint32_t n, int lane, bool allow_sample)
+// the bytes of in[0..n) the sample counts: the unaligned ends and one stripe of 64 aligned 16-byte chunks in four
+__device__ __forceinline__ uint32_t hist_sample_bytes(const uint8_t* in, uint32_t n)
+{
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)in & 15u)) & 15u);
+    const uint32_t h = head < n ? head : n;
+    const uint32_t nvec = (n - h) >> 4, tail0 = h + (nvec << 4);
+    const uint32_t stripes = (nvec + WAVE - 1) / WAVE, groups = stripes >> 2, last = stripes & 3u;
+    uint32_t chunks = groups * WAVE;     // sampled chunks: the first stripe of every group of four ...
+    if (last) chunks += (nvec - groups * 4u * WAVE) < (uint32_t)WAVE ? (nvec - groups * 4u * WAVE) : (uint32_t)WAVE;
+    return h + (n - tail0) + 16u * chunks;
+}
+
+template <class LDS>
+__device__ __forceinline__ uint32_t region_histogram(LDS& L, const uint8_t* in, uint32_t n, int lane, bool allow_sample);
+
+// The same histogram from what the svb encoder left in the read's plan (EncPlan::hist_mode; svb_kernels.hip TOK counts exactly the
+// bytes region_histogram would: `sample` = the sampled data bytes, `rest` = the others or nullptr): L.hist and the return value are
+// region_histogram's.  What the hand-over cannot answer (an exact count without `rest`) is counted from memory as before.
+template <class LDS>
+__device__ __forceinline__ uint32_t region_histogram_from_plan(LDS& L, const uint8_t* in, uint32_t n, int lane, bool allow_sample, const uint32_t* sample, const uint32_t* rest)
+{
+    uint32_t seen = 0;
+    uint32_t c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        c[j] = sample[lane + 64 * j];
+        seen += c[j] ? 1u : 0u;
+    }
+    seen = wave_sum_u32(seen);
+    if (allow_sample && n >= HIST_SAMPLE_FROM && seen >= HIST_SAMPLE_SEEN) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) L.hist[lane + 64 * j] = c[j] ? c[j] : 1u;
+        wave_lds_sync();
+        return hist_sample_bytes(in, n) + (256u - seen);
+    }
+    if (!rest) return region_histogram(L, in, n, lane, allow_sample);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.hist[lane + 64 * j] = c[j] + rest[lane + 64 * j];
+    wave_lds_sync();
+    return n;
+}
+
+template <class LDS>
+__device__ __forceinline__ uint32_t region_histogram(LDS& L, const uint8_t* in, uint32_t n, int lane, bool allow_sample)
 {
     static_assert(sizeof(HufPmWksp) >= 4 * 256 * sizeof(uint32_t), "the sub-histograms live in the table-construction workspace");
     uint32_t* sub = reinterpret_cast<uint32_t*>(&L.pm);
@@ -219,10 +294,7 @@ __device__ uint32_t region_histogram(EncLds& L, const uint8_t* in, uint32_t n, i
             for (int i = lane; i < 256; i += WAVE)
                 if (L.hist[i] == 0) L.hist[i] = 1;   // a value the sample missed may still occur: it gets a (long) word
             wave_lds_sync();
-            const uint32_t stripes = (nvec + WAVE - 1) / WAVE, groups = stripes >> 2, last = stripes & 3u;
-            uint32_t chunks = groups * WAVE;     // sampled chunks: the first stripe of every group of four ...
-            if (last) chunks += (nvec - groups * 4u * WAVE) < (uint32_t)WAVE ? (nvec - groups * 4u * WAVE) : (uint32_t)WAVE;
-            return h + (n - tail0) + 16u * chunks + (256u - seen);
+            return hist_sample_bytes(in, n) + (256u - seen);
         }
         count(1, 1, 4, 3);                       // the rest: stripes 1, 2, 3 of every four
     } else {
@@ -256,7 +328,8 @@ __device__ __forceinline__ uint32_t sorted_count(const uint32_t* arr, uint32_t v
     return lo;
 }
 
-__device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBits, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
+template <class LDS>
+__device__ __forceinline__ uint32_t huf_build_wave(LDS& L, uint32_t maxSym, uint32_t maxNbBits, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
 {
     HufPmWksp& K = L.pm;
     // --- sort the present symbols by (count, 255 - symbol), ascending: bitonic network over 256 keys, element e = 4*lane + j
@@ -465,7 +538,7 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
             if (nb == (uint32_t)l) code = val[l] + (uint32_t)__popcll(m & below);
             val[l] += (uint32_t)__popcll(m);
         }
-        L.ctable[s] = make_uint2(code, nb);
+        L.set_code(s, code, nb);
     }
     wave_lds_sync();
     return maxNbBits;
@@ -478,7 +551,8 @@ __device__ uint32_t huf_build_wave(EncLds& L, uint32_t maxSym, uint32_t maxNbBit
 // unusual -- a weight list too short or too uniform to compress, the second normalisation method, a description that does
 // not pay -- is left to the serial function.  L.weights[0..maxSym) and L.fw.count[] are filled by the caller.
 // (__forceinline__: as a called function this faulted on hardware with ROCm 7.2)
-__device__ __forceinline__ int huf_write_tree_wave(EncLds& L, uint32_t maxSym, uint32_t huffLog, int lane)
+template <class LDS>
+__device__ __forceinline__ int huf_write_tree_wave(LDS& L, uint32_t maxSym, uint32_t huffLog, int lane)
 {
     FseWeightWksp& W = L.fw;
     const uint32_t wtSize = maxSym;
@@ -614,7 +688,8 @@ __device__ __forceinline__ int huf_write_tree_wave(EncLds& L, uint32_t maxSym, u
 
 // all lanes: choose the coding mode of a region from its histogram and, for Huffman, build the table
 // S: bytes of the region; Sh: bytes its histogram counts (S, or the size of the sample: region_histogram)
-__device__ void region_plan(EncLds& L, uint32_t S, uint32_t Sh, uint32_t nblk, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
+template <class LDS>
+__device__ __forceinline__ void region_plan(LDS& L, uint32_t S, uint32_t Sh, uint32_t nblk, int lane, unsigned long long* tsub = nullptr, unsigned long long* tl = nullptr)
 {
     uint32_t mx = 0, msym = 0;
 #pragma unroll
@@ -697,14 +772,11 @@ __device__ void region_plan(EncLds& L, uint32_t S, uint32_t Sh, uint32_t nblk, i
 // literals (everything outside the run tails) are Huffman coded as before.  Which bytes are run tails is a
 // morphological open of the zero mask, computed with shifts on a 64-bit window per lane; positions come from
 // wave prefix sums; the FSE state chains of the sequences section run on all lanes too (encode_zero_run_sequences).
-#ifndef VBZ_RMIN
-#define VBZ_RMIN 12
-#endif
 #ifndef VBZ_DATA_BLOCKS
 #define VBZ_DATA_BLOCKS 15
 #endif
 constexpr uint32_t DATA_BLOCKS = VBZ_DATA_BLOCKS;  // blocks of the data-byte region when the control bytes take one block
-constexpr uint32_t RMIN = VBZ_RMIN;  // shortest zero run that becomes a match (break-even is ~13 bytes); >= 8, <= 24
+// (RMIN, the shortest run that becomes a match: vbz_kernels.h -- the svb encoder's tokeniser uses it too)
 static_assert(RMIN >= 8 && RMIN <= 24, "the tokeniser handles at most two run ends per 16 positions and a 64-bit window");
 constexpr uint32_t TOK_PAYLOAD = 60 * 16;
 
@@ -955,7 +1027,8 @@ __device__ __forceinline__ SeqStep seq_fse_step(uint32_t st, uint32_t dnb, int32
     return { stab[(int32_t)(st >> nb) + dfs], (st & ((1u << nb) - 1u)) | (nb << 6) };
 }
 
-__device__ uint32_t encode_zero_run_sequences(EncLds& L, uint8_t* dst, const uint2* rec, uint32_t nseq, int lane, uint32_t of_dist = 0)
+template <class LDS>
+__device__ __forceinline__ uint32_t encode_zero_run_sequences(LDS& L, uint8_t* dst, const uint2* rec, uint32_t nseq, int lane, uint32_t of_dist = 0)
 {
     const uint32_t of_code = of_dist ? (uint32_t)hb32(of_dist + 3u) : 0u;
     const uint32_t of_extra = of_dist ? (of_dist + 3u) - (1u << of_code) : 0u;
@@ -1177,33 +1250,12 @@ __device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN,
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
 // DEEP: with the long-repeat matcher (level >= 4); a separate instantiation so that the ordinary kernel does not carry its registers
-// STAGE: 0 the whole frame in one launch (span mode, the long-repeat matcher, phase timers, and every read the staged launches
-// leave in redo[]: then only those).  1: the PLANNING launch of the staged encoder -- for the ordinary read (control-byte region with
-// run sequences or without, data-byte region, both Huffman coded, one pass of streams each) everything up to and including the
-// table construction of both regions and the sequences section, left in an EncPlan per read; zstd_pack_kernel then only packs
-// (tree, streams, headers, the sequences section moved into place, trailer).  The packing loop is 65 % of the fused kernel and
-// needs half its registers (profiles/r04_experiments.md): on its own it runs at 1.5 x the occupancy.  A read that is not of the
-// ordinary shape, or whose packing overruns (a sampled histogram that misled), keeps redo[r] = 1 and is coded by the STAGE 0
-// launch behind (which takes the tokeniser's result from the plan: that step works in place).
-struct EncRegionPlan
-{
-    uint32_t S, nblk, nrec, seqmode, Sh, treeSize, huffLog, pad;
-    uint32_t ctable[256];   // code | length << 16
-    uint32_t tree[34];      // the tree description (136 bytes)
-};
-struct EncPlan
-{
-    EncRegionPlan reg[2];
-    uint32_t seqBytes, seqOff;      // the sequences section of region 0, coded by the planning launch at the top of the destination slot
-    uint32_t cpCount, cpSpacing;    // its decoder checkpoints (CP_MAGIC trailer)
-    uint32_t cp[64];
-    // the tokeniser compacts the control bytes' literals IN PLACE: once the planning launch has run it, whoever codes the read
-    // afterwards (the packing launch, or the fused kernel for a read left in redo[]) takes its result from here
-    uint32_t tok_done, tok_nrec, tok_lit;
-    uint32_t pad[9];
-};
+// This kernel codes a whole frame in one launch: span mode, the long-repeat matcher, phase timers, and on the one-wavefront path every
+// read the staged launches below (zstd_plan_kernel, zstd_pack_kernel) leave in redo[] -- then only those; it
+// takes the tokeniser's result from the read's plan, because that step works in place.
+// (EncRegionPlan / EncPlan: vbz_kernels.h -- the svb encoder fills part of them)
 
-template <bool TIMED, bool DEEP, int STAGE = 0>
+template <bool TIMED, bool DEEP>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab, const EncSpan* spans,
@@ -1227,12 +1279,8 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     }
     const uint32_t r = span_mode ? sp.read : blockIdx.x;
     // the bytes produced (or an error code): the read's result, or the span's size
-#define FINISH(v) do { if (lane == 0) { if (span_mode) span_size[blockIdx.x] = (v); else if (STAGE == 0) b.result[r] = (v); } } while (0)
-    if (STAGE == 0 && redo && !span_mode && !redo[r]) return;   // the launch behind the staged ones: only what they left
-    if (STAGE == 1 && lane == 0) {
-        redo[r] = 1;                                            // until this read's plan is complete
-        plans[r].tok_done = 0;
-    }
+#define FINISH(v) do { if (lane == 0) { if (span_mode) span_size[blockIdx.x] = (v); else b.result[r] = (v); } } while (0)
+    if (redo && !span_mode && redo[r] == PLAN_READY) return;   // the launch behind the staged ones: only what they left (redo[]: their pstate[])
     if (!span_mode && b.gate && b.gate[r] >= GATE_SKIP) {
         if (b.gate[r] != GATE_SKIP) FINISH(b.gate[r]);
         return;
@@ -1287,7 +1335,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     bool frame_cp = false;  // a sequences section with checkpoints was written
     if (!span_mode || (sp.flags & SPAN_FIRST)) {
         NEED(hdr + 9 + (N == 0 ? 3 : 0));
-        if (lane == 0 && STAGE != 1) {
+        if (lane == 0) {
             if (hdr) put_le(out, orig_size[r], 4);
             uint8_t* p = out + hdr;
             put_le(p, 0xFD2FB528u, 4);
@@ -1298,7 +1346,6 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         opos = hdr + 5 + (N < 256 ? 1 : (N < 65536 + 256 ? 2 : 4));
     }
     if (N == 0) {
-        if (STAGE != 0) return;   // (left to the launch behind)
         if (lane == 0) put_le(out + opos, 1, 3);
         FINISH(opos + 3);
         return;
@@ -1381,18 +1428,13 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             if (need <= slot) {
                 uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * recs_all) & ~7u) + 8u * (r0 / RMIN + 2u * ord);
                 uint32_t Lit = 0;
-                if (STAGE == 0 && plans && !span_mode && plans[r].tok_done) {
-                    // the launch behind the staged ones: the planning launch has tokenised this region already
+                if (plans && !span_mode && plans[r].tok_done) {
+                    // the launch behind the staged ones: zstd_plan_kernel has tokenised this region already
                     nrec = plans[r].tok_nrec;
                     Lit = plans[r].tok_lit;
                 } else {
                     tokenise_runs<false, false, TIMED>(const_cast<uint8_t*>(rin), S, reinterpret_cast<uint2*>(ws), Lit, nrec, nullptr, lane, tph, &tlast);
                     __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
-                    if (STAGE == 1 && lane == 0) {
-                        plans[r].tok_nrec = nrec;
-                        plans[r].tok_lit = Lit;
-                        plans[r].tok_done = 1;
-                    }
                 }
                 if (nrec) {
                     seqmode = true;
@@ -1441,53 +1483,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             goto region_done;
         }
         const uint32_t mode = L.mode;
-        if (STAGE == 1) {
-            // the ordinary read: both regions Huffman coded, the first with run sequences or without; everything else is left
-            // to the launch behind (redo[r] stays 1)
-            if (mode != 2u || region > 1) return;
-            EncRegionPlan* P = &plans[r].reg[region];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint2 e = L.ctable[lane + 64 * j];
-                P->ctable[lane + 64 * j] = e.x | (e.y << 16);
-            }
-            if (lane < 34) P->tree[lane] = reinterpret_cast<const uint32_t*>(L.tree)[lane];
-            if (lane == 0) {
-                P->S = S;
-                P->nblk = nblk;
-                P->nrec = nrec;
-                P->seqmode = seqmode ? 1u : 0u;
-                P->Sh = Sh;
-                P->treeSize = (uint32_t)L.treeSize;
-                P->huffLog = L.huffLog;
-            }
-            if (nblk > (uint32_t)MAXBLK) return;   // (more than one pass of streams: the fused kernel)
-            if (region == 0) {
-                EncPlan* FP = &plans[r];
-                uint32_t sb = 0, so = 0;
-                if (seqmode) {
-                    // the sequences section does not depend on the packing: it is coded here, at the top of the read's destination
-                    // slot, and the packing launch moves it behind the block's literals (it checks that the frame stays below it)
-                    const uint64_t room = 24ull + 8ull * nrec;
-                    if (room + 4096u > cap) return;
-                    so = (uint32_t)((cap - room) & ~15ull);
-                    wave_lds_sync();
-                    sb = encode_zero_run_sequences(L, out + so, rec, nrec, lane, 0u);
-                    wave_lds_sync();
-                    if (lane < 64) FP->cp[lane] = L.cp[lane];
-                }
-                if (lane == 0) {
-                    FP->seqBytes = sb;
-                    FP->seqOff = so;
-                    FP->cpCount = seqmode ? L.cpCount : 0u;
-                    FP->cpSpacing = seqmode ? L.cpSpacing : 0u;
-                }
-            }
-            wave_lds_sync();
-            PHASE(4);
-            goto region_done;
-        }
-        if (STAGE == 0 && seqmode && mode != 2) {
+        if (seqmode && mode != 2) {
             // literals do not pay for a Huffman table: Raw_Literals_Block + sequences in one compressed block
             const uint32_t lh = S < 32 ? 1u : (S < 4096 ? 2u : 3u);
             NEED(3ull + lh + S + 8 + 8ull * nrec);
@@ -1504,7 +1500,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             opos += 3 + lh + S + sb;
             goto region_done;
         }
-        if (STAGE == 0 && mode == 1) {
+        if (mode == 1) {
             // RLE blocks (Block_Type 1): Block_Size = run length, one byte of content
             const uint32_t nb = (S + BLOCK_MAX - 1) / BLOCK_MAX;
             NEED(4ull * nb);
@@ -1521,7 +1517,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             opos += 4 * nb;
             goto region_done;
         }
-        if (STAGE == 0 && mode == 0) {
+        if (mode == 0) {
             // raw blocks (Block_Type 0), copied by the whole wave
             const uint32_t nb = (S + BLOCK_MAX - 1) / BLOCK_MAX;
             NEED(3ull * nb + S);
@@ -1785,7 +1781,6 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         }
     region_done:
         if (need_redo) {
-            if (STAGE != 0) return;   // a sample that misled: the launch behind codes the read with the exact histogram
             exact_hist = true;
             opos = opos_region;
             wave_lds_sync();
@@ -1793,12 +1788,6 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             exact_hist = false;
             ++region;
         }
-    }
-    if (STAGE == 1) {   // both regions planned
-        if (lane == 0) redo[r] = 0;
-        if (TIMED && lane == 0)
-            for (int k = 0; k < PHASE_SLOTS; ++k) dbg[(size_t)r * PHASE_SLOTS + k] = tph[k];
-        return;
     }
     const uint32_t main_bytes = opos;
     if (frame_cp && (trailers & 1u) && (!span_mode || (sp.flags & SPAN_FIRST))) {  // the skippable frame with the decoder checkpoints (optional: only if it fits)
@@ -1831,8 +1820,193 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 #undef FINISH
 }
 
+// ---- the planning launches of the staged encoder ---------------------------------------------------------------------------------
+// Round 4 planned a read (tokeniser, two histograms, two table constructions, the sequences section) in one launch of the big kernel
+// above: 128 registers and 10 KB of LDS per wavefront, 16 wavefronts per CU (profiles/r04_experiments.md: 505 k cycles per frame).  Now
+// every read is planned by TWO wavefronts of 8 KB of LDS and 71 registers each (zstd_plan_kernel below: 20 per CU), the data bytes'
+// histogram comes from the svb encoder (svb_kernels.hip CNT), and zstd_pack_kernel packs the reads whose plans are complete; everything
+// else stays in redo[] for the kernel above.  What round 5 measured on the way (profiles/r05_experiments.md): the launch is bound by
+// instruction issue (VALU 65 % busy, LDS 46 % with half of it bank conflicts), not by latency alone -- each phase as a launch of its
+// own, at up to 32 wavefronts per CU, was SLOWER (the tables alone, 20 LDS-heavy wavefronts per CU: 1.55 ms per 32 768 reads);
+// wavefronts of different phases sharing a CU is what pays.
+// Byte for byte the frames the one-launch form writes (tests/test_gpu_soak_slice.py holds the two against each other).
+#ifndef VBZ_TABLE_WAVES
+#define VBZ_TABLE_WAVES 5
+#endif
+
+// per read: block size target, the control-byte region (0: none)
+__device__ __forceinline__ uint32_t enc_key_bytes(uint32_t N, uint32_t r, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes)
+{
+    uint32_t K = 0;
+    if (N >= SPLIT_MIN) {
+        if (key_bytes) K = key_bytes[r];
+        else if (key_elem) K = (orig_size[r] / key_elem + 3u) >> 2;
+        if (K >= N) K = 0;
+    }
+    return K;
+}
+__device__ __forceinline__ uint32_t enc_block_target(uint32_t N)
+{
+    const uint32_t T = (N + 13) / 14;
+    return T < MIN_BLOCK ? MIN_BLOCK : (T > HUF_BLOCK_MAX ? HUF_BLOCK_MAX : T);
+}
+
+// One launch, two wavefronts per read (blockIdx = 2 * read + role), so that wavefronts in memory-bound phases (the tokeniser) and in
+// LDS-bound phases (sort, package-merge) share a CU at any time -- as separate launches the two lose that overlap (round 5 measured
+// tokeniser + sequences 0.59 ms and tables 1.55 ms per 32 768 reads against 1.88 ms for the one-wavefront planning launch of round 4).
+//   role 0: the control bytes' tokeniser, their sequences section, the table of region 0 (the literals);
+//   role 1: the table of region 1 (the data bytes) from the histogram the svb encoder left -- it cannot wait for role 0, so it GUESSES
+//           what only the tokeniser knows (did the control bytes get run sequences: then they are one block and the data bytes get 15),
+//           and role 0, which knows, opens the plan only if the guess was right.
+// pstate[read] (zeroed before the launch) collects PLAN_OPEN | PLAN_REG0 from role 0 and PLAN_REG1 from role 1; the packing launch packs
+// the reads that reach PLAN_READY (and takes a read's state back to 0 if its packing overruns), the one-launch kernel codes the others.
+__device__ __forceinline__ bool plan_guess_tokenised(uint32_t N, uint32_t K) { return K != 0 ? (K >= 256 && K <= BLOCK_MAX) : (N >= 256 && N <= BLOCK_MAX); }
+
+struct PlanLds
+{
+    union
+    {
+        TokSeqLds ts;
+        TableLds tb;
+    };
+};
+
+// the table of one region into the read's plan; returns whether the region is of the ordinary kind (Huffman coded, one pass of streams)
+__device__ __forceinline__ bool plan_region_table(TableLds& L, EncPlan* FP, uint32_t region, const uint8_t* rin, uint32_t S, uint32_t nblk, bool seqmode,
+                                                  uint32_t nrec, bool from_plan, int lane)
+{
+    uint32_t Sh;
+    if (from_plan) Sh = region_histogram_from_plan(L, rin, S, lane, true, FP->reg[1].ctable, FP->hist_mode == 2u ? FP->histB : nullptr);
+    else Sh = region_histogram(L, rin, S, lane, !seqmode);
+    region_plan(L, S, Sh, nblk, lane);
+    wave_lds_sync();
+    // a sample that says "does not pay" is not believed (the one-launch kernel counts again, exactly); raw / RLE regions and more
+    // than 16 blocks are its business too
+    if (L.mode != 2u) return false;
+    EncRegionPlan* P = &FP->reg[region];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) P->ctable[lane + 64 * j] = L.ctable[lane + 64 * j];
+    if (lane < 34) P->tree[lane] = reinterpret_cast<const uint32_t*>(L.tree)[lane];
+    if (lane == 0) {
+        P->S = S;
+        P->nblk = nblk;
+        P->nrec = nrec;
+        P->seqmode = seqmode ? 1u : 0u;
+        P->Sh = Sh;
+        P->treeSize = (uint32_t)L.treeSize;
+        P->huffLog = L.huffLog;
+    }
+    return nblk <= (uint32_t)MAXBLK;
+}
+
+__global__ __launch_bounds__(WAVE, VBZ_TABLE_WAVES) void zstd_plan_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
+                                                                          uint32_t hdr, const uint32_t* src_cap, const SeqCTables* seqtab, uint32_t* deep_d,
+                                                                          EncPlan* plans, uint32_t* pstate, uint32_t pre_filled)
+{
+    __shared__ __attribute__((aligned(16))) PlanLds LL;
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x >> 1, role = blockIdx.x & 1u;
+    EncPlan* FP = &plans[r];
+    if (role == 0 && lane == 0) {
+        FP->tok_done = 0;
+        FP->seqBytes = 0;
+        FP->seqOff = 0;
+        FP->cpCount = 0;
+        FP->cpSpacing = 0;
+    }
+    if (b.gate && b.gate[r] >= GATE_SKIP) return;
+    const uint32_t N = b.src_size[r];
+    if (N >= E_FIRST || N == 0) return;   // (an error of the svb stage, the empty frame: the one-launch kernel reports / writes them)
+    const uint8_t* in = b.src + b.src_off[r];
+    const uint32_t K = enc_key_bytes(N, r, orig_size, key_elem, key_bytes);
+    const uint32_t T = enc_block_target(N);
+    const bool guess = src_cap && seqtab && plan_guess_tokenised(N, K);
+    if (role == 1) {
+        if (K == 0) return;   // (a frame of one region: role 0 says so)
+        uint32_t S = N - K;
+        uint32_t nblk = (S + T - 1) / T;
+        if (guess) {
+            // the control bytes took one block (4 streams): the data bytes get the other 15 x 4 lanes of the decoder
+            uint32_t Td = (S + DATA_BLOCKS - 1) / DATA_BLOCKS;
+            Td = Td < MIN_BLOCK ? MIN_BLOCK : (Td > HUF_BLOCK_MAX ? HUF_BLOCK_MAX : Td);
+            nblk = (S + Td - 1) / Td;
+        }
+        const bool ok = plan_region_table(LL.tb, FP, 1, in + K, S, nblk, false, 0, pre_filled && FP->hist_mode != 0, lane);
+        __syncthreads();   // the plan is in memory before the bit that says so
+        if (ok && lane == 0) atomicOr(&pstate[r], PLAN_REG1);
+        return;
+    }
+    const uint32_t cap = b.dst_cap[r];
+    uint8_t* out = b.dst + b.dst_off[r];
+    // a read whose repeat distance holds is the matcher's (the check the one-launch kernel makes at its top; deep_d[r] keeps the verdict)
+    if (deep_d) {
+        const uint32_t hint = deep_d[r];
+        if (hint) {
+            bool ok = false;
+            if (K != 0 && src_cap && seqtab && N - K >= 8192) {
+                DeepLayout dl;
+                ok = deep_layout(N, K, in, src_cap[r], out, cap, hdr, dl) && period_holds(in + K, N - K, hint, lane);
+            }
+            if (ok) return;
+            if (lane == 0) deep_d[r] = 0;
+        }
+    }
+    if ((uint64_t)hdr + 9 > cap) return;
+    // the control-byte region (a stream too short to be cut in two: the whole stream): long runs become sequences, the literals are
+    // compacted in place, the run records go to the unused tail of the scratch slot
+    const uint32_t S0 = K ? K : N;
+    uint32_t nrec = 0, Lit = 0;
+    const uint2* rec = nullptr;
+    if (src_cap && seqtab && S0 >= 256 && S0 <= BLOCK_MAX) {
+        const uint32_t slot = src_cap[r];
+        const uint32_t recs_all = S0 / RMIN + 2u + 2u;
+        const uint64_t need = (uint64_t)N + 16 + 8ull * recs_all;
+        if (need <= slot) {
+            uint8_t* ws = const_cast<uint8_t*>(in) + ((slot - 8u * recs_all) & ~7u);
+            tokenise_runs<false>(const_cast<uint8_t*>(in), S0, reinterpret_cast<uint2*>(ws), Lit, nrec, nullptr, lane);
+            __syncthreads();  // the compacted literals and the records are re-read below (vmcnt drain)
+            rec = reinterpret_cast<const uint2*>(ws);
+            if (lane == 0) {
+                FP->tok_nrec = nrec;
+                FP->tok_lit = Lit;
+                FP->tok_done = 1;
+            }
+        }
+    }
+    if ((nrec != 0) != guess) return;   // role 1 has planned the data bytes for the other case: the one-launch kernel takes the read
+    if (nrec) {
+        // the sequences section does not depend on the packing: it is coded here, at the top of the read's destination slot, and the
+        // packing launch moves it behind the block's literals (it checks that the frame stays below it)
+        const uint64_t room = 24ull + 8ull * nrec;
+        if (room + 4096u > cap) return;
+        const uint32_t so = (uint32_t)((cap - room) & ~15ull);
+        TokSeqLds& L = LL.ts;
+        {
+            const uint32_t* g = reinterpret_cast<const uint32_t*>(seqtab);   // 968 bytes of encoding tables
+            uint32_t* l = reinterpret_cast<uint32_t*>(&L.seq);
+            for (uint32_t i = lane; i < sizeof(SeqCTables) / 4; i += WAVE) l[i] = g[i];
+        }
+        wave_lds_sync();
+        const uint32_t sb = encode_zero_run_sequences(L, out + so, rec, nrec, lane, 0u);
+        wave_lds_sync();
+        FP->cp[lane] = L.cp[lane];
+        if (lane == 0) {
+            FP->seqBytes = sb;
+            FP->seqOff = so;
+            FP->cpCount = L.cpCount;
+            FP->cpSpacing = L.cpSpacing;
+        }
+        wave_lds_sync();   // (the table workspace below shares this LDS)
+    }
+    const uint32_t S = nrec ? Lit : S0;
+    const uint32_t nblk = nrec ? 1u : (S + T - 1) / T;
+    const bool ok = plan_region_table(LL.tb, FP, 0, in, S, nblk, nrec != 0, nrec, false, lane);
+    __syncthreads();
+    if (ok && lane == 0) atomicOr(&pstate[r], PLAN_OPEN | PLAN_REG0 | (K == 0 ? PLAN_REG1 : 0u));
+}
+
 // ---- the packing launch of the staged encoder ---------------------------------------------------------------------------------
-// What zstd_encode_kernel does behind its table constructions, for the reads the planning launch (STAGE 1) has prepared: frame
+// What zstd_encode_kernel does behind its table constructions, for the reads whose plans the launches above have completed: frame
 // header; per region the tree description, the streams packed one after the other in frame order (the same loop: 16 symbols per lane
 // and step, a wave prefix sum of the bit counts, bits OR-ed into an LDS buffer, 16-byte quads out), the block headers; the sequences
 // section of the first block moved into place; the checkpoint trailer.  Byte for byte the fused kernel's frame.  80 registers and
@@ -1850,30 +2024,23 @@ struct PackLds
 // TIMED (VBZ_HIP_PHASE_TIMING=3, a separate instantiation): shader-clock counters per frame -- 0 set-up, 1 a region's table and
 // stream geometry, 2 the packing steps' table look-ups and prefix sum, 3 their bits into the LDS buffer, 4 the buffer's quads to
 // memory, 5 stream ends and block headers, 6 the sequences section moved into place, 7 trailer and result.
-// (the counters' buffer travels in PackArgs: an argument of the launch, nothing shared between contexts)
-struct PackArgs
-{
-    const EncPlan* plans;
-    uint32_t* redo;
-    unsigned long long* dbg;   // TIMED only
-};
+// (dbg: the TIMED instantiation's counters -- an argument of the launch, nothing shared between contexts.  redo[] = pstate[].)
 template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
-                                                                             uint32_t hdr, uint32_t trailers, PackArgs pa)
+                                                                             uint32_t hdr, uint32_t trailers, const EncPlan* plans, uint32_t* redo,
+                                                                             unsigned long long* dbg_)
 {
-    const EncPlan* const plans = pa.plans;
-    uint32_t* const redo = pa.redo;
-    unsigned long long* const dbg = TIMED ? pa.dbg : nullptr;
+    unsigned long long* const dbg = TIMED ? dbg_ : nullptr;
     __shared__ __attribute__((aligned(16))) PackLds L;
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PPHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
     const int lane = threadIdx.x;
     const uint32_t r = blockIdx.x;
-    if (redo[r]) return;
+    if (redo[r] != PLAN_READY) return;   // (redo[] = pstate[]: how far zstd_plan_kernel has brought the read)
 #define REDO()                          \
     do {                                \
-        if (lane == 0) redo[r] = 1;     \
+        if (lane == 0) redo[r] = 0;     \
         return;                         \
     } while (0)
     const uint32_t N = b.src_size[r];
@@ -2519,9 +2686,10 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
 
 hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                               uint32_t hdr, unsigned long long* dbg, const uint32_t* src_cap, const void* seq_tables, bool trailers,
-                              uint32_t* deep_d, void* plan_meta, unsigned long long* pack_dbg, hipStream_t s)
+                              uint32_t* deep_d, void* plan_meta, bool staged, bool pre_filled, unsigned long long* pack_dbg, hipStream_t s)
 {
-    const uint32_t tr = trailers ? 1u : 0u;
+    if (!plan_meta) staged = pre_filled = false;
+    const uint32_t tr = (trailers ? ENC_TRAILERS : 0u) | (pre_filled ? ENC_PRE_FILLED : 0u);
     if (b.n_reads == 0) return hipSuccess;
     const SeqCTables* st = reinterpret_cast<const SeqCTables*>(seq_tables);
 #ifdef VBZ_EXPERIMENTS   // the timed instantiations (phase cycle counters) are part of the experiments build only
@@ -2536,23 +2704,18 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
 #endif
     EncPlan* plans = reinterpret_cast<EncPlan*>(plan_meta);
     uint32_t* redo = plans ? reinterpret_cast<uint32_t*>(plans + b.n_reads) : nullptr;
-    if (plans && src_cap && st) {
-        // the ordinary read in two launches (plan, pack at twice the occupancy); whatever they leave in redo[] in the fused form
-        const PackArgs pa = { plans, redo, pack_dbg };
-#ifdef VBZ_EXPERIMENTS
-        if (dbg)   // VBZ_HIP_PHASE_TIMING=2: the planning launch with its phase counters, under load (the other launches as they are)
-            hipLaunchKernelGGL((zstd_encode_kernel<true, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                               src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
-        else
-#endif
-        hipLaunchKernelGGL((zstd_encode_kernel<false, false, 1>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, nullptr,
-                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, plans, redo);
+    if (staged && src_cap && st) {
+        // the ordinary read in stages (tokeniser + sequences section, tables per region, packing); whatever they leave in redo[] in the
+        // one-launch form behind them
+        (void)hipMemsetAsync(redo, 0, 4ull * b.n_reads, s);   // pstate[]
+        hipLaunchKernelGGL(zstd_plan_kernel, dim3(2 * b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, src_cap, st, deep_d, plans, redo,
+                           pre_filled ? 1u : 0u);
 #ifdef VBZ_EXPERIMENTS
         if (pack_dbg)   // VBZ_HIP_PHASE_TIMING=3: the packing launch with its phase counters
-            hipLaunchKernelGGL(zstd_pack_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, pa);
+            hipLaunchKernelGGL(zstd_pack_kernel<true>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo, pack_dbg);
         else
 #endif
-        hipLaunchKernelGGL(zstd_pack_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, pa);
+        hipLaunchKernelGGL(zstd_pack_kernel<false>, dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, tr, plans, redo, (unsigned long long*)nullptr);
     } else {
         redo = nullptr;
     }
@@ -2560,11 +2723,11 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
                        src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, redo);
     if (deep_d)  // the reads in which the first launch found a repeat distance (it wrote deep_d[] for every read)
         hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, nullptr,
-                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, nullptr, nullptr);
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, nullptr);
     return hipGetLastError();
 }
 
-size_t zstd_encode_plan_bytes(uint32_t n_reads) { return (size_t)n_reads * (sizeof(EncPlan) + 4) + 256; }
+size_t zstd_encode_plan_bytes(uint32_t n_reads) { return (size_t)n_reads * (sizeof(EncPlan) + 4) + 256; }   // plans, pstate[]
 
 // ---- the long-repeat matcher in front of span mode ----------------------------------------------------------------------------
 hipError_t launch_zstd_encode_matcher(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
