@@ -401,11 +401,9 @@ def run_rank(args):
         else:
             dist.init_process_group(backend=backend)
         assert dist.get_world_size() == args.gpus
-        # every rank sits on its own device
-        mine = torch.tensor([local_rank if dev is not None else rank], dtype=torch.int64, device=dev if backend == "nccl" else None)
-        seen = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(seen, mine)
-        assert len({int(t) for t in seen}) == world, "two ranks share a device"
+    # every rank sits on its own device: the ordinals as gathered over the process group (they go into the line's `collective` object)
+    devices = shard.gather_row([local_rank if dev is not None else rank], dev if (world > 1 and backend == "nccl") else None)[:, 0].tolist()
+    assert len(devices) == world and len(set(devices)) == world, "two ranks share a device: %s" % devices
 
     def barrier():
         if world > 1:
@@ -433,8 +431,13 @@ def run_rank(args):
         raw = sum(int(lengths[x:y].sum()) * 2 for x, y in batches) * args.steps // R
         elapsed = shard.max_over_ranks(time.perf_counter() - t0 + 1e-6)
         table, off = shard.exchange_tallies(sum(y - x for x, y in batches), raw, raw // 2)
+        mine_us = int((time.perf_counter() - t0 + 1e-6) * 1e6)
+        rows = shard.gather_row([sum(y - x for x, y in batches), raw, mine_us])
+        assert int(rows[:, 0].sum()) == total_reads, "the ranks' shares do not add up to the job: %s of %d reads" % (rows[:, 0].tolist(), total_reads)
+        coll = dict(shard.describe(backend, devices), reads_per_rank=rows[:, 0].tolist(),
+                    per_rank_MBps=[round(float(b_) / max(float(u_), 1.0), 1) for _, b_, u_ in rows.tolist()])
         if rank == 0:
-            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            print(json.dumps({"metric": METRIC, "value": 0.0, "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "collective": coll,
                               "ms_per_step": round(elapsed * 1e3, 3), "higher_is_better": True, "scaling": "strong" if fixed_job else "weak",
                               "vs_baseline": None, "dtype": "int16", "data": "dry-run (no codec: launcher and work-queue plumbing only)",
                               "config": {"workload": "dry-run" + (" of configs[4]: %d reads over %d rank(s)" % (total_reads, world) if fixed_job else ""),
@@ -450,7 +453,7 @@ def run_rank(args):
     codec = batch.GpuCodec(local_rank)
     torch.cuda.set_stream(codec.stream)  # everything below (generation, events, kernels) runs on the codec's stream
     if args.workload in ("config4", "config1"):
-        run_large(args, codec, dev, rank, world, coll_dev, barrier)
+        run_large(args, codec, dev, rank, world, coll_dev, barrier, shard.describe(backend, devices))
         if world > 1:
             barrier()
             dist.destroy_process_group()
@@ -554,6 +557,12 @@ def run_rank(args):
     barrier()
     elapsed = time.perf_counter() - t0
     codec.profile(False)
+    # what every rank did, gathered: its distinct reads (the shares must add up to the job), the raw bytes it coded in the timed
+    # region and the time that took it -- the line's `collective` object, so that a multi-GPU line certifies itself
+    rows = shard.gather_row([sum(B["n"] for B in batches), raw_bytes, int(elapsed * 1e6)], coll_dev)
+    assert int(rows[:, 0].sum()) == total_reads, "the ranks' shares do not add up to the job: %s of %d reads" % (rows[:, 0].tolist(), total_reads)
+    coll = dict(shard.describe(backend, devices), reads_per_rank=rows[:, 0].tolist(),
+                per_rank_MBps=[round(float(b_) / max(float(u_), 1.0), 1) for _, b_, u_ in rows.tolist()])
     elapsed = shard.max_over_ranks(elapsed, coll_dev)
     prof = codec.profile_read()
     ratio = raw_bytes / comp_bytes
@@ -653,6 +662,7 @@ def run_rank(args):
             "value": round(total_raw / elapsed / 1e6, 1),
             "unit": "MB/s",
             "n_gpus": world,
+            "collective": coll,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -710,7 +720,7 @@ def run_rank(args):
     return 0
 
 
-def run_large(args, codec, dev, rank, world, coll_dev, barrier):
+def run_large(args, codec, dev, rank, world, coll_dev, barrier, coll):
     """BASELINE.json configs[3] (`--workload config4`: uint32, no zig-zag, level 3, 10 M-element buffers) and configs[0]
     (`--workload config1`: one 400 k-sample int16 read): batches of few, large buffers, which the library spreads over many
     workgroups (segmented svb kernels, one wavefront per span of the entropy stage)."""
@@ -801,7 +811,7 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier):
         traffic, traffic_src = committed_traffic_large(dom_dir, nbuf)
     out = {
         "metric": METRIC if kind != "u32" else "MB/s encode+decode, uint32 buffers (BASELINE configs[3]: UD=32020,5,0,0,4,0,3), 1 MI355X vs CPU; ratio preserved",
-        "value": round(total_raw / elapsed / 1e6, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(total_raw / elapsed / 1e6, 1), "unit": "MB/s", "n_gpus": world, "collective": coll, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "uint32" if kind == "u32" else "int16", "data": "synthetic",
         "config": {"workload": name + ", encode then decode through the batched entry points, inputs resident in HBM",

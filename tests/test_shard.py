@@ -97,6 +97,12 @@ def test_bench_launcher_starts_one_process_per_rank():
     t = out["tallies"]
     assert t[0][0] == b0 - a0 and t[1][0] == b1 - a1
     assert abs(t[0][1] - t[1][1]) / t[0][1] < 0.01      # balanced by samples
+    # the line certifies its own collective: the backend, the world size the process group reports, every rank's device ordinal
+    # as gathered over it, what every rank did (the shares add up to the job: bench.py asserts it in every rank) and its rate
+    c = out["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and sorted(c["devices"]) == [0, 1]
+    assert c["reads_per_rank"] == [b0 - a0, b1 - a1] and sum(c["reads_per_rank"]) == 2 * 2 * 300
+    assert len(c["per_rank_MBps"]) == 2 and all(v > 0 for v in c["per_rank_MBps"])
     # a world size that does not match --gpus is refused, and a failing rank makes the launcher fail
     env2 = dict(env, WORLD_SIZE="2", RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True, timeout=120, env=env2)
@@ -129,6 +135,8 @@ def test_fixed_job_is_sharded_over_the_ranks():
     t = two["tallies"]
     assert t[0][0] + t[1][0] == 3001 and t[0][1] + t[1][1] == one["tallies"][0][1]
     assert 1.0 <= two["rank_imbalance"] < 1.01
+    assert one["collective"] == dict(one["collective"], backend=None, world_size=1, devices=[0], reads_per_rank=[3001])
+    assert two["collective"]["world_size"] == 2 and sum(two["collective"]["reads_per_rank"]) == 3001
 
 
 def test_launcher_counts_gpus_without_the_hip_runtime():
@@ -147,6 +155,11 @@ def test_launcher_counts_gpus_without_the_hip_runtime():
     src = open(os.path.join(root, "bench.py")).read()
     launcher = src[src.index("def main():"):]
     assert "device_count" not in launcher and "is_available" not in launcher
+
+
+def test_gather_row_and_describe_without_a_group():
+    assert shard.gather_row([3, 4, 5]).tolist() == [[3, 4, 5]]
+    assert shard.describe("nccl", [0]) == {"backend": None, "world_size": 1, "devices": [0]}
 
 
 def test_single_rank_identity():

@@ -76,3 +76,21 @@ def max_over_ranks(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_row(values, device=None):
+    """All-gather one row of int64 values per rank; returns table[world, len(values)] on the CPU (the single-rank identity
+    without an initialised process group).  Work-queue metadata only: a few words per rank."""
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    if not _active():
+        return mine.unsqueeze(0).cpu()
+    table = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(table, mine)
+    return torch.stack(table).cpu()
+
+
+def describe(backend, device_ordinals):
+    """What carried the work queue, as the ranks themselves see it (bench.py's `collective` object): the backend, the world size the
+    process group reports (1 without a group), and every rank's device ordinal as gathered over that group."""
+    ws = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    return {"backend": backend if ws > 1 else None, "world_size": ws, "devices": [int(d) for d in device_ordinals]}
