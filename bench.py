@@ -703,7 +703,8 @@ def run_rank(args):
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import pcie_pipeline
 
-            h = pcie_pipeline.measure(codec, 2048, 8)
+            # (16 batches: with 8 the pipeline's fill and drain -- two of ten stage times -- held the decode leg at half the link)
+            h = pcie_pipeline.measure(codec, 2048, 16)
             out["host_resident"] = {"encode_decode_MBps": h["encode_decode_MBps"], "encode_MBps": h["encode_MBps"], "decode_MBps": h["decode_MBps"],
                                     "h2d_GBps": h["h2d_GBps"], "d2h_GBps": h["d2h_GBps"], "round_trip_ok": h["round_trip_ok"],
                                     "note": "PCIe-inclusive rate with pinned host buffers both ends (tools/pcie_pipeline.py); never `value`"}

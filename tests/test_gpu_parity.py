@@ -223,6 +223,12 @@ def test_wave_svb_decoder_behind_the_entropy_stage():
 # ------------------------------------------------------------------------------------------------
 # stage 2: zstd-format entropy stage
 # ------------------------------------------------------------------------------------------------
+def _lib_opts(zz, size, level, version):
+    from vbz_compression_amd import _lib
+
+    return _lib.CompressionOptions(zz, size, level, version)
+
+
 def _svb_streams():
     out = []
     for i, n in enumerate([0, 1, 5, 40, 200, 700, 1000, 3000, 9000, 30000, 100000, 110000, 400000]):
@@ -472,6 +478,30 @@ def test_zstd_ratio_close_to_libzstd_on_signal():
     gpu = sum(len(f) for f in frames)
     ref = sum(len(O.compress(a, O.options(True, 2, 1, 1))) for a in reads)
     assert abs(gpu / ref - 1.0) < 0.01, (gpu, ref)  # ratio within 1 % of the reference
+
+
+def test_zstd_levels_above_one_write_the_level_one_frames():
+    """The reference hands zstd_compression_level to libzstd (vbz/vbz.cpp:194-207) and its own HDF5 test writes at level 5
+    (vbz_plugin/test/vbz_hdf_plugin_test.cpp:34).  This library has ONE encoder (include/vbz.h): any level but 0 gives the bytes of
+    level 1 -- and on nanopore signal that is where libzstd's levels are anyway: the ten real reads of the shipped fast5 file and eight
+    synthetic ones at level 5 (the plugin's case: UD=32020,0,2,1,1,5) come out within 1 % of what libzstd writes at level 1 (libzstd's
+    own level 5 gains 0.1 % on the real reads and 0.5 % on the synthetic ones), sized and decodable by the reference path at either level."""
+    import gpu_util as G
+
+    idx = json.load(open(os.path.join(GOLDEN, "fast5_chunks.json")))
+    blob = np.fromfile(os.path.join(GOLDEN, "fast5_chunks.bin"), np.uint8)
+    real = [O.decompress(blob[e["chunk_offset"] : e["chunk_offset"] + e["chunk_size"]], 2 * e["samples"], O.options(True, 2, 1, 0), sized=True).view(np.int16) for e in idx]
+    reads = real + [O.synth_signal(5, 100 + i, O.synth_read_length(5, 100 + i)) for i in range(8)]
+    by_level = {lv: G.compress(reads, _lib_opts(True, 2, lv, 0), sized=True) for lv in (1, 5, 19)}
+    for f1, f5, f19, a in zip(by_level[1], by_level[5], by_level[19], reads):
+        assert not isinstance(f5, int) and f1.tobytes() == f5.tobytes() == f19.tobytes()
+        assert O.decompress(f5, a.nbytes, O.options(True, 2, 5, 0), sized=True).tobytes() == a.tobytes()
+    for group in (slice(0, len(real)), slice(len(real), None)):
+        gpu = sum(len(f) for f in by_level[5][group])
+        ref1 = sum(len(O.compress(a, O.options(True, 2, 1, 0), sized=True)) for a in reads[group])
+        ref5 = sum(len(O.compress(a, O.options(True, 2, 5, 0), sized=True)) for a in reads[group])
+        assert abs(gpu / ref1 - 1.0) < 0.01, (gpu, ref1, ref5)
+        assert gpu < 1.02 * ref5, (gpu, ref1, ref5)    # ... and within 2 % of what libzstd's level 5 finds
 
 
 def test_checkpoint_trailer_is_optional_and_untrusted():
@@ -788,8 +818,9 @@ def test_pyvbz_interface():
         vbz.compress(np.arange(4, dtype=np.int16), True)   # a bare zig-zag flag in the options slot is refused, not ignored
     sig = np.arange(0, 1000, dtype=np.int16)    # python/pyvbz/README.md:18-23
     c = vbz.compress(sig)
-    # the reference's answer is 27 bytes (libzstd finds the two runs); this encoder's run sequences get within 2x of it
-    assert c[:4].view("<u4")[0] == 2000 and len(c) <= 54, len(c)
+    # the reference's answer is 27 bytes (libzstd finds the two runs: kat.json "pyvbz_readme"); this encoder's run sequences -- the 251
+    # zero bytes and the 999 twos of the 1 250-byte stream are two sequences behind two literals -- need 25, on either launch path
+    assert c[:4].view("<u4")[0] == 2000 and len(c) <= 27, len(c)
     assert (vbz.decompress(c, np.int16) == sig).all()
 
 
@@ -1050,6 +1081,63 @@ def test_fast5_bulk_repacker(tmp_path):
     back = fast5.compress_fast5(src + ".v1", ".gz", decompress=True)
     again = fast5.list_fast5(back)
     assert [(r["name"], r["filters"], r["fnv1a64"]) for r in again] == [(r["name"], [1], r["fnv1a64"]) for r in before]
+
+
+@pytest.mark.gpu
+def test_fast5_repacker_pipelines_many_files(tmp_path):
+    """The reference's users convert many files side by side (README.md:36-40 `xargs -P 10 ... h5repack`, fast5vbz.py:72-75 one file
+    after the other).  `vbz_fast5_repack a b c` is a pipeline: file k + 1 is copied, read and inflated and file k - 1 stored while the
+    GPU codes file k.  Three copies of the reference's test file in one call: every read's samples survive (sha256 pinned by the golden
+    index), every chunk is a sized VBZ buffer the reference path decodes -- the same bytes whichever position the file had --, the
+    names come back in input order, and three files take less than twice the time of one."""
+    import hashlib
+    import shutil
+    import time
+
+    from vbz_compression_amd import fast5
+
+    idx = {e["read"]: e for e in json.load(open(os.path.join(GOLDEN, "fast5_chunks.json")))}
+    files = []
+    for i in range(4):
+        f = str(tmp_path / ("reads%d.fast5" % i))
+        shutil.copy(os.path.join(GOLDEN, "multi_fast5_zip.fast5"), f)
+        files.append(f)
+    try:
+        fast5.file_samples(files[:1])
+    except fast5.Hdf5NotFound:
+        pytest.skip("no libhdf5 >= 1.10.3 on this box")
+    fast5.compress_many(files[3:], ".warm", vbz_version=1)      # (the first call of a process pays for the page-in of the libraries)
+    t0 = time.perf_counter()
+    one = fast5.compress_many(files[:1], ".one", vbz_version=1)
+    t1 = time.perf_counter()
+    three = fast5.compress_many(files[:3], ".vbz", vbz_version=1)
+    t2 = time.perf_counter()
+    assert one == [files[0] + ".one"] and three == [f + ".vbz" for f in files[:3]]
+    print("one file %.0f ms, three files %.0f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3))
+    assert (t2 - t1) < 2.0 * (t1 - t0), (t1 - t0, t2 - t1)
+    oo = O.options(True, 2, 1, 1)
+    first = None
+    for out in three:
+        listing = fast5.list_fast5(out, export_chunks=str(tmp_path / "chunks"), export_signal=str(tmp_path / "sig"))
+        assert len(listing) == 10 and all(r["filters"] == [32020] for r in listing)
+        chunks = np.fromfile(str(tmp_path / "chunks"), np.uint8)
+        sig = np.fromfile(str(tmp_path / "sig"), np.int16)
+        cp = sp = 0
+        digest = hashlib.sha256(chunks.tobytes()).hexdigest()
+        first = first or digest
+        assert digest == first                                    # the same chunks in every copy
+        for r in listing:
+            a = sig[sp : sp + r["samples"]]
+            sp += r["samples"]
+            assert hashlib.sha256(a.tobytes()).hexdigest() == idx[r["name"]]["raw_sha256"]
+            chunk = chunks[cp : cp + r["chunk_bytes"]]
+            cp += r["chunk_bytes"]
+            back = O.decompress(chunk, a.nbytes, oo, sized=True)   # the reference path reads what was written
+            assert not isinstance(back, int) and back.tobytes() == a.tobytes()
+    # ... and back to gzip, three files in one call
+    back = fast5.compress_many(three, ".gz", decompress=True)
+    for b, out in zip(back, three):
+        assert [(r["name"], r["filters"], r["fnv1a64"]) for r in fast5.list_fast5(b)] == [(r["name"], [1], r["fnv1a64"]) for r in fast5.list_fast5(out)]
 
 
 @pytest.mark.gpu

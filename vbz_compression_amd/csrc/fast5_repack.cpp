@@ -11,8 +11,15 @@
 // stored with deflate alone are read and written raw as well and (de)flated by a pool of threads, not one by one
 // inside libhdf5.
 //
-//   vbz_fast5_repack [-d] [-s SUFFIX] [--vbz-version N] FILE...      (fast5vbz.py:58-75)
+//   vbz_fast5_repack [-d] [-s SUFFIX] [--vbz-version N] [--device D] FILE...      (fast5vbz.py:58-75)
 //   vbz_fast5_repack --list FILE [--export-signal OUT] [--export-chunks OUT]
+//   vbz_fast5_repack --samples FILE...          (one line per file: name, reads, samples -- what a work queue deals files by)
+//
+// Several files are a PIPELINE (the reference's users run many files side by side: README.md:36-40 `xargs -P 10`): while the GPU
+// codes file k, a loader thread copies, reads and inflates file k + 1 and a writer thread stores file k - 1 -- the codec is a few
+// milliseconds of a file's 100+, the rest is libhdf5 and zlib on the host.  libhdf5 is not thread-safe in its usual builds: every
+// call into it is made under one mutex, whichever thread makes it.  Several GPUs: one process per device over a share of the file
+// list (python -m vbz_compression_amd.fast5 --gpus N deals the files by their sample counts).
 //
 // libhdf5 (>= 1.10.3, for the direct chunk calls) is loaded at run time: --hdf5-lib PATH, $VBZ_HDF5_LIB, or the
 // usual names.  Its few entry points used here are declared below with their public 1.10 signatures.
@@ -27,6 +34,9 @@
 #include <cstring>
 #include <filesystem>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -87,6 +97,13 @@ struct Hdf5
     herr_t (*H5Zregister)(const void*);
     hid_t dataset_create_class = 0;  // H5P_DATASET_CREATE
 };
+
+// libhdf5's usual builds are not thread-safe: whichever thread calls into it holds this mutex
+std::mutex& g_h5()
+{
+    static std::mutex m;
+    return m;
+}
 
 const int H5D_CHUNKED = 2, H5T_INTEGER = 0, H5Z_FILTER_DEFLATE = 1;
 const unsigned H5F_ACC_RDONLY = 0, H5F_ACC_RDWR = 1, H5Z_FLAG_OPTIONAL = 1;
@@ -302,6 +319,7 @@ bool inflate_chunks(const Hdf5& h, hid_t file, std::vector<Read>& reads, Timers&
         r.gz = false;
         if (good[k]) continue;
         const std::string path = r.name + "/Raw/Signal";
+        std::lock_guard<std::mutex> lock(g_h5());
         const hid_t d = h.H5Dopen2(file, path.c_str(), 0);
         const hid_t ty = d >= 0 ? h.H5Dget_type(d) : -1;
         r.signal.resize(r.samples * r.elem);
@@ -319,9 +337,13 @@ bool inflate_chunks(const Hdf5& h, hid_t file, std::vector<Read>& reads, Timers&
 struct Gpu
 {
     vbz_gpu_ctx* ctx = nullptr;
+    int device = 0;
     bool init()
     {
-        if (!ctx) ctx = vbz_gpu_create(0, nullptr);
+        if (!ctx) {
+            (void)hipSetDevice(device);   // (the tool's own hipMalloc / hipMemcpy calls go to the context's device)
+            ctx = vbz_gpu_create(device, nullptr);
+        }
         if (!ctx) fprintf(stderr, "vbz_fast5_repack: no usable MI355X (gfx950) device\n");
         return ctx != nullptr;
     }
@@ -451,35 +473,61 @@ bool decode_chunks(Gpu& g, std::vector<Read>& reads, Timers& t)
     return true;
 }
 
-// ---- the two commands -----------------------------------------------------------------------------------
-// mirrors compress_fast5(filename, output_suffix, vbz_version, decompress) of fast5vbz.py:17-55
-bool compress_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const std::string& suffix, unsigned vbz_version, bool decompress)
+// ---- the commands ----------------------------------------------------------------------------------------
+// (every call into libhdf5 is made under g_h5(): see its definition)
+
+// One file on its way through the three stages of compress_fast5(filename, output_suffix, vbz_version, decompress)
+// (fast5vbz.py:17-55): load (copy the file, read every read's stored chunk or samples, inflate) -> code (the GPU: decode stored vbz
+// chunks, code the new ones; or gzip on the host's cores) -> store (the datasets deleted and created again, the chunks written as
+// they are).
+struct Job
+{
+    std::string in_name, out_name;
+    hid_t file = -1;
+    std::vector<Read> reads;
+    std::vector<std::vector<uint8_t>> packed;
+    Timers t;
+    double t_start = 0;
+    bool ok = false;
+};
+
+bool job_load(const Hdf5& h, Job& j, const std::string& filename, const std::string& suffix)
 {
     namespace fs = std::filesystem;
-    Timers t;
-    const double t_all = now_ms();
+    j.t_start = now_ms();
     std::error_code ec;
-    const std::string in_name = fs::absolute(filename, ec).string(), out_name = in_name + suffix;
-    fs::copy_file(in_name, out_name, fs::copy_options::overwrite_existing, ec);
+    j.in_name = fs::absolute(filename, ec).string();
+    j.out_name = j.in_name + suffix;
+    fs::copy_file(j.in_name, j.out_name, fs::copy_options::overwrite_existing, ec);
     if (ec) {
-        fprintf(stderr, "vbz_fast5_repack: cannot copy %s: %s\n", in_name.c_str(), ec.message().c_str());
+        fprintf(stderr, "vbz_fast5_repack: cannot copy %s: %s\n", j.in_name.c_str(), ec.message().c_str());
         return false;
     }
-    fs::permissions(out_name, fs::perms::owner_write, fs::perm_options::add, ec);
-    const hid_t file = h.H5Fopen(out_name.c_str(), H5F_ACC_RDWR, 0);
-    if (file < 0) {
-        fprintf(stderr, "vbz_fast5_repack: cannot open %s\n", out_name.c_str());
-        return false;
+    fs::permissions(j.out_name, fs::perms::owner_write, fs::perm_options::add, ec);
+    {
+        std::lock_guard<std::mutex> lock(g_h5());
+        j.file = h.H5Fopen(j.out_name.c_str(), H5F_ACC_RDWR, 0);
+        if (j.file < 0) {
+            fprintf(stderr, "vbz_fast5_repack: cannot open %s\n", j.out_name.c_str());
+            return false;
+        }
+        for (const std::string& name : read_groups(h, j.file)) {
+            Read r;
+            r.name = name;
+            if (load_read(h, j.file, r, j.t)) j.reads.push_back(std::move(r));
+        }
     }
-    std::vector<Read> reads;
-    for (const std::string& name : read_groups(h, file)) {
-        Read r;
-        r.name = name;
-        if (load_read(h, file, r, t)) reads.push_back(std::move(r));
-    }
-    bool ok = inflate_chunks(h, file, reads, t) && decode_chunks(g, reads, t);
+    return inflate_chunks(h, j.file, j.reads, j.t);   // (zlib on a pool of threads; its fall-back into libhdf5 takes the mutex itself)
+}
+
+bool job_code(Gpu& g, Job& j, unsigned vbz_version, bool decompress)
+{
+    std::vector<Read>& reads = j.reads;
+    Timers& t = j.t;
+    bool ok = decode_chunks(g, reads, t);
     // the new chunks: 2-byte (here: elem-byte) integers with zig-zag, level 1 zstd (fast5vbz.py:33-36)
-    std::vector<std::vector<uint8_t>> packed(reads.size());
+    j.packed.assign(reads.size(), std::vector<uint8_t>());
+    std::vector<std::vector<uint8_t>>& packed = j.packed;
     if (ok && !decompress) {
         std::vector<bool> done(reads.size(), false);
         for (size_t a = 0; ok && a < reads.size(); ++a) {
@@ -514,6 +562,17 @@ bool compress_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const st
         for (char gk : good) ok = ok && gk;
         t.zlib += now_ms() - t0;
     }
+    return ok;
+}
+
+bool job_store(const Hdf5& h, Job& j, unsigned vbz_version, bool decompress, bool coded)
+{
+    std::lock_guard<std::mutex> lock(g_h5());
+    const hid_t file = j.file;
+    std::vector<Read>& reads = j.reads;
+    std::vector<std::vector<uint8_t>>& packed = j.packed;
+    Timers& t = j.t;
+    bool ok = coded;
     uint64_t raw_bytes = 0, new_bytes = 0;
     for (size_t k = 0; ok && k < reads.size(); ++k) {
         const Read& r = reads[k];
@@ -554,16 +613,119 @@ bool compress_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const st
         t.h5_write += now_ms() - t0;
         if (!ok) fprintf(stderr, "vbz_fast5_repack: cannot rewrite %s\n", path.c_str());
     }
-    ok = h.H5Fclose(file) >= 0 && ok;
+    if (file >= 0) ok = h.H5Fclose(file) >= 0 && ok;
+    j.file = -1;
     if (ok) {
-        printf("%s\n", out_name.c_str());  // fast5vbz.py:60-64
+        printf("%s\n", j.out_name.c_str());  // fast5vbz.py:60-64
+        fflush(stdout);
         fprintf(stderr,
                 "vbz_fast5_repack: %zu reads, %llu raw bytes -> %llu stored; hdf5 read %.1f ms, gzip on the host %.1f ms, "
-                "host<->device %.1f ms, codec %.1f ms, hdf5 write %.1f ms, total %.1f ms\n",
+                "host<->device %.1f ms, codec %.1f ms, hdf5 write %.1f ms, in the pipeline %.1f ms\n",
                 reads.size(), (unsigned long long)raw_bytes, (unsigned long long)new_bytes, t.h5_read, t.zlib, t.copies, t.gpu, t.h5_write,
-                now_ms() - t_all);
+                now_ms() - j.t_start);
     }
     return ok;
+}
+
+// a bounded hand-over between two stages
+template <typename T>
+struct Channel
+{
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<T> q;
+    size_t cap;
+    bool closed = false;
+    explicit Channel(size_t c) : cap(c) {}
+    void put(T v)
+    {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return q.size() < cap; });
+        q.push_back(std::move(v));
+        cv.notify_all();
+    }
+    bool get(T& v)
+    {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        v = std::move(q.front());
+        q.pop_front();
+        cv.notify_all();
+        return true;
+    }
+    void close()
+    {
+        std::lock_guard<std::mutex> lock(m);
+        closed = true;
+        cv.notify_all();
+    }
+};
+
+// every file through load -> code -> store, the three stages on threads of their own (one file in each at any time, one more
+// waiting between them); results in the order of the command line, like the reference's loop (fast5vbz.py:72-75)
+int repack_files(const Hdf5& h, Gpu& g, const std::vector<std::string>& files, const std::string& suffix, unsigned vbz_version, bool decompress)
+{
+    Channel<Job*> loaded(1), coded(1);
+    std::atomic<int> failed{ 0 };
+    const double t0 = now_ms();
+    std::thread loader([&] {
+        for (const std::string& f : files) {
+            Job* j = new Job();
+            j->ok = job_load(h, *j, f, suffix);
+            loaded.put(j);
+        }
+        loaded.close();
+    });
+    std::thread writer([&] {
+        Job* j;
+        while (coded.get(j)) {
+            if (!job_store(h, *j, vbz_version, decompress, j->ok)) failed++;
+            if (j->file >= 0) {   // (a job that failed before the store stage still holds its file)
+                std::lock_guard<std::mutex> lock(g_h5());
+                h.H5Fclose(j->file);
+            }
+            delete j;
+        }
+    });
+    Job* j;
+    while (loaded.get(j)) {
+        if (j->ok) j->ok = job_code(g, *j, vbz_version, decompress);
+        coded.put(j);
+    }
+    coded.close();
+    loader.join();
+    writer.join();
+    if (files.size() > 1)
+        fprintf(stderr, "vbz_fast5_repack: %zu files in %.1f ms (%d failed)\n", files.size(), now_ms() - t0, failed.load());
+    return failed.load() ? 1 : 0;
+}
+
+// one line per file: name, read_* groups with a signal, samples in all (dataset extents only: nothing is read or decoded)
+bool count_samples(const Hdf5& h, const std::string& filename)
+{
+    const hid_t file = h.H5Fopen(filename.c_str(), H5F_ACC_RDONLY, 0);
+    if (file < 0) {
+        fprintf(stderr, "vbz_fast5_repack: cannot open %s\n", filename.c_str());
+        return false;
+    }
+    uint64_t reads = 0, samples = 0;
+    for (const std::string& name : read_groups(h, file)) {
+        const std::string raw = name + "/Raw", path = raw + "/Signal";
+        if (h.H5Lexists(file, raw.c_str(), 0) <= 0 || h.H5Lexists(file, path.c_str(), 0) <= 0) continue;
+        const hid_t d = h.H5Dopen2(file, path.c_str(), 0);
+        if (d < 0) continue;
+        const hid_t sp = h.H5Dget_space(d);
+        if (sp >= 0) {
+            ++reads;
+            samples += (uint64_t)h.H5Sget_simple_extent_npoints(sp);
+            h.H5Sclose(sp);
+        }
+        h.H5Dclose(d);
+    }
+    h.H5Fclose(file);
+    printf("%s\t%llu\t%llu\n", filename.c_str(), (unsigned long long)reads, (unsigned long long)samples);
+    return true;
 }
 
 // one line per read: name, samples, bytes per sample, filter ids, stored bytes, FNV-1a-64 of the samples
@@ -601,8 +763,10 @@ bool list_fast5(const Hdf5& h, Gpu& g, const std::string& filename, const char* 
 void usage()
 {
     fprintf(stderr,
-            "usage: vbz_fast5_repack [-d] [-s SUFFIX] [--vbz-version N] [--hdf5-lib PATH] FILE...\n"
+            "usage: vbz_fast5_repack [-d] [-s SUFFIX] [--vbz-version N] [--device D] [--hdf5-lib PATH] FILE...\n"
             "       vbz_fast5_repack --list FILE [--export-signal OUT] [--export-chunks OUT] [--hdf5-lib PATH]\n"
+            "       vbz_fast5_repack --samples FILE...      (name, reads, samples of every file; no GPU needed)\n"
+            "  --device D            the GPU to use (default 0, or $VBZ_HIP_DEVICE)\n"
             "  -d, --decompress      store the signal with gzip level 1 instead of vbz\n"
             "  -s, --output-suffix   appended to the name of the copy that is rewritten (default .tmp)\n"
             "  --vbz-version N       0 or 1 (default 1)\n");
@@ -612,7 +776,8 @@ void usage()
 
 int main(int argc, char** argv)
 {
-    bool decompress = false, list = false;
+    bool decompress = false, list = false, samples = false;
+    int device = getenv("VBZ_HIP_DEVICE") ? atoi(getenv("VBZ_HIP_DEVICE")) : 0;
     std::string suffix = ".tmp";
     unsigned vbz_version = 1;
     const char *hdf5_lib = nullptr, *export_signal = nullptr, *export_chunks = nullptr;
@@ -625,6 +790,8 @@ int main(int argc, char** argv)
         else if (a == "--vbz-version") { const char* v = value(); if (!v) { usage(); return 2; } vbz_version = (unsigned)atoi(v); }
         else if (a == "--hdf5-lib") hdf5_lib = value();
         else if (a == "--list") list = true;
+        else if (a == "--samples") samples = true;
+        else if (a == "--device") { const char* v = value(); if (!v) { usage(); return 2; } device = atoi(v); }
         else if (a == "--export-signal") export_signal = value();
         else if (a == "--export-chunks") export_chunks = value();
         else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -638,10 +805,14 @@ int main(int argc, char** argv)
     }
     Hdf5 h;
     if (!load_hdf5(h, hdf5_lib)) return 3;
+    if (samples) {
+        int rc = 0;
+        for (const std::string& f : files)
+            if (!count_samples(h, f)) rc = 1;
+        return rc;
+    }
     Gpu g;
+    g.device = device;
     if (list) return list_fast5(h, g, files[0], export_signal, export_chunks) ? 0 : 1;
-    int rc = 0;
-    for (const std::string& f : files)
-        if (!compress_fast5(h, g, f, suffix, vbz_version, decompress)) rc = 1;
-    return rc;
+    return repack_files(h, g, files, suffix, vbz_version, decompress);
 }

@@ -7,13 +7,16 @@ in one batched call on the GPU and the finished chunks are stored with H5Dwrite_
 (a copy of the file named filename + output_suffix whose signal datasets are one vbz chunk each, or gzip level 1
 with decompress=True); nothing here falls back to a CPU codec.
 
-    python -m vbz_compression_amd.fast5 [-d] [-s SUFFIX] [--vbz-version N] FILE...
+    python -m vbz_compression_amd.fast5 [-d] [-s SUFFIX] [--vbz-version N] [--gpus N] FILE...
+
+Several files are a pipeline inside the tool (load | code | store on threads of their own) and, with --gpus N, one such process per
+device over a share of the file list dealt by sample counts (compress_many).
 """
 import argparse
 import os
 import subprocess
 
-__version__ = "0.1.1"
+__version__ = "0.2.0"
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOOL = os.path.join(HERE, "bin", "vbz_fast5_repack")
@@ -49,6 +52,55 @@ def compress_fast5(filename, output_suffix, vbz_version=0, decompress=False, hdf
     return out.stdout.strip().splitlines()[-1]
 
 
+def file_samples(filenames, hdf5_lib=None):
+    """[(reads, samples)] of every file: the read_*/Raw/Signal datasets' extents, nothing read or decoded (no GPU needed)."""
+    cmd = [_tool(), "--samples"] + (["--hdf5-lib", hdf5_lib] if hdf5_lib else []) + list(filenames)
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, universal_newlines=True)
+    if out.returncode != 0:
+        _fail("vbz_fast5_repack --samples", filenames[0], out.returncode)
+    rows = [ln.rsplit("\t", 2) for ln in out.stdout.splitlines()]
+    assert [r[0] for r in rows] == list(filenames)
+    return [(int(r[1]), int(r[2])) for r in rows]
+
+
+def deal_files(samples, gpus):
+    """Contiguous shares of the file list for `gpus` devices, balanced by cumulative SAMPLES (the work queue of shard.py:
+    files hold reads of very different lengths, so neither the file count nor the read count balances).  Returns a list of
+    (first, last_exclusive) per device."""
+    from . import shard
+
+    return shard.partition_reads(samples, gpus)
+
+
+def compress_many(filenames, output_suffix, vbz_version=0, decompress=False, gpus=1, hdf5_lib=None):
+    """compress_fast5 for a list of files, the way the reference's users run it (README.md:36-40: many files side by side): one
+    process of the native tool per GPU, each over its share of the list, each a pipeline -- the next file is read and inflated and
+    the previous one stored while the GPU codes the current one.  Returns the names of the rewritten copies, in input order."""
+    filenames = list(filenames)
+    if not filenames:
+        return []
+    gpus = max(1, min(int(gpus), len(filenames)))
+    shares = [(0, len(filenames))] if gpus == 1 else deal_files([s for _, s in file_samples(filenames, hdf5_lib)], gpus)
+    base = [_tool(), "-s", output_suffix, "--vbz-version", str(int(vbz_version))] + (["-d"] if decompress else []) + (["--hdf5-lib", hdf5_lib] if hdf5_lib else [])
+    procs = []
+    for device, (a, b) in enumerate(shares):
+        if b > a:
+            procs.append((a, b, subprocess.Popen(base + ["--device", str(device)] + filenames[a:b], stdout=subprocess.PIPE, universal_newlines=True)))
+    names = [None] * len(filenames)
+    failed = None
+    for a, b, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = failed or (filenames[a], p.returncode)
+            continue
+        got = out.strip().splitlines()
+        assert len(got) == b - a, (got, filenames[a:b])
+        names[a:b] = got
+    if failed:
+        _fail("vbz_fast5_repack", *failed)
+    return names
+
+
 def list_fast5(filename, export_signal=None, export_chunks=None, hdf5_lib=None):
     """The read_*/Raw/Signal datasets of a file: dicts with name, samples, integer size, filter ids, stored bytes
     and the FNV-1a-64 of the samples (vbz datasets are decoded on the GPU)."""
@@ -79,9 +131,10 @@ def main(args=None):
     parser.add_argument("-v", "--version", action="version", version=__version__)
     parser.add_argument("--vbz-version", type=int, default=1)
     parser.add_argument("--hdf5-lib", default=None, help="libhdf5 shared object to load (default: search)")
+    parser.add_argument("--gpus", type=int, default=1, help="deal the files over this many GPUs (one process each), by their sample counts")
     a = parser.parse_args(args)
-    for filename in a.files:
-        print(compress_fast5(filename, a.output_suffix, a.vbz_version, a.decompress, a.hdf5_lib))
+    for name in compress_many(a.files, a.output_suffix, a.vbz_version, a.decompress, a.gpus, a.hdf5_lib):
+        print(name)
 
 
 if __name__ == "__main__":
