@@ -491,10 +491,10 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
     // pay (the walk is a launch of its own whose duration is one chain's latency, ~0.7 ms: measured break-even 2 500 such frames).
     // Records of walked chains: 16 bytes per sequence, claimed from one workspace of the call as the lanes go (an atomic counter; a frame
     // that finds no room is decoded as before).  libzstd on nanopore signal writes ~1 100 sequences per 126 KB of content -- records of
-    // 14 % of the content's size --: the workspace is a quarter of the declared content + 1 MiB, at most 256 MiB (the declared size
-    // is the caller's word, and the buffer stays with the context: ADVICE round 4).
+    // 14 % of the content's size --: the workspace is a quarter of the declared content + 1 MiB, at most 1 GiB (the declared size
+    // is the caller's word, and the buffer stays with the context: ADVICE round 4; 16 384 reads of 100 k samples need 290 MB).
     const bool walk = c->ref_chains >= 2 || (c->ref_chains == 1 && n >= REF_MIN_READS);
-    const uint64_t recs_bytes = walk ? std::min<uint64_t>(((content_bytes >> 2) + (1ull << 20)) & ~15ull, 256ull << 20) : 0;
+    const uint64_t recs_bytes = walk ? std::min<uint64_t>(((content_bytes >> 2) + (1ull << 20)) & ~15ull, 1ull << 30) : 0;
     if (walk && (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
         return -1;
     if (walk && !c->side.stream && !dbg) {
