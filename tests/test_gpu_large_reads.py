@@ -87,7 +87,7 @@ def test_span_index_is_verified_not_trusted():
     body, tr = _trailers(g)
     assert tr and int(tr[0][:4].view("<u4")[0]) == IDX_MAGIC
     idx = tr[0]
-    ns = int(idx[8:12].view("<u4")[0])
+    ns = int(idx[8:12].view("<u4")[0]) & 0x7FFFFFFF   # (bit 31: spans that begin with a treeless block)
     assert ns >= 6 and len(idx) == 16 + 8 * ns
     rng = np.random.default_rng(4)
     variants = [g, np.ascontiguousarray(g[: len(g) - len(idx)])]
@@ -123,6 +123,102 @@ def test_span_index_is_verified_not_trusted():
         else:
             assert not isinstance(gq, int), hex(gq)
             assert gq.tobytes() == a.tobytes()
+
+
+def _blocks(body, start):
+    """[(offset, block type, literals type or None, size)] of the frame's blocks from `start` on"""
+    out, pos = [], start
+    while True:
+        h = int(body[pos]) | int(body[pos + 1]) << 8 | int(body[pos + 2]) << 16
+        bt, size = (h >> 1) & 3, h >> 3
+        out.append((pos, bt, int(body[pos + 3]) & 3 if bt == 2 else None, size))
+        pos += 3 + (1 if bt == 1 else size)
+        if h & 1:
+            return out, pos
+
+
+def test_shared_tables_one_tree_for_the_data_bytes():
+    """The data bytes of a large read are packed with ONE table (zstd_encode.hip, SpanRegion): their first span's block carries
+    the tree description, every later span is one treeless block, and the index says so (bit 31 of the span count).  The
+    decoder gives every such span the block with the tree and decodes the frame span by span -- no second launch
+    (vbz_gpu_decode_span_paths) --; libzstd reads the frame; VBZ_HIP_SHARED_TABLES=0 writes round 4's frames (a tree per span), which
+    decode the same way."""
+    c = G.codec()
+    a = O.synth_signal(5, 21, 300_000)
+    o = (True, 2, 1, 1)
+    go, oo = _lib.CompressionOptions(*o), O.options(*o)
+    g = G.compress([a], go)[0]
+    body, tr = _trailers(g)
+    idx = tr[0]
+    word = int(idx[8:12].view("<u4")[0])
+    ns = word & 0x7FFFFFFF
+    assert word >> 31 == 1 and len(idx) == 16 + 8 * ns
+    starts = [int(idx[12 + 8 * j : 16 + 8 * j].view("<u4")[0]) for j in range(ns)]
+    content = [int(idx[16 + 8 * j : 20 + 8 * j].view("<u4")[0]) for j in range(ns)]
+    blocks, end = _blocks(body, starts[0])
+    assert end == len(body)
+    K = (a.size + 3) // 4                                   # the control bytes come first
+    first_data = content.index(K)
+    at = {b[0]: b for b in blocks}
+    assert at[starts[first_data]][2] == 2                   # Compressed_Literals_Block: the tree
+    later = [at[starts[j]] for j in range(first_data + 1, ns)]
+    assert len(later) >= 30 and all(b[1] == 2 and b[2] == 3 for b in later), "treeless blocks behind the span with the tree"
+    assert all(content[j + 1] - content[j] <= 8192 for j in range(first_data, ns - 1))
+    assert O.decompress(g, a.nbytes, oo).tobytes() == a.tobytes()
+    assert G.decompress([g], [a.nbytes], go)[0].tobytes() == a.tobytes()
+    assert c.decode_span_paths() == (1, 1), "decoded span by span"
+    # round 4's frames: the same entry points read them
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, oracle_lib as O, gpu_util as G\nfrom vbz_compression_amd import _lib\n"
+            "a = O.synth_signal(5, 21, 300000)\ng = G.compress([a], _lib.CompressionOptions(True, 2, 1, 1))[0]\n"
+            "sys.stdout.buffer.write(g.tobytes())" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__))))
+    old = np.frombuffer(subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VBZ_HIP_SHARED_TABLES="0"), capture_output=True, check=True).stdout, np.uint8)
+    body_o, tr_o = _trailers(old)
+    assert int(tr_o[0][8:12].view("<u4")[0]) >> 31 == 0
+    assert abs(len(old) - len(g)) < 0.004 * len(g), (len(old), len(g))     # the ratio is what it was
+    assert G.decompress([old], [a.nbytes], go)[0].tobytes() == a.tobytes()
+    assert c.decode_span_paths() == (1, 1)
+
+
+def test_inherited_trees_are_verified_not_trusted():
+    """What a treeless span decodes with is the tree of an EARLIER block, which the decoder's plan picks from the index (the last span
+    whose first block brings a tree) -- a claim like every other in the index.  Frames whose index or blocks make that claim false
+    (the flag without treeless spans, no flag with them, a span boundary moved into the treeless run, the tree span's entry
+    dropped) still decode to what libzstd says, or are refused where libzstd refuses."""
+    a = O.synth_signal(5, 22, 260_000)
+    o = (True, 2, 1, 1)
+    go, oo = _lib.CompressionOptions(*o), O.options(*o)
+    g = G.compress([a], go)[0]
+    body, tr = _trailers(g)
+    idx = tr[0]
+    base = len(g) - len(idx)
+    ns = int(idx[8:12].view("<u4")[0]) & 0x7FFFFFFF
+    content = [int(idx[16 + 8 * j : 20 + 8 * j].view("<u4")[0]) for j in range(ns)]
+    first_data = content.index((a.size + 3) // 4)
+    variants = []
+    d = g.copy()                                            # no flag: the treeless spans fail, the frame goes to the second launch
+    d[base + 8 : base + 12] = np.array([ns], "<u4").view(np.uint8)
+    variants.append(d)
+    for drop in (first_data, first_data + 1, first_data + 5, ns - 1):     # an index without one of its entries
+        ent = np.delete(idx[12 : 12 + 8 * ns].view("<u4").reshape(ns, 2), drop, axis=0)
+        tb = 16 + 8 * (ns - 1)
+        t = np.concatenate([np.array([IDX_MAGIC, tb - 8, (ns - 1) | 0x80000000], "<u4"), ent.reshape(-1), np.array([tb], "<u4")]).view(np.uint8)
+        variants.append(np.concatenate([g[:base], t]))
+    d = g.copy()                                            # the tree span's block made treeless: no tree anywhere for the data bytes
+    starts = [int(idx[12 + 8 * j : 16 + 8 * j].view("<u4")[0]) for j in range(ns)]
+    d[starts[first_data] + 3] |= 1
+    variants.append(d)
+    d = g.copy()                                            # a later treeless block claims a tree of its own (garbage for a description)
+    d[starts[first_data + 3] + 3] &= 0xFE
+    variants.append(d)
+    got = G.decompress(variants, [a.nbytes] * len(variants), go)
+    for k, (v, gq) in enumerate(zip(variants, got)):
+        lz = O.decompress(v, a.nbytes, oo)
+        if isinstance(lz, int):
+            assert isinstance(gq, int), (k, gq if isinstance(gq, int) else "data", lz)
+        else:
+            assert not isinstance(gq, int), (k, hex(gq))
+            assert gq.tobytes() == lz.tobytes() == a.tobytes(), k
 
 
 def test_large_reads_in_one_batch_with_errors():
@@ -241,7 +337,7 @@ def test_last_block_flag_inside_a_large_frame():
     g = G.compress([a], go)[0]
     body, tr = _trailers(g)
     idx = [t for t in tr if int(t[:4].view("<u4")[0]) == IDX_MAGIC][0]
-    ns = int(idx[8:12].view("<u4")[0])
+    ns = int(idx[8:12].view("<u4")[0]) & 0x7FFFFFFF   # (bit 31: spans that begin with a treeless block)
     starts = [int(idx[12 + 8 * j : 16 + 8 * j].view("<u4")[0]) for j in range(ns)]
     # walk the blocks of the frame (3-byte headers: last | type << 1 | size << 3; an RLE block holds one byte)
     pos, blocks = starts[0], []

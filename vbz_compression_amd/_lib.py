@@ -83,6 +83,7 @@ GPU_API = [
     "vbz_gpu_profile_read",
     "vbz_gpu_profile_reset",
     "vbz_gpu_decode_paths",
+    "vbz_gpu_decode_span_paths",
     "vbz_gpu_version",
 ]
 
@@ -153,6 +154,9 @@ def load():
     L.vbz_gpu_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     L.vbz_gpu_decode_paths.restype = ctypes.c_int
     L.vbz_gpu_decode_paths.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    if hasattr(L, "vbz_gpu_decode_span_paths"):   # (tools/ab_libs.py, tools/compare_libs.py load builds of earlier rounds through VBZ_HIP_LIB)
+        L.vbz_gpu_decode_span_paths.restype = ctypes.c_int
+        L.vbz_gpu_decode_span_paths.argtypes = [vp, ctypes.POINTER(u32)]
     L.vbz_gpu_version.restype = ctypes.c_char_p
     L.vbz_gpu_version.argtypes = []
     _lib = L

@@ -184,6 +184,14 @@ class GpuCodec:
             raise RuntimeError("vbz_gpu_decode_paths failed")
         return n, int(b.value), int(w.value)
 
+    def decode_span_paths(self):
+        """(frames, by_spans) of the last decompress launch group on the large-read path: include/vbz_gpu.h, vbz_gpu_decode_span_paths."""
+        b = ctypes.c_uint32(0)
+        n = self.L.vbz_gpu_decode_span_paths(self.ctx, ctypes.byref(b))
+        if n < 0:
+            raise RuntimeError("vbz_gpu_decode_span_paths failed")
+        return n, int(b.value)
+
     def synchronize(self):
         self._rc(self.L.vbz_gpu_synchronize(self.ctx), "synchronize")
 

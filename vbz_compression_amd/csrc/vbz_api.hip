@@ -67,6 +67,7 @@ struct vbz_gpu_ctx
     DevBuf vgate;     // verdicts on the caller's descriptor table (one word per read)
     DevBuf encplan;   // per-read plans of the staged encoder (tables of both regions: zstd_encode.hip STAGE 1 / 2)
     bool staged_encode = true;  // VBZ_HIP_STAGED_ENCODE=0: the fused encoder kernel for every read
+    bool shared_tables = true;  // VBZ_HIP_SHARED_TABLES=0: large-read path, every span of the data bytes with a table of its own (round 4's frames)
     DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
     bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
     DevBuf refpre, reftab, refrecs;  // frames the reference wrote: per-frame hand-over, tables (large batches), records (zstd_decode_ref.hip)
@@ -75,6 +76,8 @@ struct vbz_gpu_ctx
     FastSide side;             // the walk's own stream (beside the launches for this library's frames)
     bool last_walked = false;
     uint32_t last_frames = 0;  // vbz_gpu_decode_paths: the frames of the last zstd_frames call (0: none, or not on the batched path)
+    uint32_t last_span_frames = 0;          // ... of the last call on the large-read path, and its redo[] (in spanmeta)
+    const uint32_t* last_span_redo = nullptr;
     bool trailers = true;      // decoder hints (checkpoints, span index) in skippable frames behind the zstd frame
     int segmented = -1;  // -1: by batch shape; 0 / 1: forced (VBZ_HIP_SEGMENTED, for tests)
     bool zero_run_sequences = true;
@@ -281,6 +284,27 @@ constexpr uint64_t SEGMENTED_MIN_AVG = 512u << 10;
 // so short that a read is hardly more than one span.
 constexpr uint64_t SMALL_BATCH_MIN_AVG = 64u << 10, SMALL_BATCH_MAX_BYTES = 96u << 20;
 
+// The context's second stream (the chain walk beside the launches for own frames; the shared-table spans beside the control-byte
+// spans): all three objects or none -- a context must never keep a stream without its events.
+bool ensure_side(vbz_gpu_ctx* c)
+{
+    if (c->side.stream) return true;
+    FastSide side;
+    const bool ok = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) == hipSuccess &&
+                    hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) == hipSuccess &&
+                    hipEventCreateWithFlags(&side.join, hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        const char* why = hipGetErrorString(hipGetLastError());
+        if (side.join) (void)hipEventDestroy(side.join);
+        if (side.fork) (void)hipEventDestroy(side.fork);
+        if (side.stream) (void)hipStreamDestroy(side.stream);
+        set_error(c, "second stream: %s", why);
+        return false;
+    }
+    c->side = side;
+    return true;
+}
+
 bool use_segments(const vbz_gpu_ctx* c, uint64_t raw_arena_bytes, uint32_t n)
 {
     if (c->segmented >= 0) return c->segmented != 0;
@@ -426,8 +450,16 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         }
         const uint64_t tmp_bytes = zstd_span_tmp_bytes(scratch_need, n, max_spans);
         if (!ensure(c, c->spantmp, tmp_bytes)) return -1;
-        if (!ensure(c, c->spanmeta, (size_t)max_spans * (zstd_span_desc_bytes() + 12) + ((size_t)n + 2) * 4 + 256)) return -1;
+        // Shared tables (zstd_encode.hip, SpanRegion): the data bytes of a read get ONE table, built beside the control-byte spans, and are
+        // packed in spans of 8 KB by a launch of their own.  For calls that are a matter of latency (zstd_span_shared_bytes) and for 8 / 16-bit
+        // elements, whose control bytes are mostly zero and cheap to code: 0.176 -> 0.140 ms per call for a 100 k-sample read.  The
+        // control-byte spans of 32-bit elements take as long as the table construction itself (a 40 MB buffer: 100 us in the first launch,
+        // + 15 us counting + 34 us packing against 125 us for everything in one launch) -- they keep a table per span.
+        const uint32_t shspan = (c->shared_tables && (o->integer_size == 1 || o->integer_size == 2)) ? zstd_span_shared_bytes(scratch_need) : 0u;
+        const bool shared = shspan != 0;
+        if (!ensure(c, c->spanmeta, (size_t)max_spans * (zstd_span_desc_bytes() + 12) + ((size_t)n + 2) * 4 + 256 + (shared ? zstd_span_region_bytes(n) + 64 : 0))) return -1;
         MetaCarver sm(c->spanmeta.p);
+        uint8_t* regions = shared ? sm.take<uint8_t>(zstd_span_region_bytes(n)) : nullptr;
         uint8_t* desc = sm.take<uint8_t>((size_t)max_spans * zstd_span_desc_bytes());
         uint32_t* span_first = sm.take<uint32_t>((size_t)n + 1);
         uint32_t* span_count = sm.take<uint32_t>(1);
@@ -451,7 +483,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         Timed t(c, "zstd_encode");
         HIPCHK(c, launch_zstd_encode_spans(z, bt->src_size, o->integer_size, hdr, c->zero_run_sequences ? svb_cap : nullptr,
                                            c->zero_run_sequences ? c->seqtab.p : nullptr, desc, span_first, span_count, max_spans,
-                                           (uint8_t*)c->spantmp.p, tmp_bytes, span_size, span_trail, span_dst, c->trailers, s),
+                                           (uint8_t*)c->spantmp.p, tmp_bytes, span_size, span_trail, span_dst, c->trailers, regions, shspan, s),
                "zstd_encode (spans) launch");
         return 0;
     }
@@ -497,22 +529,7 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
     const uint64_t recs_bytes = walk ? std::min<uint64_t>(((content_bytes >> 2) + (1ull << 20)) & ~15ull, 1ull << 30) : 0;
     if (walk && (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
         return -1;
-    if (walk && !c->side.stream && !dbg) {
-        // all three or none: a context must never keep a stream without its events
-        FastSide side;
-        const bool ok = hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) == hipSuccess &&
-                        hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) == hipSuccess &&
-                        hipEventCreateWithFlags(&side.join, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {
-            const char* why = hipGetErrorString(hipGetLastError());
-            if (side.join) (void)hipEventDestroy(side.join);
-            if (side.fork) (void)hipEventDestroy(side.fork);
-            if (side.stream) (void)hipStreamDestroy(side.stream);
-            set_error(c, "second stream for the chain walk: %s", why);
-            return -1;
-        }
-        c->side = side;
-    }
+    if (walk && !dbg && !ensure_side(c)) return -1;
     HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, walk ? c->refpre.p : nullptr, c->reftab.p, c->refrecs.p,
                                       recs_bytes / 16, dbg, c->side, s),
            "zstd_decode (batched) launch");
@@ -608,7 +625,11 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
         Timed t(c, "zstd_decode");
         HIPCHK(c, launch_zstd_decode_spans(z, E_STREAM, c->seqdtab.p, desc, dspan_first, dspan_count, max_spans, dspan_status, redo, s),
                "zstd_decode (spans) launch");
+        c->last_frames = 0;
+        c->last_span_frames = n;
+        c->last_span_redo = redo;
     } else {
+        c->last_span_frames = 0;
         // a frame whose content cannot be a valid svb stream of the expected size: the reference would
         // decode it and then fail in the svb stage with a stream error
         if (zstd_frames(c, z, E_STREAM, dst_bytes, dbg) != 0) return -1;
@@ -830,6 +851,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_FAST_DECODE")) c->fast_decode = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_REF_CHAINS")) c->ref_chains = atoi(e);
     if (const char* e = getenv("VBZ_HIP_STAGED_ENCODE")) c->staged_encode = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_SHARED_TABLES")) c->shared_tables = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
@@ -1040,6 +1062,21 @@ void vbz_gpu_profile_enable(vbz_gpu_ctx* c, int enable)
     if (!c) return;
     if (!enable) drain_profile(c);
     c->profiling = enable != 0;
+}
+
+int vbz_gpu_decode_span_paths(vbz_gpu_ctx* c, uint32_t* by_spans)
+{
+    if (!c) return -1;
+    DeviceGuard guard(c->device);
+    if (by_spans) *by_spans = 0;
+    if (c->last_span_frames == 0) return 0;
+    std::vector<uint32_t> redo(c->last_span_frames);
+    if (hipMemcpyAsync(redo.data(), c->last_span_redo, 4ull * redo.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    uint32_t nb = 0;
+    for (uint32_t v : redo) nb += v == 0;
+    if (by_spans) *by_spans = nb;
+    return (int)c->last_span_frames;
 }
 
 int vbz_gpu_decode_paths(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)

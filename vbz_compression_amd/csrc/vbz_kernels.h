@@ -117,6 +117,14 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
 size_t zstd_encode_plan_bytes(uint32_t n_reads);
 size_t seq_tables_bytes();
 void seq_tables_build(void* host_buffer);
+// A second stream and two events for launches that run beside the main chain (the chain walk beside the launches for own frames, the
+// shared-table spans beside the control-byte spans); stream == nullptr: none
+struct SideStream
+{
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+typedef SideStream FastSide;
 // The same stage for batches of few, large reads: one wavefront per SPAN of a read's stream (see zstd_encode.hip).
 // stream_bytes bounds the total of the source streams.  span_desc: max_spans x zstd_span_desc_bytes(); span_first[n_reads + 1];
 // span_count[1]; span_size / span_trail / span_dst [max_spans]; span_tmp: zstd_span_tmp_bytes(...) bytes.
@@ -126,7 +134,14 @@ uint64_t zstd_span_tmp_bytes(uint64_t stream_bytes, uint32_t n_reads, uint32_t m
 hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
                                     const void* seq_tables, void* span_desc, uint32_t* span_first, uint32_t* span_count, uint32_t max_spans,
                                     uint8_t* span_tmp, uint64_t span_tmp_bytes, uint32_t* span_size, uint32_t* span_trail, uint32_t* span_dst,
-                                    bool trailers, hipStream_t s);  // trailers: checkpoints and span index behind the frame
+                                    bool trailers, void* shared_regions, uint32_t shared_span_bytes, hipStream_t s);  // trailers: checkpoints and span index behind the frame
+// shared_regions (nullable: every span builds its own table): zstd_span_region_bytes(n_reads) bytes of device scratch, 16-byte aligned -- the
+// data bytes of a read with a control-byte region get ONE table (counted and built by extra wavefronts of the launch that codes the
+// control-byte spans) and are packed one wavefront per 8 KB span by the launch behind it.
+// shared_span_bytes: zstd_span_shared_bytes(the call's stream bytes) -- 0 (pass shared_regions = nullptr then): a batch of large buffers,
+// a matter of throughput, where every span builds its own table in one launch.
+size_t zstd_span_region_bytes(uint32_t n_reads);
+uint32_t zstd_span_shared_bytes(uint64_t stream_bytes);
 // The long-repeat matcher in front of the span launches (batches too small to fill the device run as spans): a probe over
 // every read below max_raw bytes, the check of launch_zstd_encode's first launch, and its matcher instantiation for the reads
 // whose distance holds.  deep_d[n_reads] is scratch; gate_out[i] = GATE_SKIP for the reads coded here (the spans skip them),
@@ -183,11 +198,6 @@ hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, c
 // launch_zstd_decode.  meta: zstd_fast_meta_bytes(n_reads) bytes of device scratch.
 // ref_*: scratch of launch_zstd_ref_chain (ref_pre == nullptr: frames of other writers go to the one-wavefront decoder as they are).
 // dbg (nullable): phase cycle counters of the one-wavefront decoder, which then decodes EVERY frame (walked chains included).
-struct FastSide  // a second stream (and two events) on which the chain walk runs beside the launches for own frames; stream == nullptr: none
-{
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-};
 size_t zstd_fast_meta_bytes(uint32_t n_reads);
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads);  // after the call: redo[i] == 0 <=> frame i was decoded by the batched decoder
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,

@@ -1488,8 +1488,17 @@ struct DecSpan
     uint32_t dst_pos;   // content offset of the span's first byte
     uint32_t flags;     // DSPAN_*
     uint32_t ord;       // ordinal of the span in its frame
+    uint32_t tree_pos;  // != 0: the block (offset in the read's source) whose Huffman tree is in force where this span begins
+    uint32_t pad;
 };
 constexpr uint32_t DSPAN_WHOLE = 1, DSPAN_LAST = 2, DSPAN_FIRST = 4;
+// Shared tables (zstd_encode.hip, round 5): the data bytes of a large read are spans of ONE block each, the first with the region's tree
+// description, the others treeless.  The plan kernel looks at the first block of every span (does it bring a tree?) and gives the
+// spans behind the LAST such span T that block as tree_pos: a span with a tree_pos reads that tree before its own first block.  Like
+// the index itself this is verified, not trusted -- every span reports whether its first block brought a tree and whether a later
+// block did (status word 3: DSPAN_ST_*), and a frame stands only if T brought its tree in its first block and nowhere else, and no
+// span behind T brought any: then the table in force at every span behind T is T's, by the frame's own rules.
+constexpr uint32_t DSPAN_ST_REP1 = 1, DSPAN_ST_TREE_FIRST = 2, DSPAN_ST_TREE_LATER = 4;
 constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;      // zstd_encode.hip: the span index trailer
 constexpr uint32_t DSPAN_MIN_CONTENT = 8u << 10;    // an honest index has at most fcs / this + 4 spans (spans are cut evenly, none below 16 KB)
 // A span whose block carries zero-run sequences stages its literals and (literal, match) length pairs behind the frame's
@@ -1507,11 +1516,14 @@ struct SvbFuse
     const uint64_t* out_off;
     const uint32_t* out_size;   // exact decoded byte count of every read
 };
-template <bool TIMED, bool FUSED>
+// SPANS: the span-mode instantiation (dspans != nullptr; the other one carries none of its code: the ordinary decoder's register
+// allocation is not the spans' business)
+template <bool TIMED, bool FUSED, bool SPANS = false>
 __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBatch b, uint32_t toosmall_code, unsigned long long* dbg, const SeqDTables* dtabs,
-                                                                      const DecSpan* dspans, const uint32_t* dspan_count, uint32_t* dspan_status,
+                                                                      const DecSpan* dspans_, const uint32_t* dspan_count, uint32_t* dspan_status,
                                                                       const uint32_t* only, SvbFuse fuse, RefChains chains)
 {
+    const DecSpan* const dspans = SPANS ? dspans_ : nullptr;
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
@@ -1522,7 +1534,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         sp = dspans[blockIdx.x];
     }
     // partial: this wave decodes one span of the frame and reports to dspan_status instead of the read's result
-    const bool partial = dspans != nullptr && !(sp.flags & DSPAN_WHOLE);
+    const bool partial = SPANS && dspans != nullptr && !(sp.flags & DSPAN_WHOLE);
     const uint32_t r = dspans ? sp.read : blockIdx.x;
     if (only && !only[r]) return;  // second launch of span mode: only the frames whose spans did not work out
     if (b.gate && b.gate[r] >= GATE_SKIP) {
@@ -1654,6 +1666,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     const uint32_t first_opos = partial ? sp.dst_pos : 0u;
     uint32_t opos = 0, ntask = 0;
     uint32_t rep0_end = 1;  // repeat offset 1 when the span is done (lane 0)
+    uint32_t tree_info = 0; // span mode: DSPAN_ST_TREE_*
     for (int attempt = 0;; ++attempt) {
     if (partial && attempt != 0) FAIL();  // a frame that needs the careful second attempt is not decoded in spans
     // attempt 0 lets the stream decoders' rings reuse the LDS of FSE tables that are (normally) dead; if a later
@@ -1673,6 +1686,11 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
     uint32_t d_opos = 0, d_regen = 0, d_nseq = 0, d_ltype = 0, d_pairs = 0;
     const uint8_t* d_lit = nullptr;
     int cur_slot = 0, cur_log = 0;      // current Huffman table: slot and table log
+    tree_info = 0;
+    // a span that begins under another block's tree (see DSPAN_ST_*) takes one trip through the block loop at that block first, up
+    // to the point where its table stands, and starts over at its own first block
+    bool tree_only = SPANS && partial && sp.tree_pos != 0;
+    if (tree_only) pos = sp.tree_pos;
     bool have_ll = false, have_of = false, have_ml = false;
     int log_ll = 0, log_of = 0, log_ml = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;  // lane 0 only
@@ -1707,7 +1725,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         const uint32_t bh = (uint32_t)H0 & 0xFFFFFFu;
         pos += 3;
         const uint32_t last = bh & 1, btype = (bh >> 1) & 3, bsize = bh >> 3;
-        if (btype == 3) FAIL();
+        if (btype == 3 || (SPANS && tree_only && btype != 2)) FAIL();
         pf_ok = false;
         if (!last) {
             const uint64_t nextpos = (uint64_t)pos + (btype == 1 ? 1u : bsize);
@@ -1830,6 +1848,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     tlog = L.ctl[C_H];
                 }
                 if (used_tree < 0) FAIL();
+                if (SPANS && !tree_only) tree_info |= (pos - 3u == first_block) ? DSPAN_ST_TREE_FIRST : DSPAN_ST_TREE_LATER;
                 tree_used = (uint32_t)used_tree;
                 // new Huffman table: pick the slot not used by the current table; pending tasks that
                 // still reference the slot we are about to overwrite must run first
@@ -1846,6 +1865,13 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 cur_slot = slot;
                 cur_log = (int)tlog;
                 PHASE(5);
+            }
+            if (SPANS && tree_only) {   // the table stands (or the block has no tree: not what the index promised)
+                if (ltype != 2) FAIL();
+                tree_only = false;
+                pos = first_block;
+                pf_ok = false;
+                continue;
             }
             uint32_t nseq = SQB(0), sq_used = 1;
             const bool has_seq = nseq != 0;
@@ -2392,7 +2418,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         if (lane == 0) {
             dspan_status[4 * blockIdx.x + 1] = pos;
             dspan_status[4 * blockIdx.x + 2] = opos;
-            dspan_status[4 * blockIdx.x + 3] = rep0_end;
+            dspan_status[4 * blockIdx.x + 3] = (rep0_end == 1 ? DSPAN_ST_REP1 : 0u) | tree_info;
             dspan_status[4 * blockIdx.x] = 1;
         }
         return;
@@ -2415,7 +2441,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
         if (lane == 0) {
             dspan_status[4 * blockIdx.x + 1] = pos;
             dspan_status[4 * blockIdx.x + 2] = opos;
-            dspan_status[4 * blockIdx.x + 3] = rep0_end;
+            dspan_status[4 * blockIdx.x + 3] = (rep0_end == 1 ? DSPAN_ST_REP1 : 0u) | tree_info;
             dspan_status[4 * blockIdx.x] = 1;
         }
         return;
@@ -2448,6 +2474,7 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
     __shared__ uint32_t wcnt[16];
     __shared__ uint32_t carry_c, limit_s;
     __shared__ uint32_t q_ns[1024], q_tb[1024], q_ok[1024], q_first[1024], q_hl[1024], q_fcs[1024];
+    __shared__ uint32_t q_T[1024];   // 1 + the last span of the read whose first block brings a Huffman tree (0: none)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) {
         carry_c = 0;
@@ -2460,6 +2487,7 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
         // (1) one thread per read: frame header (single segment, no dictionary, no checksum: what zstd_encode.hip writes)
         // and the envelope of the index trailer
         q_ok[tid] = 0;
+        q_T[tid] = 0;
         if (i < b.n_reads) {
             const uint32_t n = b.src_size[i];
             const bool gated = (b.gate && b.gate[i] >= GATE_SKIP) || n >= E_FIRST;
@@ -2478,7 +2506,7 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                     hl = 5 + fsz;
                     ok = fcs <= b.dst_cap[i] && fcs < 0xFFFFFFF0ull;
                 }
-                uint32_t tb = 0, ns = 0;
+                uint32_t tb = 0, ns = 0, treeless = 0;
                 if (ok) {
                     __builtin_memcpy(&tb, src + n - 4, 4);
                     ok = tb >= 32 && (tb & 7u) == 0 && (uint64_t)tb + hl + 8 <= n;
@@ -2486,10 +2514,12 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                 if (ok) {
                     uint32_t m[3];
                     __builtin_memcpy(m, src + n - tb, 12);
-                    ns = m[2];
+                    ns = m[2] & 0x7FFFFFFFu;
+                    treeless = m[2] >> 31;   // the writer's hint that spans lean on earlier trees (a wrong hint costs time, nothing else)
                     ok = m[0] == IDX_MAGIC && m[1] == tb - 8 && ns >= 2 && tb == 16 + 8 * ns && ns <= fcs / DSPAN_MIN_CONTENT + 4;
                 }
                 q_ok[tid] = ok ? 1u : 0u;
+                q_T[tid] = treeless ? 0x80000000u : 0u;
                 q_ns[tid] = ns;
                 q_tb[tid] = tb;
                 q_hl[tid] = hl;
@@ -2511,6 +2541,11 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                 bool ok = j == 0 ? (v[0] == q_hl[q] && v[1] == 0) : (v[0] > pv[0] && v[1] > pv[1]);
                 ok = ok && (uint64_t)v[0] + 3 <= n - tb && v[1] < q_fcs[q];
                 bad |= !ok;
+                if (ok && (q_T[q] & 0x80000000u)) {   // does the span's first block bring a tree?  (compressed block, Compressed_Literals_Block)
+                    uint32_t h4;
+                    __builtin_memcpy(&h4, b.src + b.src_off[base + q] + v[0], 4);   // (the fourth byte: inside the frame or its trailer)
+                    if (((h4 >> 1) & 3u) == 2u && ((h4 >> 24) & 3u) == 2u) atomicMax(&q_T[q], 0x80000000u | (j + 1));
+                }
             }
             if (bad) q_ok[q] = 0;  // (racing stores of the same value)
         }
@@ -2559,6 +2594,10 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                 d.dst_pos = v[1];
                 d.flags = (j == 0 ? DSPAN_FIRST : 0u) | (j + 1 == ns ? DSPAN_LAST : 0u);
                 d.ord = j;
+                d.tree_pos = 0;
+                d.pad = 0;
+                const uint32_t T1 = q_T[q] & 0x7FFFFFFFu;
+                if (T1 != 0 && j + 1 > T1) __builtin_memcpy(&d.tree_pos, e + 8 * (T1 - 1), 4);   // (never 0: behind the frame header)
                 spans[si + j] = d;
                 dspan_status[4 * (si + j)] = 0;
             }
@@ -2592,11 +2631,19 @@ __global__ __launch_bounds__(256) void zstd_dspan_finish_kernel(ReadBatch b, con
         return;
     }
     bool bad = false;
+    const uint32_t tree_pos = spans[s1 - 1].tree_pos;   // (the last span has one iff any span has)
     for (uint32_t k = s0 + tid; k < s1; k += 256) {
         bool ok = dspan_status[4 * k] == 1;
+        const uint32_t st3 = dspan_status[4 * k + 3];
         // the span ended where the next one starts, and left repeat offset 1 at 1 (what a later zero-run span assumed)
         if (ok && k + 1 < s1)
-            ok = dspan_status[4 * k + 1] == spans[k + 1].src_pos && dspan_status[4 * k + 2] == spans[k + 1].dst_pos && dspan_status[4 * k + 3] == 1;
+            ok = dspan_status[4 * k + 1] == spans[k + 1].src_pos && dspan_status[4 * k + 2] == spans[k + 1].dst_pos && (st3 & DSPAN_ST_REP1) != 0;
+        // the tree the spans behind T were given is the one in force there: T brought it in its first block and nothing after it brought another
+        if (ok && tree_pos) {
+            const uint32_t trees = st3 & (DSPAN_ST_TREE_FIRST | DSPAN_ST_TREE_LATER);
+            if (spans[k].src_pos == tree_pos) ok = trees == DSPAN_ST_TREE_FIRST;
+            else if (spans[k].src_pos > tree_pos) ok = trees == 0;
+        }
         bad |= !ok;
     }
     if (bad) bad_s = 1;
@@ -2674,7 +2721,7 @@ hipError_t launch_zstd_decode_spans(const ReadBatch& b, uint32_t toosmall_code, 
     const SeqDTables* dt = reinterpret_cast<const SeqDTables*>(seq_dtables);
     hipLaunchKernelGGL(zstd_dspan_plan_kernel, dim3(1), dim3(1024), 0, s, b, max_spans, spans, dspan_first, dspan_count, dspan_status);
     const SvbFuse none = { nullptr, nullptr, nullptr };
-    hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, spans, dspan_count, dspan_status,
+    hipLaunchKernelGGL((zstd_decode_kernel<false, false, true>), dim3(max_spans), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, spans, dspan_count, dspan_status,
                        nullptr, none, RefChains());
     hipLaunchKernelGGL(zstd_dspan_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, spans, dspan_first, max_spans, dspan_status, redo);
     hipLaunchKernelGGL((zstd_decode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, toosmall_code, nullptr, dt, nullptr, nullptr, nullptr, redo, none, RefChains());

@@ -89,6 +89,41 @@ struct EncSpan
     uint32_t ord;        // ordinal of the span in its frame
 };
 constexpr uint32_t SPAN_FIRST = 1, SPAN_LAST = 2, SPAN_KEYSEQ = 4, SPAN_SKIP = 8;
+constexpr uint32_t SPAN_SHARED = 16;   // a span of the data bytes that is packed with the table of the read's whole data-byte region
+constexpr uint32_t SPAN_TREE = 32;     // ... and carries that table's description (the first of them)
+
+// Shared tables (round 5).  A lone wavefront needs ~25 us to build a Huffman table and ~15 us to pack 8 KB with it; with a table per
+// 32 KB span the table construction was the larger part of the 0.12 ms the entropy stage took for ONE large read.  The data bytes of a
+// read with a control-byte region now get one table for the whole region.  The launch that codes the control-byte spans (which keep
+// a table each: their literals are known only after the tokeniser) has one more wavefront per read in the TABLE ROLE: it builds the
+// table of the read's data bytes with region_plan, as for any region, from the histogram zstd_span_count_kernel has left -- so the
+// table construction (60 us for a lone wavefront and 256 symbols) runs beside the control-byte spans, not in front of them.
+// zstd_span_pack_kernel then packs the data bytes in spans of SHSPAN_BYTES,
+// one block each, the first with the tree description, the others treeless.  The decoder gives every treeless span the block with
+// the tree (zstd_decode.hip: DecSpan::tree_pos) and verifies that it was the one in force.
+// Whether a call uses them is the host's choice (zstd_span_shared_bytes): yes, with spans of 8 KB, one block, while the call's spans fit
+// the device at once -- there the longest wavefront is the call's latency --; no beyond: a batch of large buffers is a matter of
+// throughput, where three launches one after the other lose against one launch in which every span builds its own table (measured:
+// eight 40 MB buffers per call, zstd_encode 0.38 -> 0.49 ms with shared tables and spans of 32 KB; profiles/r05_experiments.md).
+constexpr uint32_t SHSPAN_BYTES = 8u << 10, SHSPAN_BATCH_FROM = 64u << 20;   // (of the bound on the call's stream bytes)
+constexpr uint32_t SHSPAN_BYTES_LARGE = 4u * SPAN_BLOCK;  // reads of SPAN_LARGE_FROM bytes of stream and more
+constexpr uint32_t SHSPAN_MIN_REGION = 2u * SHSPAN_BYTES;
+
+// per read: the data-byte region's histogram, the ticket of the workgroups that count it, its table
+struct SpanRegion
+{
+    uint32_t hist[256];     // (the first SPANREGION_ZEROED words are zeroed by zstd_span_plan_kernel)
+    uint32_t done;          // (unused)
+    uint32_t nshared;       // shared spans of the read (0: none -- the read's spans bring their own tables)
+    uint32_t mode;          // 0 raw, 1 rle, 2 huffman (region_plan's verdict on the whole region)
+    uint32_t treeSize, huffLog;
+    uint32_t pad0[3];
+    uint32_t ctable[256];   // code | length << 16
+    uint32_t tree[34];
+    uint32_t pad1[2];
+};
+constexpr uint32_t SPANREGION_ZEROED = 264;
+static_assert(sizeof(SpanRegion) % 16 == 0 && offsetof(SpanRegion, ctable) == 4 * SPANREGION_ZEROED, "SpanRegion");
 
 struct EncLds
 {
@@ -1228,14 +1263,148 @@ __device__ __forceinline__ uint32_t span_tmp_bytes(uint32_t S, bool keyseq)
     return (b + 15u) & ~15u;
 }
 
+// a shared-table span's slot holds the worst case of its table: 11 bits per byte (+ tree description, block headers, jump tables)
+__device__ __forceinline__ uint32_t shspan_tmp_bytes(uint32_t S) { return (((S * 11u + 7u) >> 3) + 512u + 32u * ((S + SPAN_BLOCK - 1) / SPAN_BLOCK) + 15u) & ~15u; }
+
 // per read: how its stream is cut.  keyN = spans of the control-byte region, dataN = of the rest.
-__device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN, uint32_t& dataN)
+// shspan: the launch has the shared-table kernels, and this is their span size (0: none); shared (out): this read's data spans use them
+__device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t shspan, uint32_t& keyN, uint32_t& dataN, bool& shared)
 {
-    const uint32_t SB = span_bytes_for(N);
-    keyN = K == 0 ? 0u : (K + keyspan_bytes_for(K) - 1) / keyspan_bytes_for(K);
     const uint32_t D = N - K;
+    shared = shspan != 0 && K != 0 && D >= SHSPAN_MIN_REGION;
+    const uint32_t SB = shared ? (N >= SPAN_LARGE_FROM ? SHSPAN_BYTES_LARGE : shspan) : span_bytes_for(N);
+    // (with shared tables the call is a matter of latency, whatever the length of the control-byte region: short spans)
+    const uint32_t KB = shspan != 0 ? KEYSPAN_BYTES : keyspan_bytes_for(K);
+    keyN = K == 0 ? 0u : (K + KB - 1) / KB;
     dataN = D ? (D + SB - 1) / SB : 0u;
     if (N == 0) dataN = 1;  // the empty frame
+}
+
+// ---- shared tables: the table role of zstd_encode_kernel (see SpanRegion) -----------------------------------------------------------
+struct SpanShared
+{
+    SpanRegion* regions;     // nullptr: no shared tables in this launch
+    uint32_t first_block;    // workgroups from this one on are in the table role
+    uint32_t shspan;         // the span size the plan was made with
+};
+
+// the bytes [p, p + n) into hist (LDS atomics); the requests of up to 8 KB are in flight together
+__device__ __forceinline__ void span_count_bytes(uint32_t* hist, const uint8_t* p, uint32_t n, int lane)
+{
+    uint32_t head = (uint32_t)(-(intptr_t)p) & 15u;
+    head = head < n ? head : n;
+    const uint32_t nch = (n - head) >> 4, tail0 = head + 16u * nch;
+    if ((uint32_t)lane < head) atomicAdd(&hist[p[lane]], 1u);
+    if (tail0 + (uint32_t)lane < n) atomicAdd(&hist[p[tail0 + lane]], 1u);
+    for (uint32_t c0 = 0; c0 < nch; c0 += 8u * WAVE) {
+        uint4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t c = c0 + (uint32_t)lane + 64u * i;
+            v[i] = c < nch ? *reinterpret_cast<const uint4*>(p + head + 16u * c) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t c = c0 + (uint32_t)lane + 64u * i;
+            if (c < nch) {
+                const uint32_t w[4] = { v[i].x, v[i].y, v[i].z, v[i].w };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) atomicAdd(&hist[(w[q] >> (8 * j)) & 0xFFu], 1u);
+                }
+            }
+        }
+    }
+}
+
+// One workgroup per 4 * D consecutive spans (D = 1 for a single read ... 8 for a batch of large buffers: the fewer workgroups, the
+// fewer additions to the reads' histograms -- atomics on 256 words per read, which serialise).  Its four wavefronts count a span each,
+// D times, into LDS histograms of their own; the workgroup adds them up per read (nearly always ONE read) and adds the sum to the
+// read's histogram.
+__global__ __launch_bounds__(256) void zstd_span_count_kernel(ReadBatch b, const EncSpan* spans, const uint32_t* span_count, SpanRegion* regions)
+{
+    __shared__ uint32_t h[4][256];
+    __shared__ uint32_t rd[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t nsp = *span_count;
+    uint32_t D = nsp / 512u;
+    D = D < 1u ? 1u : (D > 8u ? 8u : D);
+    const uint32_t g0 = blockIdx.x * 4u * D;
+    if (g0 >= nsp) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j][tid] = 0;
+    if (tid < 4) rd[tid] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (uint32_t d = 0; d < D; ++d) {
+        // wavefront wv: span g0 + 4 d + wv
+        const uint32_t k = g0 + 4u * d + (uint32_t)wv;
+        EncSpan sp = {};
+        bool sh = false;
+        if (k < nsp) {
+            sp = spans[k];
+            sh = (sp.flags & (SPAN_SHARED | SPAN_SKIP)) == SPAN_SHARED;
+        }
+        const uint32_t mine = sh ? sp.read : 0xFFFFFFFFu;
+        if (mine != rd[wv]) {   // (wave-uniform) the wavefront moves on to another read: what it has counted so far goes out
+            if (rd[wv] != 0xFFFFFFFFu) {
+                wave_lds_sync();
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t v = h[wv][lane + 64 * j];
+                    h[wv][lane + 64 * j] = 0;
+                    if (v) atomicAdd(&regions[rd[wv]].hist[lane + 64 * j], v);
+                }
+            }
+            wave_lds_sync();
+            if (lane == 0) rd[wv] = mine;
+            wave_lds_sync();
+        }
+        if (sh) span_count_bytes(h[wv], b.src + b.src_off[sp.read] + sp.r0, sp.r1 - sp.r0, lane);
+    }
+    __syncthreads();
+    // the wavefronts that ended on the same read as the first are added up and go out together; the others one by one
+    const uint32_t r0 = rd[0];
+    uint32_t v = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (rd[j] == r0 && r0 != 0xFFFFFFFFu) v += h[j][tid];
+    if (v) atomicAdd(&regions[r0].hist[tid], v);
+    for (int j = 1; j < 4; ++j) {
+        if (rd[j] == r0 || rd[j] == 0xFFFFFFFFu) continue;
+        const uint32_t u = h[j][tid];
+        if (u) atomicAdd(&regions[rd[j]].hist[tid], u);
+    }
+}
+
+// the table role of zstd_encode_kernel<.., TABLES>: one wavefront per read builds the table of its data bytes from the count
+__device__ __forceinline__ void span_table_role(EncLds& L, SpanRegion* R, int lane)
+{
+    const uint32_t ns = R->nshared;
+    if (ns == 0) return;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t c = R->hist[lane + 64 * j];
+        L.hist[lane + 64 * j] = c;
+        mine += c;
+    }
+    const uint32_t D = wave_sum_u32(mine);   // the bytes of the region
+    wave_lds_sync();
+    const uint32_t per = (D + ns - 1) / ns;
+    region_plan(L, D, D, ns * ((per + SPAN_BLOCK - 1) / SPAN_BLOCK), lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint2 e = L.ctable[lane + 64 * j];
+        R->ctable[lane + 64 * j] = e.x | (e.y << 16);
+    }
+    if (lane < 34) R->tree[lane] = reinterpret_cast<const uint32_t*>(L.tree)[lane];
+    if (lane == 0) {
+        R->mode = L.mode;
+        R->treeSize = (uint32_t)L.treeSize;
+        R->huffLog = L.huffLog;
+    }
 }
 
 #ifndef VBZ_ENC_PACK_WAVES
@@ -1255,14 +1424,20 @@ __device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t& keyN,
 // takes the tokeniser's result from the read's plan, because that step works in place.
 // (EncRegionPlan / EncPlan: vbz_kernels.h -- the svb encoder fills part of them)
 
-template <bool TIMED, bool DEEP>
+// TABLES: the span-mode instantiation with the shared tables' role (extra wavefronts behind the spans': see SpanRegion)
+template <bool TIMED, bool DEEP, bool TABLES = false>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem,
                                                            const uint32_t* key_bytes, uint32_t hdr, unsigned long long* dbg,
                                                            const uint32_t* src_cap, const SeqCTables* seqtab, const EncSpan* spans,
                                                            const uint32_t* span_count, uint8_t* span_tmp, uint32_t* span_size,
-                                                           uint32_t* span_trail, uint32_t trailers, uint32_t* deep_d, EncPlan* plans, uint32_t* redo)
+                                                           uint32_t* span_trail, uint32_t trailers, uint32_t* deep_d, EncPlan* plans, uint32_t* redo,
+                                                           SpanShared shared)
 {
     __shared__ __attribute__((aligned(16))) EncLds L;
+    if (TABLES && shared.regions && blockIdx.x >= shared.first_block) {   // span mode, shared tables: the wavefronts behind the spans' build the tables
+        span_table_role(L, shared.regions + (blockIdx.x - shared.first_block), threadIdx.x);
+        return;
+    }
     unsigned long long tph[PHASE_SLOTS] = {};
     unsigned long long tlast = TIMED ? __builtin_readcyclecounter() : 0;
 #define PHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
@@ -1274,6 +1449,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     if (span_mode) {
         if (blockIdx.x >= *span_count) return;
         sp = spans[blockIdx.x];
+        if (sp.flags & SPAN_SHARED) return;  // zstd_span_pack_kernel's, in the next launch
         if (lane == 0) { span_size[blockIdx.x] = 0; span_trail[blockIdx.x] = 0; }
         if (sp.flags & SPAN_SKIP) return;  // the read failed earlier: zstd_span_finish_kernel reports it
     }
@@ -1420,7 +1596,8 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             // records of all control-byte spans of the frame live behind the stream, each span's at its own offset
             uint32_t keyN = 1, dataN = 0, ord = 0;
             if (span_mode) {
-                span_cut(N, K, keyN, dataN);
+                bool shared_;
+                span_cut(N, K, TABLES ? shared.shspan : 0u, keyN, dataN, shared_);   // (only keyN is wanted)
                 ord = sp.ord;
             }
             const uint32_t recs_all = (K ? K : N) / RMIN + 2u * keyN + 2u;  // (a frame without a control-byte region is tokenised as a whole)
@@ -2025,6 +2202,262 @@ struct PackLds
 // stream geometry, 2 the packing steps' table look-ups and prefix sum, 3 their bits into the LDS buffer, 4 the buffer's quads to
 // memory, 5 stream ends and block headers, 6 the sequences section moved into place, 7 trailer and result.
 // (dbg: the TIMED instantiation's counters -- an argument of the launch, nothing shared between contexts.  redo[] = pstate[].)
+// One region packed with one table, in frame order: blocks of S / nblk bytes, the tree description (treeSize != 0) in the first of them, the
+// others treeless.  out + opos is where the first block goes; the frame may grow to `limit`.  false: it does not fit (nothing of the
+// caller's state is touched then).  Used by zstd_pack_kernel (a read's two regions) and zstd_span_pack_kernel (a span of a large read).
+template <bool TIMED>
+__device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint32_t r0, uint8_t* out, uint32_t& opos, uint32_t limit, const uint32_t* ctable_g,
+                                            const uint32_t* tree_g, uint32_t S, uint32_t nblk, uint32_t treeSize, bool seqmode, bool lastRegion,
+                                            uint32_t seqBytes, uint32_t seqOff, int lane, unsigned long long (&tph)[PHASE_SLOTS], unsigned long long& tlast)
+{
+#define PPHASE(k) do { if (TIMED) { unsigned long long tn = __builtin_readcyclecounter(); tph[k] += tn - tlast; tlast = tn; } } while (0)
+#define REDO() return false
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L.ctable[lane + 64 * j] = ctable_g[lane + 64 * j];
+    if (lane < 34) L.tree[lane] = tree_g[lane];
+    const uint32_t base = S / nblk, extra = S % nblk;
+    {
+        const uint32_t bj = (uint32_t)(lane >> 2);   // this lane describes stream q of block bj
+        const int q = lane & 3;
+        const bool active = bj < nblk;
+        uint32_t bs = 0, boff = 0;
+        if (active) {
+            bs = base + (bj < extra ? 1u : 0u);
+            boff = bj * base + (bj < extra ? bj : extra);
+        }
+        const bool single = bs < 256;
+        const uint32_t seg = single ? bs : (bs + 3) >> 2;
+        uint32_t cnt = 0;
+        if (active) {
+            if (single) cnt = q == 0 ? bs : 0;
+            else cnt = q < 3 ? seg : bs - 3 * seg;
+        }
+        L.sbeg[lane] = active ? (cnt ? boff + (uint32_t)q * seg : boff + bs) : S;
+        L.scnt[lane] = cnt;
+        L.ssize[lane] = 0;
+    }
+    for (int i = lane; i < 2 * OBUF_WORDS; i += WAVE) (&L.obuf[0][0])[i] = 0;
+    wave_lds_sync();
+    const uint32_t nb = nblk;
+    uint32_t st = 0;
+    while (st < 4 * nb && L.scnt[st] == 0) ++st;
+    uint32_t done = 0;
+#if VBZ_PACK_PREFETCH
+    uint32_t cur[STEP_DW], nxt[STEP_DW];
+#else
+    uint32_t cur[STEP_DW];
+#endif
+    auto load_chunk = [&](uint32_t sbeg, uint32_t scount, uint32_t dn, uint32_t (&w)[STEP_DW]) {
+#pragma unroll
+        for (int k = 0; k < STEP_DW; ++k) w[k] = 0;
+        const int32_t room = (int32_t)(scount - dn) - STEP_LANE * lane;
+        if (room > 0) {
+            const uint8_t* p = rin + sbeg + room - STEP_LANE;  // may start before the stream: those bytes are masked when used
+            const bool headroom = (uint64_t)r0 + sbeg >= (uint32_t)STEP_LANE;  // ... but not before the input buffer
+            if (room >= STEP_LANE || headroom) {
+                uint4 v0;
+                __builtin_memcpy(&v0, p, 16);
+                w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < STEP_LANE; ++k) {
+                    const uint32_t byte = (room - STEP_LANE + k >= 0) ? (uint32_t)p[k] : 0u;
+                    w[k >> 2] |= byte << (8 * (k & 3));
+                }
+            }
+        }
+    };
+    auto blk_bs = [&](uint32_t j) { return base + (j < extra ? 1u : 0u); };
+    auto blk_lh = [&](uint32_t j) {
+        const uint32_t jbs = blk_bs(j);
+        const uint32_t worst = (j == 0 ? treeSize : 0u) + 6u + ((jbs * 11u + 7u) >> 3) + 4u;  // every code <= 11 bits
+        const uint32_t big = jbs > worst ? jbs : worst;
+        return 3u + (big >= 1024u ? 1u : 0u) + (big >= 16384u ? 1u : 0u);
+    };
+    auto block_headers = [&](uint32_t j, uint32_t at, uint32_t seqB) {
+        if (lane == 0) {
+            const uint32_t jbs = blk_bs(j);
+            const bool jsingle = jbs < 256u;
+            const uint32_t lh = blk_lh(j), tsz = j == 0 ? treeSize : 0u;
+            const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
+            const uint32_t lit = tsz + (jsingle ? 0u : 6u) + s0 + s1 + s2 + s3;
+            uint8_t* bp = out + at;
+            const uint32_t last = (lastRegion && j + 1 == nblk) ? 1u : 0u;
+            put_le(bp, ((lh + lit + seqB) << 3) | (2u << 1) | last, 3);
+            const uint64_t type = (j == 0 && treeSize) ? 2 : 3;  // Compressed_Literals_Block / Treeless
+            if (lh == 3) put_le(bp + 3, type | ((jsingle ? 0ull : 1ull) << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 14), 3);
+            else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 18), 4);
+            else put_le(bp + 3, type | (3ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 22), 5);
+            if (!jsingle) {
+                uint8_t* tp = bp + 3 + lh + tsz;
+                put_le(tp, s0, 2);
+                put_le(tp + 2, s1, 2);
+                put_le(tp + 4, s2, 2);
+            }
+        }
+    };
+    uint32_t ocur = opos;        // where the current block starts
+    uint32_t spos = 0;           // where the current stream starts
+    uint32_t curblk = 0xFFFFFFFFu;
+    if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
+    PPHASE(1);
+    uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
+    uint32_t flushed = 0;     // bytes of the stream already written to memory (or waiting in the other buffer for it)
+    uint32_t cb = 0;          // the buffer this step fills
+    uint32_t pend_fq = 0;     // quads of the step before that wait in the other buffer ...
+    uint8_t* pend_dst = nullptr;  // ... for this address
+    auto flush_pending = [&]() {
+        uint4* pq = reinterpret_cast<uint4*>(L.obuf[cb ^ 1u]);
+        for (uint32_t q = lane; q < pend_fq; q += WAVE) {
+            const uint4 v = pq[q];
+            pq[q] = make_uint4(0u, 0u, 0u, 0u);
+            __builtin_memcpy(pend_dst + 16u * q, &v, 16);
+        }
+        pend_fq = 0;
+    };
+    while (st < 4 * nb) {
+        if ((st >> 2) != curblk) {  // first stream of a block: reserve its headers, place the tree
+            curblk = st >> 2;
+            const uint32_t tsz = curblk == 0 ? treeSize : 0u;
+            const uint32_t hl = 3u + blk_lh(curblk) + tsz + (blk_bs(curblk) < 256u ? 0u : 6u);
+            if ((uint64_t)ocur + hl > limit) REDO();
+            for (uint32_t i = lane; i < tsz; i += WAVE) out[ocur + 3u + blk_lh(curblk) + i] = reinterpret_cast<const uint8_t*>(L.tree)[i];
+            spos = ocur + hl;
+        }
+        const uint32_t scnt = L.scnt[st];
+        uint8_t* sop = out + spos;
+        uint32_t nst = st, ndone = done + STEP_SYMS;
+        if (ndone >= scnt) {
+            ndone = 0;
+            ++nst;
+            while (nst < 4 * nb && L.scnt[nst] == 0) ++nst;
+        }
+        flush_pending();   // (the step before: its quads, in front of the request below)
+#if VBZ_PACK_PREFETCH
+        if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, nxt);
+#endif
+        const int32_t room = (int32_t)(scnt - done) - STEP_LANE * lane;
+        const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
+        uint32_t ent[STEP_LANE];   // code | length << 16 of the lane's symbols
+#pragma unroll
+        for (int k = 0; k < STEP_LANE; ++k) ent[k] = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
+        if (skip != 0) {  // only the last step of a stream has lanes in front of its start
+#pragma unroll
+            for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
+        }
+        uint32_t Tb = 0;  // bits of this lane's codes
+#pragma unroll
+        for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k] >> 16;
+        const uint32_t incl = wave_incl_scan_u32(Tb);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
+        const uint32_t fq = allbits >> 7;             // complete 16-byte quads
+        if ((uint64_t)spos + flushed + 16ull * fq + 24 > limit) REDO();
+        PPHASE(2);
+        {
+            const uint32_t pos = base_bits + incl - Tb;
+            uint32_t word = pos >> 5;
+            uint32_t accbits = pos & 31;
+            uint64_t acc = 0;
+#pragma unroll
+            for (int k = STEP_LANE - 1; k >= 0; k -= 2) {
+                // two symbols (at most 22 bits) per flush check: accbits < 32 before, < 54 after
+                const uint32_t e1 = ent[k], e0 = ent[k - 1];
+                const uint32_t l1 = e1 >> 16, l0 = e0 >> 16;
+                const uint64_t pair = (uint64_t)((e1 & 0xFFFFu) | ((e0 & 0xFFFFu) << l1));
+                acc |= pair << accbits;
+                accbits += l1 + l0;
+                if (accbits >= 32) {
+                    atomicOr(&L.obuf[cb][word], (uint32_t)acc);
+                    acc >>= 32;
+                    accbits -= 32;
+                    ++word;
+                }
+            }
+            if (acc) atomicOr(&L.obuf[cb][word], (uint32_t)acc);
+        }
+        wave_lds_sync();
+        PPHASE(3);
+        {   // complete quads wait in this buffer for the top of the next step; the rest moves to the front of the other buffer
+            uint4* obq = reinterpret_cast<uint4*>(L.obuf[cb]);
+            uint4* nbq = reinterpret_cast<uint4*>(L.obuf[cb ^ 1u]);   // (stored and cleared at the top of this step)
+            if (lane == 0) {
+                const uint4 c = obq[fq];
+                obq[fq] = make_uint4(0u, 0u, 0u, 0u);
+                nbq[0] = c;
+            }
+            pend_fq = fq;
+            pend_dst = sop + flushed;
+            cb ^= 1u;
+        }
+        flushed += 16u * fq;
+        base_bits = allbits & 127u;
+        wave_lds_sync();
+        PPHASE(4);
+        if (nst != st) {
+            // stream finished: end mark and the bits still in quad 0 (lane k writes byte k)
+            const uint32_t nbytes = (base_bits + 1 + 7) >> 3;  // <= 16
+            {
+                uint4* obq = reinterpret_cast<uint4*>(L.obuf[cb]);
+                const uint4 c = obq[0];
+                const uint32_t cw[4] = { c.x, c.y, c.z, c.w };
+                uint32_t mine = cw[(lane >> 2) & 3];
+                if ((uint32_t)(lane >> 2) == (base_bits >> 5)) mine |= 1u << (base_bits & 31u);
+                if ((uint32_t)lane < nbytes) sop[flushed + lane] = (uint8_t)(mine >> (8 * (lane & 3)));
+                wave_lds_sync();
+                if (lane == 0) {
+                    obq[0] = make_uint4(0u, 0u, 0u, 0u);
+                    L.ssize[st] = flushed + nbytes;
+                }
+            }
+            spos += flushed + nbytes;
+            base_bits = 0;
+            flushed = 0;
+            if ((nst >> 2) != curblk && !seqmode) {
+                // block finished: a plain block ends with Number_of_Sequences = 0; then the headers
+                wave_lds_sync();
+                if ((uint64_t)spos + 1 > limit) REDO();
+                if (lane == 0) out[spos] = 0;
+                block_headers(curblk, ocur, 1u);
+                ocur = spos + 1u;
+            }
+        }
+#if VBZ_PACK_PREFETCH
+#pragma unroll
+        for (int k = 0; k < STEP_DW; ++k) cur[k] = nxt[k];
+#else
+        if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, cur);
+#endif
+        st = nst;
+        done = ndone;
+        PPHASE(5);
+    }
+    flush_pending();
+    if (seqmode && curblk != 0xFFFFFFFFu) {
+        // the block with the run sequences: its sequences section, coded by the planning launch above the frame, moves behind
+        // the literals (upwards in memory never: the frame has stayed below it)
+        wave_lds_sync();
+        if ((uint64_t)spos + seqBytes > seqOff) REDO();
+        for (uint32_t i = 16u * (uint32_t)lane; i < seqBytes; i += 16u * WAVE) {
+            uint4 v;
+            __builtin_memcpy(&v, out + seqOff + i, 16);   // (reads up to 15 bytes past the section: inside the slot)
+            if (i + 16u <= seqBytes) __builtin_memcpy(out + spos + i, &v, 16);
+            else {
+                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+                for (uint32_t k = i; k < seqBytes; ++k) out[spos + k] = (uint8_t)(w[(k - i) >> 2] >> (8 * ((k - i) & 3)));
+            }
+        }
+        wave_lds_sync();
+        block_headers(curblk, ocur, seqBytes);
+        ocur = spos + seqBytes;
+    }
+    opos = ocur;
+    return true;
+#undef PPHASE
+#undef REDO
+}
+
 template <bool TIMED>
 __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(ReadBatch b, const uint32_t* orig_size, uint32_t key_elem, const uint32_t* key_bytes,
                                                                              uint32_t hdr, uint32_t trailers, const EncPlan* plans, uint32_t* redo,
@@ -2072,253 +2505,12 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
         if (region == 1 && K == 0) break;
         const uint32_t r0 = region == 0 ? 0u : K;
         const uint32_t r1 = region == 0 ? (K ? K : N) : N;
-        const bool lastRegion = r1 == N;
-        const uint8_t* rin = in + r0;
         const EncRegionPlan* P = &FP->reg[region];
-        const uint32_t S = P->S, nblk = P->nblk, Sh = P->Sh, treeSize = P->treeSize;
-        const bool seqmode = P->seqmode != 0;
+        const uint32_t S = P->S, Sh = P->Sh;
         const uint32_t opos_region = opos;
-        wave_lds_sync();
-#pragma unroll
-        for (int j = 0; j < 4; ++j) L.ctable[lane + 64 * j] = P->ctable[lane + 64 * j];
-        if (lane < 34) L.tree[lane] = P->tree[lane];
-        const uint32_t base = S / nblk, extra = S % nblk;
-        {
-            const uint32_t bj = (uint32_t)(lane >> 2);   // this lane describes stream q of block bj
-            const int q = lane & 3;
-            const bool active = bj < nblk;
-            uint32_t bs = 0, boff = 0;
-            if (active) {
-                bs = base + (bj < extra ? 1u : 0u);
-                boff = bj * base + (bj < extra ? bj : extra);
-            }
-            const bool single = bs < 256;
-            const uint32_t seg = single ? bs : (bs + 3) >> 2;
-            uint32_t cnt = 0;
-            if (active) {
-                if (single) cnt = q == 0 ? bs : 0;
-                else cnt = q < 3 ? seg : bs - 3 * seg;
-            }
-            L.sbeg[lane] = active ? (cnt ? boff + (uint32_t)q * seg : boff + bs) : S;
-            L.scnt[lane] = cnt;
-            L.ssize[lane] = 0;
-        }
-        for (int i = lane; i < 2 * OBUF_WORDS; i += WAVE) (&L.obuf[0][0])[i] = 0;
-        wave_lds_sync();
-        const uint32_t nb = nblk;
-        uint32_t st = 0;
-        while (st < 4 * nb && L.scnt[st] == 0) ++st;
-        uint32_t done = 0;
-#if VBZ_PACK_PREFETCH
-        uint32_t cur[STEP_DW], nxt[STEP_DW];
-#else
-        uint32_t cur[STEP_DW];
-#endif
-        auto load_chunk = [&](uint32_t sbeg, uint32_t scount, uint32_t dn, uint32_t (&w)[STEP_DW]) {
-#pragma unroll
-            for (int k = 0; k < STEP_DW; ++k) w[k] = 0;
-            const int32_t room = (int32_t)(scount - dn) - STEP_LANE * lane;
-            if (room > 0) {
-                const uint8_t* p = rin + sbeg + room - STEP_LANE;  // may start before the stream: those bytes are masked when used
-                const bool headroom = (uint64_t)r0 + sbeg >= (uint32_t)STEP_LANE;  // ... but not before the input buffer
-                if (room >= STEP_LANE || headroom) {
-                    uint4 v0;
-                    __builtin_memcpy(&v0, p, 16);
-                    w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < STEP_LANE; ++k) {
-                        const uint32_t byte = (room - STEP_LANE + k >= 0) ? (uint32_t)p[k] : 0u;
-                        w[k >> 2] |= byte << (8 * (k & 3));
-                    }
-                }
-            }
-        };
-        auto blk_bs = [&](uint32_t j) { return base + (j < extra ? 1u : 0u); };
-        auto blk_lh = [&](uint32_t j) {
-            const uint32_t jbs = blk_bs(j);
-            const uint32_t worst = (j == 0 ? treeSize : 0u) + 6u + ((jbs * 11u + 7u) >> 3) + 4u;  // every code <= 11 bits
-            const uint32_t big = jbs > worst ? jbs : worst;
-            return 3u + (big >= 1024u ? 1u : 0u) + (big >= 16384u ? 1u : 0u);
-        };
-        auto block_headers = [&](uint32_t j, uint32_t at, uint32_t seqB) {
-            if (lane == 0) {
-                const uint32_t jbs = blk_bs(j);
-                const bool jsingle = jbs < 256u;
-                const uint32_t lh = blk_lh(j), tsz = j == 0 ? treeSize : 0u;
-                const uint32_t s0 = L.ssize[4 * j], s1 = L.ssize[4 * j + 1], s2 = L.ssize[4 * j + 2], s3 = L.ssize[4 * j + 3];
-                const uint32_t lit = tsz + (jsingle ? 0u : 6u) + s0 + s1 + s2 + s3;
-                uint8_t* bp = out + at;
-                const uint32_t last = (lastRegion && j + 1 == nblk) ? 1u : 0u;
-                put_le(bp, ((lh + lit + seqB) << 3) | (2u << 1) | last, 3);
-                const uint64_t type = j == 0 ? 2 : 3;  // Compressed_Literals_Block / Treeless
-                if (lh == 3) put_le(bp + 3, type | ((jsingle ? 0ull : 1ull) << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 14), 3);
-                else if (lh == 4) put_le(bp + 3, type | (2ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 18), 4);
-                else put_le(bp + 3, type | (3ull << 2) | ((uint64_t)jbs << 4) | ((uint64_t)lit << 22), 5);
-                if (!jsingle) {
-                    uint8_t* tp = bp + 3 + lh + tsz;
-                    put_le(tp, s0, 2);
-                    put_le(tp + 2, s1, 2);
-                    put_le(tp + 4, s2, 2);
-                }
-            }
-        };
-        uint32_t ocur = opos;        // where the current block starts
-        uint32_t spos = 0;           // where the current stream starts
-        uint32_t curblk = 0xFFFFFFFFu;
-        if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
-        PPHASE(1);
-        uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
-        uint32_t flushed = 0;     // bytes of the stream already written to memory (or waiting in the other buffer for it)
-        uint32_t cb = 0;          // the buffer this step fills
-        uint32_t pend_fq = 0;     // quads of the step before that wait in the other buffer ...
-        uint8_t* pend_dst = nullptr;  // ... for this address
-        auto flush_pending = [&]() {
-            uint4* pq = reinterpret_cast<uint4*>(L.obuf[cb ^ 1u]);
-            for (uint32_t q = lane; q < pend_fq; q += WAVE) {
-                const uint4 v = pq[q];
-                pq[q] = make_uint4(0u, 0u, 0u, 0u);
-                __builtin_memcpy(pend_dst + 16u * q, &v, 16);
-            }
-            pend_fq = 0;
-        };
-        while (st < 4 * nb) {
-            if ((st >> 2) != curblk) {  // first stream of a block: reserve its headers, place the tree
-                curblk = st >> 2;
-                const uint32_t tsz = curblk == 0 ? treeSize : 0u;
-                const uint32_t hl = 3u + blk_lh(curblk) + tsz + (blk_bs(curblk) < 256u ? 0u : 6u);
-                if ((uint64_t)ocur + hl > limit) REDO();
-                for (uint32_t i = lane; i < tsz; i += WAVE) out[ocur + 3u + blk_lh(curblk) + i] = reinterpret_cast<const uint8_t*>(L.tree)[i];
-                spos = ocur + hl;
-            }
-            const uint32_t scnt = L.scnt[st];
-            uint8_t* sop = out + spos;
-            uint32_t nst = st, ndone = done + STEP_SYMS;
-            if (ndone >= scnt) {
-                ndone = 0;
-                ++nst;
-                while (nst < 4 * nb && L.scnt[nst] == 0) ++nst;
-            }
-            flush_pending();   // (the step before: its quads, in front of the request below)
-#if VBZ_PACK_PREFETCH
-            if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, nxt);
-#endif
-            const int32_t room = (int32_t)(scnt - done) - STEP_LANE * lane;
-            const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
-            uint32_t ent[STEP_LANE];   // code | length << 16 of the lane's symbols
-#pragma unroll
-            for (int k = 0; k < STEP_LANE; ++k) ent[k] = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
-            if (skip != 0) {  // only the last step of a stream has lanes in front of its start
-#pragma unroll
-                for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
-            }
-            uint32_t Tb = 0;  // bits of this lane's codes
-#pragma unroll
-            for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k] >> 16;
-            const uint32_t incl = wave_incl_scan_u32(Tb);
-            const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-            const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
-            const uint32_t fq = allbits >> 7;             // complete 16-byte quads
-            if ((uint64_t)spos + flushed + 16ull * fq + 24 > limit) REDO();
-            PPHASE(2);
-            {
-                const uint32_t pos = base_bits + incl - Tb;
-                uint32_t word = pos >> 5;
-                uint32_t accbits = pos & 31;
-                uint64_t acc = 0;
-#pragma unroll
-                for (int k = STEP_LANE - 1; k >= 0; k -= 2) {
-                    // two symbols (at most 22 bits) per flush check: accbits < 32 before, < 54 after
-                    const uint32_t e1 = ent[k], e0 = ent[k - 1];
-                    const uint32_t l1 = e1 >> 16, l0 = e0 >> 16;
-                    const uint64_t pair = (uint64_t)((e1 & 0xFFFFu) | ((e0 & 0xFFFFu) << l1));
-                    acc |= pair << accbits;
-                    accbits += l1 + l0;
-                    if (accbits >= 32) {
-                        atomicOr(&L.obuf[cb][word], (uint32_t)acc);
-                        acc >>= 32;
-                        accbits -= 32;
-                        ++word;
-                    }
-                }
-                if (acc) atomicOr(&L.obuf[cb][word], (uint32_t)acc);
-            }
-            wave_lds_sync();
-            PPHASE(3);
-            {   // complete quads wait in this buffer for the top of the next step; the rest moves to the front of the other buffer
-                uint4* obq = reinterpret_cast<uint4*>(L.obuf[cb]);
-                uint4* nbq = reinterpret_cast<uint4*>(L.obuf[cb ^ 1u]);   // (stored and cleared at the top of this step)
-                if (lane == 0) {
-                    const uint4 c = obq[fq];
-                    obq[fq] = make_uint4(0u, 0u, 0u, 0u);
-                    nbq[0] = c;
-                }
-                pend_fq = fq;
-                pend_dst = sop + flushed;
-                cb ^= 1u;
-            }
-            flushed += 16u * fq;
-            base_bits = allbits & 127u;
-            wave_lds_sync();
-            PPHASE(4);
-            if (nst != st) {
-                // stream finished: end mark and the bits still in quad 0 (lane k writes byte k)
-                const uint32_t nbytes = (base_bits + 1 + 7) >> 3;  // <= 16
-                {
-                    uint4* obq = reinterpret_cast<uint4*>(L.obuf[cb]);
-                    const uint4 c = obq[0];
-                    const uint32_t cw[4] = { c.x, c.y, c.z, c.w };
-                    uint32_t mine = cw[(lane >> 2) & 3];
-                    if ((uint32_t)(lane >> 2) == (base_bits >> 5)) mine |= 1u << (base_bits & 31u);
-                    if ((uint32_t)lane < nbytes) sop[flushed + lane] = (uint8_t)(mine >> (8 * (lane & 3)));
-                    wave_lds_sync();
-                    if (lane == 0) {
-                        obq[0] = make_uint4(0u, 0u, 0u, 0u);
-                        L.ssize[st] = flushed + nbytes;
-                    }
-                }
-                spos += flushed + nbytes;
-                base_bits = 0;
-                flushed = 0;
-                if ((nst >> 2) != curblk && !seqmode) {
-                    // block finished: a plain block ends with Number_of_Sequences = 0; then the headers
-                    wave_lds_sync();
-                    if ((uint64_t)spos + 1 > limit) REDO();
-                    if (lane == 0) out[spos] = 0;
-                    block_headers(curblk, ocur, 1u);
-                    ocur = spos + 1u;
-                }
-            }
-#if VBZ_PACK_PREFETCH
-#pragma unroll
-            for (int k = 0; k < STEP_DW; ++k) cur[k] = nxt[k];
-#else
-            if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, cur);
-#endif
-            st = nst;
-            done = ndone;
-            PPHASE(5);
-        }
-        flush_pending();
-        if (seqmode && curblk != 0xFFFFFFFFu) {
-            // the block with the run sequences: its sequences section, coded by the planning launch above the frame, moves behind
-            // the literals (upwards in memory never: the frame has stayed below it)
-            wave_lds_sync();
-            if ((uint64_t)spos + seqBytes > seqOff) REDO();
-            for (uint32_t i = 16u * (uint32_t)lane; i < seqBytes; i += 16u * WAVE) {
-                uint4 v;
-                __builtin_memcpy(&v, out + seqOff + i, 16);   // (reads up to 15 bytes past the section: inside the slot)
-                if (i + 16u <= seqBytes) __builtin_memcpy(out + spos + i, &v, 16);
-                else {
-                    const uint32_t w[4] = { v.x, v.y, v.z, v.w };
-                    for (uint32_t k = i; k < seqBytes; ++k) out[spos + k] = (uint8_t)(w[(k - i) >> 2] >> (8 * ((k - i) & 3)));
-                }
-            }
-            wave_lds_sync();
-            block_headers(curblk, ocur, seqBytes);
-            ocur = spos + seqBytes;
-        }
-        opos = ocur;
+        if (!pack_region<TIMED>(L, in + r0, r0, out, opos, limit, P->ctable, P->tree, S, P->nblk, P->treeSize, P->seqmode != 0, r1 == N, seqBytes, seqOff, lane,
+                                tph, tlast))
+            REDO();
         if (Sh != S && opos - opos_region > S + (S >> 6) + 256u) REDO();   // a sample that misled: coded again from the exact histogram
         PPHASE(6);
     }
@@ -2353,12 +2545,13 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_pack_kernel(Rea
 // any) goes an INDEX of the spans in a second skippable frame -- where each span's first block starts in the frame and in
 // the content -- with which zstd_decode.hip decodes the spans on different wavefronts; like the checkpoints it is verified,
 // never trusted (a decoder without it, e.g. libzstd, walks the blocks one after the other).
-//   layout: magic 0x184D2A5C, u32 payload bytes, { u32 nspans, nspans x { u32 frame offset, u32 content offset }, u32 total bytes }
+//   layout: magic 0x184D2A5C, u32 payload bytes, { u32 nspans (bit 31: some spans begin with a treeless block), nspans x { u32 frame offset,
+//           u32 content offset }, u32 total bytes }
 constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;
 
 __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const uint32_t* svb_size, const uint32_t* orig_size, uint32_t key_elem,
                                                               const uint32_t* gate, uint32_t seq_enabled, uint32_t max_spans, uint64_t tmp_limit,
-                                                              EncSpan* spans, uint32_t* span_first, uint32_t* span_count)
+                                                              EncSpan* spans, uint32_t* span_first, uint32_t* span_count, SpanRegion* regions, uint32_t shspan)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint32_t wcnt[16];
@@ -2367,14 +2560,19 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
     // the plan of the reads of one round (1024 reads), read back by all threads when the span descriptors are written
     __shared__ uint32_t q_N[1024], q_K[1024], q_keyN[1024], q_dataN[1024], q_first[1024];
     __shared__ uint64_t q_off[1024];
+    __shared__ uint8_t q_shared[1024];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) { carry_b = 0; carry_c = 0; }
+    if (regions) {   // histograms and tickets of the shared-table launch start at zero
+        for (uint32_t i = tid; i < n * SPANREGION_ZEROED; i += 1024)
+            reinterpret_cast<uint32_t*>(regions + i / SPANREGION_ZEROED)[i % SPANREGION_ZEROED] = 0;
+    }
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
         const uint32_t i = base + tid;
         uint32_t cnt = 0, N = 0, K = 0, keyN = 0, dataN = 0;
         uint64_t bytes = 0;
-        bool skip = false;
+        bool skip = false, shared = false;
         if (i < n) {
             N = svb_size[i];
             skip = (gate && gate[i] >= GATE_SKIP) || N >= E_FIRST;
@@ -2385,12 +2583,13 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                     K = (orig_size[i] / key_elem + 3u) >> 2;
                     if (K >= N) K = 0;
                 }
-                span_cut(N, K, keyN, dataN);
+                span_cut(N, K, regions ? shspan : 0u, keyN, dataN, shared);
                 cnt = keyN + dataN;
                 // every span of a region gets the slot of the region's largest span
                 if (keyN) bytes += (uint64_t)keyN * span_tmp_bytes((K + keyN - 1) / keyN, seq_enabled != 0);
                 // (a small frame without a control-byte region is one span that looks for runs, like the one-wavefront path)
-                if (dataN) bytes += (uint64_t)dataN * span_tmp_bytes((N - K + dataN - 1) / dataN, keyN == 0 && dataN == 1 && seq_enabled != 0);
+                if (dataN) bytes += (uint64_t)dataN * (shared ? shspan_tmp_bytes((N - K + dataN - 1) / dataN)
+                                                              : span_tmp_bytes((N - K + dataN - 1) / dataN, keyN == 0 && dataN == 1 && seq_enabled != 0));
             }
         }
         uint32_t ci = cnt;
@@ -2418,6 +2617,8 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
             q_K[tid] = K;
             q_keyN[tid] = (skip || !fits) ? 0xFFFFFFFFu : keyN;   // marks a skipped read
             q_dataN[tid] = (skip || !fits) ? cnt : dataN;
+            q_shared[tid] = (shared && !skip && fits) ? 1 : 0;
+            if (regions && shared && !skip && fits) regions[i].nshared = dataN;
         }
         __syncthreads();
         const uint32_t here = (n - base) < 1024u ? (n - base) : 1024u;
@@ -2436,7 +2637,7 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
             const bool keyseq1 = seq_enabled != 0;
             const uint32_t slotK = kN ? span_tmp_bytes((qK + kN - 1) / kN, keyseq1) : 0u;
             const bool dataseq = kN == 0 && dN == 1 && seq_enabled != 0 && D >= 256;
-            const uint32_t slotD = dN ? span_tmp_bytes((D + dN - 1) / dN, kN == 0 && dN == 1 && seq_enabled != 0) : 0u;
+            const uint32_t slotD = dN ? (q_shared[q] ? shspan_tmp_bytes((D + dN - 1) / dN) : span_tmp_bytes((D + dN - 1) / dN, kN == 0 && dN == 1 && seq_enabled != 0)) : 0u;
             for (uint32_t j = tid; j < cntq; j += 1024) {
                 EncSpan e = {};
                 e.read = base + q;
@@ -2454,8 +2655,9 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
                     e.tmp_off = q_off[q] + (uint64_t)kN * slotK + (uint64_t)t * slotD;
                     e.tmp_cap = slotD;
                     keyseq = dataseq;
+                    if (q_shared[q]) e.flags = SPAN_SHARED | (t == 0 ? SPAN_TREE : 0u);
                 }
-                e.flags = (j == 0 ? SPAN_FIRST : 0u) | (j + 1 == cntq ? SPAN_LAST : 0u) | (keyseq ? SPAN_KEYSEQ : 0u);
+                e.flags |= (j == 0 ? SPAN_FIRST : 0u) | (j + 1 == cntq ? SPAN_LAST : 0u) | (keyseq ? SPAN_KEYSEQ : 0u);
                 e.ord = j;
                 spans[si + j] = e;
             }
@@ -2467,6 +2669,65 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
     if (tid == 0) {
         span_first[n] = carry_c;
         *span_count = carry_c < max_spans ? carry_c : max_spans;
+    }
+}
+
+// ---- shared tables: pack the spans (the count and the table: zstd_encode_kernel's table role, see SpanRegion) --------------------------
+// One wavefront per shared span: its bytes as blocks of at most SPAN_BLOCK, packed with the region's table (pack_region: the packing
+// launch's loop) into the span's temporary slot -- which holds the worst case, 11 bits per byte, so that the span with the tree
+// description can never fail; any other span that comes out larger than raw blocks is stored as raw blocks, like a region whose
+// count said that a table does not pay (mode 0); a region of one byte value (mode 1) becomes RLE blocks.
+__global__ __launch_bounds__(WAVE, VBZ_ENC_PACK_WAVES) void zstd_span_pack_kernel(ReadBatch b, const EncSpan* spans, const uint32_t* span_count, uint8_t* span_tmp,
+                                                                                  uint32_t* span_size, uint32_t* span_trail, const SpanRegion* regions)
+{
+    __shared__ __attribute__((aligned(16))) PackLds L;
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= *span_count) return;
+    const EncSpan sp = spans[blockIdx.x];
+    if ((sp.flags & (SPAN_SHARED | SPAN_SKIP)) != SPAN_SHARED) return;
+    const SpanRegion* R = &regions[sp.read];
+    const uint8_t* in = b.src + b.src_off[sp.read];
+    uint8_t* out = span_tmp + sp.tmp_off;
+    const uint32_t S = sp.r1 - sp.r0, cap = sp.tmp_cap;
+    const uint32_t nblk = (S + SPAN_BLOCK - 1) / SPAN_BLOCK;
+    const bool last = (sp.flags & SPAN_LAST) != 0, tree = (sp.flags & SPAN_TREE) != 0;
+    const uint32_t mode = R->mode;
+    uint32_t opos = 0;
+    bool packed = false;
+    if (mode == 2u) {
+        unsigned long long tph[PHASE_SLOTS] = {}, tlast = 0;
+        packed = pack_region<false>(L, in + sp.r0, sp.r0, out, opos, cap, R->ctable, R->tree, S, nblk, tree ? R->treeSize : 0u, false, last, 0u, 0u, lane, tph, tlast);
+        if (packed && !tree && opos > S + 3u * nblk) packed = false;
+        if (!packed && tree) {   // (cannot happen: the slot holds 11 bits per byte)
+            if (lane == 0) { span_size[blockIdx.x] = E_ZSTD; span_trail[blockIdx.x] = 0; }
+            return;
+        }
+    }
+    if (!packed) {
+        if ((uint64_t)S + 3ull * nblk > cap) {
+            if (lane == 0) { span_size[blockIdx.x] = E_ZSTD; span_trail[blockIdx.x] = 0; }
+            return;
+        }
+        wave_lds_sync();
+        const uint32_t base = S / nblk, extra = S % nblk;
+        const bool rle = mode == 1u;
+        opos = 0;
+        for (uint32_t j = 0; j < nblk; ++j) {
+            const uint32_t bs = base + (j < extra ? 1u : 0u), boff = j * base + (j < extra ? j : extra);
+            const uint8_t* q = in + sp.r0 + boff;
+            if (lane == 0) put_le(out + opos, (bs << 3) | (rle ? 2u : 0u) | ((last && j + 1 == nblk) ? 1u : 0u), 3);
+            if (rle) {
+                if (lane == 0) out[opos + 3] = q[0];
+                opos += 4;
+            } else {
+                for (uint32_t i = lane; i < bs; i += WAVE) out[opos + 3 + i] = q[i];
+                opos += 3 + bs;
+            }
+        }
+    }
+    if (lane == 0) {
+        span_size[blockIdx.x] = opos;
+        span_trail[blockIdx.x] = 0;
     }
 }
 
@@ -2523,7 +2784,8 @@ __global__ __launch_bounds__(256) void zstd_span_finish_kernel(ReadBatch b, uint
         if (tid == 0) {
             put_le(tp, IDX_MAGIC, 4);
             put_le(tp + 4, ib - 8u, 4);
-            put_le(tp + 8, nsp, 4);
+            // (bit 31: the frame has treeless spans -- the decoder's plan then looks for the spans that bring trees: IDX_TREELESS)
+            put_le(tp + 8, nsp | ((spans[s1 - 1].flags & SPAN_SHARED) ? 0x80000000u : 0u), 4);
             put_le(tp + 12 + 8 * nsp, ib, 4);
         }
         __syncthreads();  // span_dst of every span is written
@@ -2695,7 +2957,7 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
 #ifdef VBZ_EXPERIMENTS   // the timed instantiations (phase cycle counters) are part of the experiments build only
     if (dbg && !plan_meta) {   // phase counters of the whole frame in one launch
         hipLaunchKernelGGL((zstd_encode_kernel<true, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, dbg,
-                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, nullptr, nullptr, nullptr);
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, nullptr, nullptr, nullptr, SpanShared{});
         return hipGetLastError();
     }
 #else
@@ -2720,10 +2982,10 @@ hipError_t launch_zstd_encode(const ReadBatch& b, const uint32_t* orig_size, uin
         redo = nullptr;
     }
     hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, nullptr,
-                       src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, redo);
+                       src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, redo, SpanShared{});
     if (deep_d)  // the reads in which the first launch found a repeat distance (it wrote deep_d[] for every read)
         hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, key_bytes, hdr, nullptr,
-                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, nullptr);
+                           src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, tr, deep_d, redo ? plans : nullptr, nullptr, SpanShared{});
     return hipGetLastError();
 }
 
@@ -2740,12 +3002,14 @@ hipError_t launch_zstd_encode_matcher(const ReadBatch& b, const uint32_t* orig_s
     ReadBatch g = b;
     g.gate = gate_in;
     hipLaunchKernelGGL((zstd_encode_kernel<false, true>), dim3(b.n_reads), dim3(WAVE), 0, s, g, orig_size, key_elem, (const uint32_t*)nullptr, hdr,
-                       (unsigned long long*)nullptr, src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, trailers ? 1u : 0u, deep_d, nullptr, nullptr);
+                       (unsigned long long*)nullptr, src_cap, st, nullptr, nullptr, nullptr, nullptr, nullptr, trailers ? 1u : 0u, deep_d, nullptr, nullptr, SpanShared{});
     return hipGetLastError();
 }
 
 // ---- span mode (few, large reads) ------------------------------------------------------------------------------------------
 size_t zstd_span_desc_bytes() { return sizeof(EncSpan); }
+size_t zstd_span_region_bytes(uint32_t n_reads) { return (size_t)n_reads * sizeof(SpanRegion); }
+uint32_t zstd_span_shared_bytes(uint64_t stream_bytes) { return stream_bytes < SHSPAN_BATCH_FROM ? SHSPAN_BYTES : 0u; }
 
 uint32_t zstd_span_max_spans(uint64_t stream_bytes, uint32_t n_reads)
 {
@@ -2762,15 +3026,25 @@ uint64_t zstd_span_tmp_bytes(uint64_t stream_bytes, uint32_t n_reads, uint32_t m
 hipError_t launch_zstd_encode_spans(const ReadBatch& b, const uint32_t* orig_size, uint32_t key_elem, uint32_t hdr, const uint32_t* src_cap,
                                     const void* seq_tables, void* span_desc, uint32_t* span_first, uint32_t* span_count, uint32_t max_spans,
                                     uint8_t* span_tmp, uint64_t span_tmp_bytes, uint32_t* span_size, uint32_t* span_trail, uint32_t* span_dst,
-                                    bool index_trailer, hipStream_t s)
+                                    bool index_trailer, void* shared_regions, uint32_t shared_span_bytes, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
     EncSpan* spans = reinterpret_cast<EncSpan*>(span_desc);
+    SpanRegion* regions = reinterpret_cast<SpanRegion*>(shared_regions);
     hipLaunchKernelGGL(zstd_span_plan_kernel, dim3(1), dim3(1024), 0, s, b.n_reads, b.src_size, orig_size, key_elem, b.gate,
-                       (src_cap && seq_tables) ? 1u : 0u, max_spans, span_tmp_bytes, spans, span_first, span_count);
-    hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
-                       reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u,
-                       nullptr, nullptr, nullptr);
+                       (src_cap && seq_tables) ? 1u : 0u, max_spans, span_tmp_bytes, spans, span_first, span_count, regions, shared_span_bytes);
+    // (shared tables: the wavefronts behind the spans' are in the table role; the data bytes' spans are packed by the launch behind)
+    const SpanShared shared = { regions, max_spans, regions ? shared_span_bytes : 0u };
+    if (regions) hipLaunchKernelGGL(zstd_span_count_kernel, dim3((max_spans + 3) / 4), dim3(256), 0, s, b, spans, span_count, regions);
+    if (regions)
+        hipLaunchKernelGGL((zstd_encode_kernel<false, false, true>), dim3(max_spans + b.n_reads), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
+                           reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u,
+                           nullptr, nullptr, nullptr, shared);
+    else
+        hipLaunchKernelGGL((zstd_encode_kernel<false, false>), dim3(max_spans), dim3(WAVE), 0, s, b, orig_size, key_elem, nullptr, hdr, nullptr, src_cap,
+                           reinterpret_cast<const SeqCTables*>(seq_tables), spans, span_count, span_tmp, span_size, span_trail, index_trailer ? 1u : 0u,
+                           nullptr, nullptr, nullptr, shared);
+    if (regions) hipLaunchKernelGGL(zstd_span_pack_kernel, dim3(max_spans), dim3(WAVE), 0, s, b, spans, span_count, span_tmp, span_size, span_trail, regions);
     hipLaunchKernelGGL(zstd_span_finish_kernel, dim3(b.n_reads), dim3(256), 0, s, b, hdr, spans, span_first, max_spans, span_size, span_trail,
                        span_dst, index_trailer ? 1u : 0u);
     hipLaunchKernelGGL(zstd_span_compact_kernel, dim3(max_spans), dim3(256), 0, s, b, spans, span_count, span_tmp, span_size, span_trail, span_dst,
