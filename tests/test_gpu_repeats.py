@@ -44,13 +44,14 @@ def test_template_cycling_reads_compress_like_libzstd():
             ref = O.compress(a, oo)                                                      # libzstd at the SAME level
             r, rr = a.nbytes / len(f), a.nbytes / len(ref)
             if i < len(lengths) and len(a) > 524288:
-                # more control bytes than one block holds: they are Huffman coded, without the runs;
-                # round 3 coded such a read as spans, 2.4 x
-                assert r > 40 and r > 0.25 * rr, (level, i, r, rr)
+                # more control bytes than one block holds: they repeat at a distance of their own and are coded as matches, chunk by
+                # chunk (round 5; round 4 Huffman coded them, 44 x against libzstd's 148 x; round 3 coded such a read as spans, 2.4 x)
+                assert r > 0.88 * rr, (level, i, r, rr)
                 print("cycled read of %d samples, level %d: %.2f, libzstd %.2f" % (len(a), level, r, rr))
             elif i < len(lengths):
-                # same options, same input: about what libzstd gets (T2; round 2 asserted r < 3 here at level 1)
-                assert r > (0.8 if len(a) <= 400000 else 0.75) * rr, (level, i, r, rr)
+                # same options, same input: about what libzstd gets (T2; round 2 asserted r < 3 here at level 1; round 4 0.75 - 0.8 x:
+                # the control bytes' own period was not used)
+                assert r > 0.88 * rr, (level, i, r, rr)
                 print("cycled read of %d samples, level %d: %.2f, libzstd %.2f" % (len(a), level, r, rr))
             elif i == len(lengths):
                 assert abs(r / rr - 1) < (0.01 if level == 1 else 0.02), (level, r, rr)  # plain signal: the +-1 % contract (level 1)

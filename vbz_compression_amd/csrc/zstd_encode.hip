@@ -966,13 +966,16 @@ __device__ bool period_holds(const uint8_t* in, uint32_t S, uint32_t D, int lane
 // frame may then use the slot up to `cap` only.  Room for every match the data could possibly hold (one per RPER + 1 bytes)
 // is not asked for: real repeats are few and long, so the records get what room there is (rec_cap) and the matches are
 // counted before anything is moved.  false: no room at all (a stream near its worst case): no matcher for this read.
-struct DeepLayout { uint8_t* recs; uint16_t* mask; uint32_t cap, rec_cap, nch; };
+struct DeepLayout { uint8_t* recs; uint16_t* mask; uint16_t* maskK; uint32_t cap, rec_cap, nch, nchK; };
 __device__ __forceinline__ bool deep_layout(uint32_t N, uint32_t K, const uint8_t* in, uint32_t slot, uint8_t* out, uint32_t dst_cap, uint32_t hdr,
                                             DeepLayout& d)
 {
     const uint32_t SD = N - K;
     d.nch = (SD + (BLOCK_MAX - 16u) - 1u) / (BLOCK_MAX - 16u);
-    const uint32_t mask_bytes = 2u * ((SD + 15u) >> 4) + 16u;
+    d.nchK = (K + (BLOCK_MAX - 16u) - 1u) / (BLOCK_MAX - 16u);
+    // (one mask bit per data byte and, behind them, one per control byte: the control bytes of a read that cycles repeat too)
+    const uint32_t maskD_bytes = 2u * ((SD + 15u) >> 4) + 16u;
+    const uint32_t mask_bytes = maskD_bytes + 2u * ((K + 15u) >> 4) + 16u;
     const uint64_t frame_worst = (uint64_t)hdr + N + (N >> 6) + 1024u;   // (raw blocks are the worst a region can do)
     if (frame_worst + 64 > dst_cap) return false;
     uint64_t room = dst_cap - frame_worst - 48;                           // of the destination slot, above the frame
@@ -986,15 +989,54 @@ __device__ __forceinline__ bool deep_layout(uint32_t N, uint32_t K, const uint8_
         room -= mask_bytes + 16u;
         mask = top - mask_bytes - 16u;
     }
-    const uint32_t worst = SD / (RPER + 1u) + 2u * d.nch + 2u;            // more matches than this the data cannot hold
+    const uint32_t worst = N / (RPER + 1u) + 2u * (d.nch + d.nchK) + 4u;  // more matches than this the stream cannot hold
     const uint64_t fit = room / 8u;
     d.rec_cap = fit < worst ? (uint32_t)fit : worst;
     if (d.rec_cap < 16u) return false;
     const uintptr_t recs = ((mask < top && mask >= (uintptr_t)out ? mask : top) - 8ull * d.rec_cap) & ~(uintptr_t)15;
     d.recs = reinterpret_cast<uint8_t*>(recs);
     d.mask = reinterpret_cast<uint16_t*>(mask);
+    d.maskK = reinterpret_cast<uint16_t*>(mask + maskD_bytes);
     d.cap = (uint32_t)(recs - (uintptr_t)out);
     return true;
+}
+
+// all lanes.  The control bytes of a read whose data bytes repeat at distance D: how many VALUES make D data bytes?  Counted from control
+// byte `from` on (the read's very first value is a delta from nothing and may be longer than its later copies): the lengths the control
+// bytes announce are added up until they reach D exactly.  Returns that number of values, 0 if D falls inside a value or behind the region.
+__device__ uint32_t control_period_values(const uint8_t* keys, uint32_t K, uint32_t from, uint32_t D, int lane)
+{
+    uint32_t done = 0;   // data bytes of the control bytes in front of this round
+    for (uint32_t k0 = from; k0 + 4u <= K; k0 += 4u * WAVE) {
+        const uint32_t at = k0 + 4u * (uint32_t)lane;
+        uint32_t w = 0;
+        if (at + 4u <= K) __builtin_memcpy(&w, keys + at, 4);
+        // sixteen 2-bit codes: length = code + 1
+        const uint32_t lo = w & 0x33333333u, hi = (w >> 2) & 0x33333333u;
+        uint32_t t = lo + hi;                                  // nibbles: two codes each
+        t = (t & 0x0F0F0F0Fu) + ((t >> 4) & 0x0F0F0F0Fu);
+        const uint32_t len = at + 4u <= K ? ((t * 0x01010101u) >> 24) + 16u : 0u;
+        const uint32_t incl = wave_incl_scan_u32(len);
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        if (done + total >= D) {
+            // the lane whose sixteen values contain the D-th byte's end
+            const uint32_t before = done + incl - len;
+            const bool mine = len != 0 && before < D && before + len >= D;
+            uint32_t vals = 0;
+            if (mine) {
+                uint32_t acc = before;
+                for (uint32_t i = 0; i < 16u && acc < D; ++i) {
+                    acc += ((w >> (2u * i)) & 3u) + 1u;
+                    vals = acc == D ? (at - from) * 4u + i + 1u : 0u;
+                }
+            }
+            const uint64_t who = __ballot(mine);
+            if (!who) return 0;
+            return (uint32_t)__shfl((int)vals, __ffsll((long long)who) - 1, 64);
+        }
+        done += total;
+    }
+    return 0;
 }
 
 // all lanes: mask16[p >> 4] bit (p & 15) = byte p equals byte p - D (0 for p < D)
@@ -1538,6 +1580,12 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     // the control-byte region's records: the data bytes' records, and below them one mask bit per data byte.  A data
     // region of more than a block is then coded in chunks of at most a block (a match may not cross a block boundary).
     uint32_t deepD = 0, nunit = 2, chunk = 0;
+    // ... and the control bytes of such a read repeat too, at a distance of their own (deepDk): the number of values that make one
+    // period of data bytes, in control bytes (times 2 or 4 if that is not a whole number of them).  Their region is then cut into
+    // chunks of at most a block like the data bytes', each one block of literals and matches; without it (no period, too few
+    // periods, no room) the region is coded as ever -- zero runs in one block, or plain Huffman blocks beyond a block's length.
+    uint32_t deepDk = 0, kunits = 1, chunkK = 0;
+    uint16_t* mask16K = nullptr;
     uint16_t* mask16 = nullptr;
     uint8_t* deep_recs = nullptr;
     uint32_t deep_used = 0;   // records of the chunks coded so far
@@ -1562,6 +1610,32 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 deepD = D;
                 chunk = ch;
                 nunit = 1u + dl.nch;
+                // the control bytes' own distance
+                if (K >= 4096u) {
+                    const uint32_t from = K >= 1024u ? 64u : 0u;
+                    const uint32_t P = control_period_values(in, K, from, D, lane);
+                    const uint32_t Dk = P == 0 ? 0u : ((P & 3u) == 0 ? P >> 2 : ((P & 1u) == 0 ? P >> 1 : P));
+                    if (Dk >= PERIOD_MIN_D && (uint64_t)4u * Dk + 64u <= K) {
+                        period_mask(in, K, Dk, dl.maskK, lane);
+                        __syncthreads();
+                        const uint32_t chK = ((K + dl.nchK - 1u) / dl.nchK + 15u) & ~15u;
+                        uint32_t totalK = 0, litK = 0;
+                        for (uint32_t c0 = 0; c0 < K; c0 += chK) {
+                            uint32_t lit = 0, n1 = 0;
+                            tokenise_runs<true, true>(const_cast<uint8_t*>(in + c0), (K - c0) < chK ? (K - c0) : chK, nullptr, lit, n1, dl.maskK + (c0 >> 4), lane);
+                            totalK += n1;
+                            litK += lit;
+                        }
+                        // (it must pay: at most a quarter of the control bytes stay literals -- the first period and what differs)
+                        if (totalK != 0 && total + totalK <= dl.rec_cap && litK <= K / 4u) {
+                            mask16K = dl.maskK;
+                            deepDk = Dk;
+                            chunkK = chK;
+                            kunits = dl.nchK;
+                            nunit = kunits + dl.nch;
+                        }
+                    }
+                }
             }
         }
     }
@@ -1572,15 +1646,18 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     // so nothing that was tokenised is touched twice).
     bool exact_hist = false;
     for (int region = 0; region < (span_mode ? 1 : (int)nunit);) {
-        const uint32_t cidx = region > 0 ? (uint32_t)region - 1u : 0u;  // chunk of the data region (0 unless long repeats were found)
-        const uint32_t r0 = span_mode ? sp.r0 : (region == 0 ? 0 : K + cidx * chunk);
-        const uint32_t r1 = span_mode ? sp.r1 : (region == 0 ? (K ? K : N) : ((deepD && N - r0 > chunk) ? r0 + chunk : N));
-        if (region == 1 && K == 0) break;
+        // units: the control bytes (kunits chunks if they have a distance of their own, else one), then the data bytes (chunks if long
+        // repeats were found, else one)
+        const bool isK = (uint32_t)region < kunits;
+        const uint32_t cidx = isK ? (uint32_t)region : (uint32_t)region - kunits;
+        const uint32_t r0 = span_mode ? sp.r0 : (isK ? cidx * chunkK : K + cidx * chunk);
+        const uint32_t r1 = span_mode ? sp.r1 : (isK ? ((deepDk && K - r0 > chunkK) ? r0 + chunkK : (K ? K : N)) : ((deepD && N - r0 > chunk) ? r0 + chunk : N));
+        if (!isK && K == 0) break;
         uint32_t S = r1 - r0;
         const bool lastRegion = span_mode ? (sp.flags & SPAN_LAST) != 0 : (r1 == N);
         const uint8_t* rin = in + r0;
         uint32_t nblk = (S + T - 1) / T;
-        if (region >= 1 && keys_one_block) {
+        if (!isK && keys_one_block) {
             // the control bytes took one block (4 streams): the data bytes get the other 15 x 4 lanes of the decoder
             uint32_t Td = (S + DATA_BLOCKS - 1) / DATA_BLOCKS;
             Td = Td < MIN_BLOCK ? MIN_BLOCK : (Td > HUF_BLOCK_MAX ? HUF_BLOCK_MAX : Td);
@@ -1591,7 +1668,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         bool seqmode = false;
         uint32_t nrec = 0;
         const uint2* rec = nullptr;
-        if ((span_mode ? (sp.flags & SPAN_KEYSEQ) != 0 : region == 0) && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
+        if ((span_mode ? (sp.flags & SPAN_KEYSEQ) != 0 : (isK && deepDk == 0)) && src_cap && seqtab && S >= 256 && S <= BLOCK_MAX) {
             const uint32_t slot = src_cap[r];
             // records of all control-byte spans of the frame live behind the stream, each span's at its own offset
             uint32_t keyN = 1, dataN = 0, ord = 0;
@@ -1623,15 +1700,15 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
             }
         }
         uint32_t of_dist = 0;  // != 0: this region's sequences carry this explicit distance (long repeats)
-        if (DEEP && deepD && region >= 1) {
+        if (DEEP && !span_mode && (isK ? deepDk != 0 : deepD != 0)) {
             uint32_t Lit = 0;
             uint2* recs = reinterpret_cast<uint2*>(deep_recs + 8u * deep_used);
-            tokenise_runs<true>(const_cast<uint8_t*>(rin), S, recs, Lit, nrec, mask16 + ((r0 - K) >> 4), lane);
+            tokenise_runs<true>(const_cast<uint8_t*>(rin), S, recs, Lit, nrec, isK ? mask16K + (r0 >> 4) : mask16 + ((r0 - K) >> 4), lane);
             deep_used += nrec;
             __syncthreads();
             if (nrec) {  // (without a single match nothing was moved)
                 seqmode = true;
-                of_dist = deepD;
+                of_dist = isK ? deepDk : deepD;
                 rec = recs;
                 S = Lit;
                 nblk = 1;
