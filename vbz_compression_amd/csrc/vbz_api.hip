@@ -283,6 +283,11 @@ constexpr uint64_t SEGMENTED_MIN_AVG = 512u << 10;
 // whatever the read's length; the one-wavefront kernels win from a few thousand reads per call on, or when the reads are
 // so short that a read is hardly more than one span.
 constexpr uint64_t SMALL_BATCH_MIN_AVG = 64u << 10, SMALL_BATCH_MAX_BYTES = 96u << 20;
+// Decoding a handful of short reads -- a chunk per call through the HDF5 filter -- is a chain of nine launches on the one-wavefront
+// path (scan, weights, streams, runs, the gated second attempt, ...: 0.17 - 0.23 ms for 1 - 64 reads of 5 - 10 k samples) and six with
+// spans (0.13 - 0.19 ms, tools/time_small_batch.py); encoding such reads is faster on one wavefront each (0.11 - 0.13 against 0.12 - 0.20 ms).
+constexpr uint64_t TINY_DECODE_MIN_AVG = 8u << 10;
+constexpr uint32_t TINY_DECODE_MAX_READS = 64;
 
 // The context's second stream (the chain walk beside the launches for own frames; the shared-table spans beside the control-byte
 // spans): all three objects or none -- a context must never keep a stream without its events.
@@ -305,11 +310,12 @@ bool ensure_side(vbz_gpu_ctx* c)
     return true;
 }
 
-bool use_segments(const vbz_gpu_ctx* c, uint64_t raw_arena_bytes, uint32_t n)
+bool use_segments(const vbz_gpu_ctx* c, uint64_t raw_arena_bytes, uint32_t n, bool decode)
 {
     if (c->segmented >= 0) return c->segmented != 0;
     const uint64_t avg = raw_arena_bytes / n;
-    return avg >= SEGMENTED_MIN_AVG || (avg >= SMALL_BATCH_MIN_AVG && raw_arena_bytes <= SMALL_BATCH_MAX_BYTES);
+    return avg >= SEGMENTED_MIN_AVG || (avg >= SMALL_BATCH_MIN_AVG && raw_arena_bytes <= SMALL_BATCH_MAX_BYTES) ||
+           (decode && n <= TINY_DECODE_MAX_READS && avg >= TINY_DECODE_MIN_AVG);
 }
 
 struct SegTables
@@ -747,7 +753,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     if (n == 0) return 0;
     ReadBatch rb = to_rb(bt);
     if (validate_descriptors(c, bt, &rb) != 0) return -1;
-    const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n);
+    const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n, false);
     if (by_shape || !routing_applies(c, o, bt->src_bytes, n)) return compress_group(c, rb, bt->src_bytes, o, sized, by_shape);
     Routed r;
     if (route(c, rb, bt->src_size, &r) != 0) return -1;
@@ -786,7 +792,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         rb.dst_cap = orig_size;
         rb.gate = gate;
     }
-    const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n);
+    const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n, true);
     if (by_shape || !routing_applies(c, o, bt->dst_bytes, n)) return decompress_group(c, rb, bt->dst_bytes, o, by_shape);
     Routed r;
     if (route(c, rb, rb.dst_cap, &r) != 0) return -1;   // by the decoded size
@@ -1274,6 +1280,9 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     int rc = compress ? compress_batch_impl(c, &bt, o, sized) : decompress_batch_impl(c, &bt, o, sized);
     if (rc != 0) return device_failure();
     uint32_t result = VBZ_DEVICE_ERROR;
+    // (result, synchronise, bytes, synchronise.  Both copies behind ONE synchronisation -- the result word and a guess of the bytes into
+    // pinned staging, then a memcpy -- was measured for results up to 1 MB: 0.204 against 0.200 ms per vbz_compress call of a 100 k-sample
+    // read: the second round trip is not what the call waits for.)
     if (hipMemcpyAsync(&hm->result, &dm->result, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         set_error(c, "kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
