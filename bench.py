@@ -460,6 +460,20 @@ def run_rank(args):
         return 0
     opts = codec.options(*opts_tuple)
     L = codec.L
+    host_resident = None
+    if world == 1 and not args.no_pcie:
+        # host-resident data (never `value`): pinned host -> H2D -> codec -> D2H, three-stage pipeline (tools/pcie_pipeline.py).  Measured
+        # FIRST, while this process has one context and three streams: behind the timed region -- the routing context, the side stream, 200 GB
+        # of HBM just released -- the same code held the decode leg at half the link (28.7 GB/s of 57; here 50), and so did the tool as a
+        # child process while this one kept its queues (round 4's VERDICT, item 9).
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pcie_pipeline
+
+        h = pcie_pipeline.measure(codec, 2048, 16)
+        host_resident = {"encode_decode_MBps": h["encode_decode_MBps"], "encode_MBps": h["encode_MBps"], "decode_MBps": h["decode_MBps"],
+                         "h2d_GBps": h["h2d_GBps"], "d2h_GBps": h["d2h_GBps"], "round_trip_ok": h["round_trip_ok"],
+                         "note": "PCIe-inclusive rate with pinned host buffers both ends (tools/pcie_pipeline.py), measured before the resident batches are built; never `value`"}
+        torch.cuda.empty_cache()
 
     # ---- how many distinct batches fit: raw signal per batch, plus ONE shared set of worst-case output slots, decoded
     # copy and library scratch (encode 9/8, decode 17/8 of the raw bytes, grown by 1/8 when (re)allocated)
@@ -694,20 +708,13 @@ def run_rank(args):
         }
         if stage:
             out["stages"] = stage
-        if world == 1 and not args.no_pcie:
-            # host-resident data (never `value`): pinned host -> H2D -> codec -> D2H, three-stage pipeline
+        if host_resident is not None:
+            out["host_resident"] = host_resident
+        if world == 1:   # (the legs below allocate: the resident batches have done their work)
             del comp, back
             for B in batches[1:]:
                 B.clear()
             torch.cuda.empty_cache()
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import pcie_pipeline
-
-            # (16 batches: with 8 the pipeline's fill and drain -- two of ten stage times -- held the decode leg at half the link)
-            h = pcie_pipeline.measure(codec, 2048, 16)
-            out["host_resident"] = {"encode_decode_MBps": h["encode_decode_MBps"], "encode_MBps": h["encode_MBps"], "decode_MBps": h["decode_MBps"],
-                                    "h2d_GBps": h["h2d_GBps"], "d2h_GBps": h["d2h_GBps"], "round_trip_ok": h["round_trip_ok"],
-                                    "note": "PCIe-inclusive rate with pinned host buffers both ends (tools/pcie_pipeline.py); never `value`"}
         if world == 1 and not args.no_cpu and not fixed_job:
             out["decode_reference_frames"] = decode_reference_frames(codec)
         if world == 1 and not args.no_cpu:
