@@ -424,107 +424,111 @@ __device__ __forceinline__ uint32_t huf_build_wave(LDS& L, uint32_t maxSym, uint
     }
     wave_lds_sync();
     SUB(6);
-    // --- package-merge (see huf_package_merge in zstd_entropy.h: the same lists, the same order of equal weights).
-    // From here on element e = lane + 64*j: the trip counts nj / mj are wave-uniform.
+    // --- package-merge (see huf_package_merge in zstd_entropy.h: the same lists, the same order of equal weights), IN REGISTERS since
+    // round 5: a level's list is the bitonic merge of the leaves (ascending, positions 0 .. 255: eight consecutive per lane in lanes
+    // 0 .. 31, padded with "infinity") and the packages of the level below (DESCENDING from position 511: lane 63 holds the eight
+    // lightest) -- nine compare-exchange stages, six of them across lanes (xor 32 .. 1), three inside a lane.  Keys are weight << 1 |
+    // is-package: a leaf comes in front of a package of its weight, as in the serial merge (a weight is at most 11 x 2^24: a leaf
+    // counts once per level).  The pairs of the merged list are in one lane each, so the next level's packages (package t in lane
+    // t / 4) cost no traffic; they move to their place at the top of the next list with eight shuffles.  What a level leaves behind is
+    // which of its items are packages: one ballot per register (bit l of mask r = item 8 l + r).  The first version searched every
+    // leaf's and every package's place in the other list by bisection in LDS: nine dependent round trips per level, 54 k cycles per
+    // table for a lone wavefront against 14 k here (profiles/r05_experiments.md).
+    // Element e = lane + 64*j from "which leaves" on: the trip count nj is wave-uniform.
     const uint32_t X0 = 2u * n - 2u;
     const uint32_t nj = (n + 63u) >> 6;
-    const uint32_t ntop = 1u << (31 - __builtin_clz(n > 255u ? 255u : n));
-    uint32_t lv[4], pv[4], ln[4];
+    constexpr uint32_t PM_INF = 0xFFFFFFFFu;
+    uint32_t ln[4] = { 0, 0, 0, 0 };
+    uint32_t lk[8];   // the leaves as keys
+    {
+        uint4 a = make_uint4(PM_INF, PM_INF, PM_INF, PM_INF), c = a;
+        if (lane < 32) {
+            a = *reinterpret_cast<const uint4*>(&K.leaf[8 * lane]);
+            c = *reinterpret_cast<const uint4*>(&K.leaf[8 * lane + 4]);
+        }
+        const uint32_t w8[8] = { a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w };
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        lv[j] = K.leaf[lane + 64 * j];
-        ln[j] = 0;
+        for (int r = 0; r < 8; ++r) lk[r] = w8[r] == PM_INF ? PM_INF : w8[r] << 1;
     }
     uint32_t m = n >> 1;
+    uint32_t pk4[4];  // the packages of the level below: package t = 4 * lane + q
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {   // packages of level 1: pairs of leaves (m <= 128)
-        const uint32_t t = (uint32_t)lane + 64u * j;
-        uint32_t v = 0xFFFFFFFFu;
-        if (t < m) {
-            const uint2 pr = *reinterpret_cast<const uint2*>(&K.leaf[2 * t]);
-            v = pr.x + pr.y;
-        }
-        pv[j] = v;
-        K.pkg[t] = v;
+    for (int q = 0; q < 4; ++q) {   // level 1: pairs of leaves (m <= 128: lanes 0 .. 31)
+        const uint32_t t = 4u * (uint32_t)lane + (uint32_t)q;
+        pk4[q] = t < m ? ((((lk[2 * q] >> 1) + (lk[2 * q + 1] >> 1)) << 1) | 1u) : PM_INF;
     }
-    wave_lds_sync();
+    wave_lds_sync();   // (the leaves have been read: the masks below reuse the workspace's list area)
+    uint64_t* const masks = reinterpret_cast<uint64_t*>(K.merged);   // [level][8]
     uint32_t levSame = maxNbBits;   // levels above this one equal it
     for (uint32_t lev = 2; lev <= maxNbBits; ++lev) {
         const bool last = lev == maxNbBits;
-        const uint32_t mj = (m + 63u) >> 6;
-        const uint32_t mtop = m ? 1u << (31 - __builtin_clz(m)) : 0u;
-        // positions in the merged list: a leaf goes behind the packages lighter than it, a package behind the leaves not
-        // heavier.  All searches of a lane advance together (up to eight independent LDS reads per step); elements past
-        // the end search with 0xFFFFFFFF and are not stored.
-        uint32_t lol[4] = { 0, 0, 0, 0 }, lop[4] = { 0, 0, 0, 0 };
-        for (uint32_t step = mtop > ntop ? mtop : ntop; step; step >>= 1) {
-            if (!last && step <= mtop) {
+        uint32_t it[8];
+        {
+            // lane l >= 32, register r: position 8 l + r holds package 511 - (8 l + r) = 8 (63 - l) + (7 - r), which lives in lane
+            // 2 (63 - l) + ((7 - r) >> 2), register (7 - r) & 3
+            const int src = 2 * (63 - lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if ((uint32_t)j < nj) lol[j] += K.pkg[lol[j] + step - 1] < lv[j] ? step : 0u;
-            }
-            if (step <= ntop) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if ((uint32_t)j < mj) lop[j] += K.leaf[lop[j] + step - 1] <= pv[j] ? step : 0u;
-            }
-        }
-        if (!last) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t e = (uint32_t)lane + 64u * j, pos = e + lol[j];
-                if (e < n && pos < X0) K.merged[pos] = lv[j];
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t p = (uint32_t)__shfl((int)pk4[(7 - r) & 3], (src + ((7 - r) >> 2)) & 63, 64);
+                it[r] = lane < 32 ? lk[r] : p;
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t t = (uint32_t)lane + 64u * j;
-            if (t < m) {
-                uint32_t cnt = lop[j];
-                if (n == 256u) cnt += (cnt == 255u && K.leaf[255] <= pv[j]) ? 1u : 0u;
-                const uint32_t pos = t + cnt;
-                if (pos < X0) {
-                    if (!last) K.merged[pos] = pv[j];
-                    atomicOr(&K.isPkg[lev][pos >> 5], 1u << (pos & 31u));
+        for (int dl = 32; dl >= 1; dl >>= 1) {
+            const bool lower = (lane & dl) == 0;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)it[r], dl, 64);
+                const uint32_t mn = o < it[r] ? o : it[r], mx = o < it[r] ? it[r] : o;
+                it[r] = lower ? mn : mx;
+            }
+        }
+#pragma unroll
+        for (int d = 4; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if ((r & d) == 0) {
+                    const uint32_t x = it[r], y = it[r | d];
+                    it[r] = x < y ? x : y;
+                    it[r | d] = x < y ? y : x;
                 }
             }
         }
-        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const uint64_t bm = __ballot((it[r] & 1u) != 0 && it[r] != PM_INF);
+            if (lane == 0) masks[8 * lev + (uint32_t)r] = bm;
+        }
         if (last) break;
         const uint32_t size = n + m < X0 ? n + m : X0;
         m = size >> 1;
         bool same = true;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t t = (uint32_t)lane + 64u * j;
-            uint32_t v = 0xFFFFFFFFu;
-            if (t < m) {
-                const uint2 pr = *reinterpret_cast<const uint2*>(&K.merged[2 * t]);
-                v = pr.x + pr.y;
-            }
-            same = same && v == pv[j];
-            pv[j] = v;
-            K.pkg[t] = v;
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t t = 4u * (uint32_t)lane + (uint32_t)q;
+            const uint32_t v = t < m ? ((((it[2 * q] >> 1) + (it[2 * q + 1] >> 1)) << 1) | 1u) : PM_INF;
+            same = same && v == pk4[q];
+            pk4[q] = v;
         }
-        wave_lds_sync();
         if (__ballot(!same) == 0) {   // the same packages as one level down: every further level repeats this one
             levSame = lev;
             break;
         }
     }
+    wave_lds_sync();
     SUB(7);
     // --- which leaves each level takes: a prefix, known from the number of packages among the level's first X items
     {
         uint32_t X = X0;
         for (uint32_t lev = maxNbBits; lev >= 2 && X; --lev) {
-            uint32_t c = 0;
-            if (lane < 16) {
-                const uint32_t w = K.isPkg[lev < levSame ? lev : levSame][lane];
-                const int32_t nb = (int32_t)X - 32 * lane;
-                const uint32_t mask = nb >= 32 ? 0xFFFFFFFFu : (nb > 0 ? (1u << nb) - 1u : 0u);
-                c = (uint32_t)__popc(w & mask);
+            const uint64_t* mk = masks + 8u * (lev < levSame ? lev : levSame);
+            uint32_t pk = 0;
+#pragma unroll
+            for (uint32_t r = 0; r < 8; ++r) {
+                const uint32_t cnt = X > r ? (X - r + 7u) >> 3 : 0u;   // lanes whose item 8 l + r is among the first X
+                const uint64_t lm = cnt >= 64u ? ~0ull : ((1ull << cnt) - 1ull);
+                pk += (uint32_t)__popcll(mk[r] & lm);
             }
-            const uint32_t pk = (uint32_t)__shfl((int)wave_incl_scan_u32(c), 63, 64);
             const uint32_t nl = X - pk;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ln[j] += ((uint32_t)lane + 64u * j) < nl ? 1u : 0u;
