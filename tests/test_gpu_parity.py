@@ -5,6 +5,7 @@ import ctypes
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -1279,6 +1280,60 @@ def test_many_tiny_reads_in_one_batch():
         mine = G.decompress([O.compress(reads[int(i)], oo) for i in pick], [reads[int(i)].nbytes for i in pick], go)
         for i, b in zip(pick, mine):
             assert not isinstance(b, int) and b.tobytes() == reads[int(i)].tobytes()
+
+
+def test_weights_alphabet_beyond_eleven_is_refused_on_every_decoder_path():
+    """tests/test_oracle_zstd.py::test_weights_alphabet_ends_at_eleven on the device: the frame whose damaged tree description lists
+    weights 12 and 13 (and still decodes consistently) is refused like libzstd refuses it -- by the batched own-frame decoder's
+    weights kernel, by the one-wavefront decoder's wave-parallel reader and by the span path's (a handful of reads per call) --, the
+    undamaged frame decodes, and bit flips in the description never make the device accept what libzstd refuses."""
+    import gpu_util as G
+    from vbz_compression_amd import _lib
+
+    z = np.load(os.path.join(GOLDEN, "weights_alphabet_beyond_11.npz"))
+    good, bad = z["original"], z["damaged"]
+    opts = _lib.CompressionOptions(True, 2, 1, 0)
+    oo = O.options(True, 2, 1, 0)
+    want = O.decompress(good, 40000, oo)
+    assert not isinstance(want, int) and isinstance(O.decompress(bad, 40000, oo), int)
+    rng = np.random.default_rng(6)
+    flips = []
+    for _ in range(200):
+        b = good.copy()
+        for _ in range(int(rng.integers(1, 3))):
+            b[int(rng.integers(23, 33))] ^= 1 << int(rng.integers(0, 8))
+        flips.append(b)
+    for env in ({}, {"VBZ_HIP_FAST_DECODE": "0"}, {"VBZ_HIP_SEGMENTED": "1"}):
+        for batch_of in (1, 40, 3000):      # the span path for a handful of reads, the batched decoder, calls that walk chains
+            frames = ([good, bad] + flips)[:max(2, min(batch_of, 202))] * (1 if batch_of <= 202 else 15)
+            got = _run_decode_in_env(frames, 40000, env)
+            for f, g in zip(frames, got):
+                lz = O.decompress(f, 40000, oo)
+                if isinstance(g, int):
+                    continue                                     # (stricter than libzstd is allowed)
+                assert not isinstance(lz, int) and lz.tobytes() == g.tobytes(), (env, batch_of)
+            assert not isinstance(got[0], int) and got[0].tobytes() == want.tobytes()
+            assert isinstance(got[1], int)
+
+
+def _run_decode_in_env(frames, nbytes, env):
+    """decompress `frames` in a process of its own with `env` added to the environment; returns arrays / error codes"""
+    import pickle
+    import subprocess
+    import tempfile
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "in.pkl"), "wb") as fh:
+            pickle.dump(([np.asarray(f) for f in frames], nbytes), fh)
+        code = ("import pickle, sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import gpu_util as G\nfrom vbz_compression_amd import _lib\n"
+                "frames, nb = pickle.load(open(%r, 'rb'))\n"
+                "got = G.decompress(frames, [nb] * len(frames), _lib.CompressionOptions(True, 2, 1, 0))\n"
+                "pickle.dump(got, open(%r, 'wb'))\n") % (root, os.path.join(root, "tests"), os.path.join(td, "in.pkl"), os.path.join(td, "out.pkl"))
+        subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), check=True, capture_output=True)
+        with open(os.path.join(td, "out.pkl"), "rb") as fh:
+            return pickle.load(fh)
 
 
 def test_zstd_decode_libzstd_frames_of_several_blocks():

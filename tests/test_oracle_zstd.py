@@ -92,3 +92,31 @@ def test_restated_decoder_rejects_corruption_without_crashing():
     assert accepted < 300
     for cut in (0, 1, 4, 5, 8, 9, 12, len(frame) // 2, len(frame) - 1):
         assert O.zstd_restate_decompress(frame[:cut], len(svb)) is None or cut == 0
+
+
+def test_weights_alphabet_ends_at_eleven():
+    """A Huffman tree description whose FSE-coded weights LIST a symbol beyond 11 -- one no weight ever takes -- can still be a complete
+    tree, and a frame built on it can decode consistently (every stream ends on its first bit): tools/soak_corrupt.py found one in
+    round 5 (seed 73: one bit of the accuracy log flipped in the frame of a read with four distinct data bytes).  libzstd >= 1.4.7 refuses
+    such a description (its workspace is sized for weights 0 .. HUF_TABLELOG_MAX - 1), so the restatement -- and the device decoders,
+    which mirror it -- must too: they may be stricter than libzstd, never more lenient.  The fixture holds the frame before and after."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "weights_alphabet_beyond_11.npz"))
+    good, bad = z["original"], z["damaged"]
+    assert np.count_nonzero(good != bad) == 1
+    ref = O.zstd_decompress(good, 60000)
+    assert ref is not None and len(ref) == 45000
+    assert O.zstd_restate_decompress(good, 60000).tobytes() == ref.tobytes()
+    assert O.zstd_decompress(bad, 60000) is None                     # libzstd 1.4.8: "Corrupted block detected"
+    assert O.zstd_restate_decompress(bad, 60000) is None
+    # ... and the hole is closed in general: bit flips in the description never make the restatement accept what libzstd refuses
+    rng = np.random.default_rng(5)
+    for _ in range(600):
+        b = good.copy()
+        for _ in range(int(rng.integers(1, 3))):
+            b[int(rng.integers(23, 33))] ^= 1 << int(rng.integers(0, 8))
+        mine = O.zstd_restate_decompress(b, 60000)
+        if mine is not None:
+            lz = O.zstd_decompress(b, 60000)
+            assert lz is not None and lz.tobytes() == mine.tobytes()

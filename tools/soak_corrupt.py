@@ -93,6 +93,13 @@ def main():
                 if isinstance(ref, int) or ref.tobytes() != g.tobytes():
                     print("MISMATCH seed %d round %d: the device returned samples the reference path does not (%s)" % (
                         args.seed, rounds, hex(ref) if isinstance(ref, int) else "different samples"))
+                    # the reproducer: the damaged buffer, the undamaged frames of the round and the options
+                    out = os.path.join(ROOT, "gpurun_out", "soak_mismatch_seed%d_round%d.npz" % (args.seed, rounds))
+                    os.makedirs(os.path.dirname(out), exist_ok=True)
+                    np.savez(out, damaged=v, nbytes=nb, size=size, zz=zz, level=level, sized=sized, lens=np.array(lens),
+                             device=g, index=np.array([i for i, x in enumerate(bad) if x is v][:1]),
+                             **{"frame%d" % i: f for i, f in enumerate(frames) if not isinstance(f, int)})
+                    print("reproducer written to", out)
                     return 1
         rounds += 1
     print("corruption soak ok: %d rounds, %d damaged buffers decoded like the reference, %d refused (%d of them accepted by libzstd), %.0f s, seed %d"

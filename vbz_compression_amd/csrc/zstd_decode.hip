@@ -297,7 +297,8 @@ __device__ __noinline__ int huf_read_weights(const uint8_t* p, int n, int* out_n
         used = 1 + hb;
         if (hb == 0 || used > n) return -1;
         int log, nsym;
-        const int hdr = read_ncount(p + 1, hb, 255, 6, &log, &nsym);
+        // (the weights' alphabet ends at 11 = HUF_TABLELOG_MAX - 1: libzstd >= 1.4.7 refuses a description that lists a symbol beyond it)
+        const int hdr = read_ncount(p + 1, hb, 11, 6, &log, &nsym);
         if (hdr < 0) return -1;
         uint32_t* tab = L.wfse;
         if (fse_build(tab, nsym, log) != 0) return -1;
@@ -403,7 +404,8 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
         uint32_t bitpos = 12, nrm = 0, sym = 0;
         int remaining = (1 << log) + 1, threshold = 1 << log, nbits = (int)log + 1;
         bool prev0 = false;
-        while (remaining > 1 && sym <= 255) {
+        // (the weights' alphabet ends at 11 = HUF_TABLELOG_MAX - 1: libzstd >= 1.4.7 refuses a description that lists a symbol beyond it)
+        while (remaining > 1 && sym <= 11) {
             if (prev0) {
                 for (;;) {
                     const uint32_t rr = bits(bitpos, 2);
@@ -412,7 +414,7 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
                     if (rr != 3) break;
                 }
                 prev0 = false;
-                if (sym > 255) break;
+                if (sym > 11) break;
                 continue;
             }
             const int max = (2 * threshold - 1) - remaining;
@@ -438,8 +440,7 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
             }
         }
         if (remaining != 1) return -1;
-        if (sym > 256) return -1;
-        if (sym > 64) return -2;
+        if (sym > 12) return -1;
         const uint32_t nsym = sym;
         const uint32_t hdr = (bitpos - 8 + 7) >> 3;  // bytes of the table description
         if (hdr > hb) return -1;
@@ -1489,7 +1490,7 @@ struct DecSpan
     uint32_t flags;     // DSPAN_*
     uint32_t ord;       // ordinal of the span in its frame
     uint32_t tree_pos;  // != 0: the block (offset in the read's source) whose Huffman tree is in force where this span begins
-    uint32_t pad;
+    uint32_t dst_len;   // content bytes of the span (what the index says)
 };
 constexpr uint32_t DSPAN_WHOLE = 1, DSPAN_LAST = 2, DSPAN_FIRST = 4;
 // Shared tables (zstd_encode.hip, round 5): the data bytes of a large read are spans of ONE block each, the first with the region's tree
@@ -1500,10 +1501,13 @@ constexpr uint32_t DSPAN_WHOLE = 1, DSPAN_LAST = 2, DSPAN_FIRST = 4;
 // span behind T brought any: then the table in force at every span behind T is T's, by the frame's own rules.
 constexpr uint32_t DSPAN_ST_REP1 = 1, DSPAN_ST_TREE_FIRST = 2, DSPAN_ST_TREE_LATER = 4;
 constexpr uint32_t IDX_MAGIC = 0x184D2A5Cu;      // zstd_encode.hip: the span index trailer
-constexpr uint32_t DSPAN_MIN_CONTENT = 8u << 10;    // an honest index has at most fcs / this + 4 spans (spans are cut evenly, none below 16 KB)
+constexpr uint32_t DSPAN_MIN_CONTENT = 4u << 10;    // an honest index has at most fcs / this + 4 spans (the writer's shortest spans hold 4 KB of control bytes)
 // A span whose block carries zero-run sequences stages its literals and (literal, match) length pairs behind the frame's
-// content in the destination slot, in a stripe of its own:
-constexpr uint32_t DSPAN_WS_STRIDE = 64u << 10;
+// content in the destination slot, in a stripe of its own: DSPAN_WS_FACTOR bytes per byte of its content (literals <= content, eight
+// bytes per sequence and a sequence regenerates four bytes or more -- what does not fit is decoded by the ordinary decoder) + 32,
+// laid out by content position: the stripes of different spans cannot overlap.  (Round 4 gave every span 64 KB by its ordinal, which
+// ran out of the slot from the fifth span with sequences on.)
+constexpr uint32_t DSPAN_WS_FACTOR = 3;
 // TIMED: per-phase shader-clock counters (VBZ_HIP_PHASE_TIMING); a separate instantiation, the counters cost
 // dozens of registers in the production kernel otherwise
 // FUSED: the frame's content is the svb stream of int16 zig-zag samples and b.dst its slot in the library's scratch: once the
@@ -1898,13 +1902,15 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         const uint32_t llm = modes >> 6, ofm = (modes >> 4) & 3;
                         const uint32_t ofsym_at = used0 + 1 + (llm == 1 ? 1u : 0u);
                         // (64-bit: a crafted index on a frame of half a gigabyte could make the stripe offset wrap)
-                        const uint64_t ws_lit64 = (((uint64_t)fcs + 15u) & ~15ull) + (partial ? (uint64_t)sp.ord * DSPAN_WS_STRIDE : 0ull);
+                        const uint64_t ws_stripe = (uint64_t)DSPAN_WS_FACTOR * sp.dst_len + 32u;
+                        const uint64_t ws_lit64 = (((uint64_t)fcs + 15u) & ~15ull) +
+                                                  (partial ? (((uint64_t)DSPAN_WS_FACTOR * sp.dst_pos + 32ull * sp.ord + 15u) & ~15ull) : 0ull);
                         const bool ws_ok = ws_lit64 + BLOCK_MAX + 16 < 0xFFFFFFF0ull;
                         ws_lit = ws_ok ? (uint32_t)ws_lit64 : 0u;
                         ws_pairs = ws_lit + (ltype >= 2 ? ((regen + 7u) & ~7u) : 0u);
                         go = (ws_ok && ofm == 1 && llm != 2 && ofsym_at < sqn && SQB(ofsym_at) == 0 && rep0 == 1 &&
                               (uint64_t)ws_pairs + 8ull * ns0 + 8 <= cap &&
-                              (!partial || (uint64_t)ws_pairs + 8ull * ns0 + 8 <= (uint64_t)ws_lit + DSPAN_WS_STRIDE)) ? 1u : 0u;
+                              (!partial || (uint64_t)ws_pairs + 8ull * ns0 + 8 + 16 <= (uint64_t)ws_lit + ws_stripe)) ? 1u : 0u;
                         // predefined LL and ML tables (what zstd_encode.hip writes): nothing to build
                         if (go && modes == 0x10u && dtabs != nullptr) go = 2u | (used0 << 2) | (ns0 << 4);
                     }
@@ -2595,7 +2601,7 @@ __global__ __launch_bounds__(1024) void zstd_dspan_plan_kernel(ReadBatch b, uint
                 d.flags = (j == 0 ? DSPAN_FIRST : 0u) | (j + 1 == ns ? DSPAN_LAST : 0u);
                 d.ord = j;
                 d.tree_pos = 0;
-                d.pad = 0;
+                d.dst_len = (j + 1 < ns ? nx[1] : q_fcs[q]) - v[1];
                 const uint32_t T1 = q_T[q] & 0x7FFFFFFFu;
                 if (T1 != 0 && j + 1 > T1) __builtin_memcpy(&d.tree_pos, e + 8 * (T1 - 1), 4);   // (never 0: behind the frame header)
                 spans[si + j] = d;

@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256) void fast_scan_kernel(ReadBatch b, FastFrame* 
 // ---- one lane per tree description ---------------------------------------------------------------------------------------------------
 // The serial reader of zstd_decode.hip (huf_read_weights: read_ncount, fse_build, two interleaved FSE states over a backward bit
 // stream, the checks on the weights) with one description per LANE: what it indexes lives in LDS columns of its own ([index][lane]:
-// no bank conflicts), the weights go to memory.  Descriptions it cannot hold (a symbol value above 15 in the weights' alphabet, a
+// no bank conflicts), the weights go to memory.  Descriptions it cannot hold (a
 // 12-bit code) are left to the careful decoder like every failure.
-constexpr int WMAXS = 15;
+constexpr int WMAXS = 11;   // the weights' alphabet: 0 .. HUF_TABLELOG_MAX - 1 (libzstd >= 1.4.7 refuses a description that lists more)
 struct WeightsLds
 {
     uint32_t desc[34][WAVE];  // the description behind its header byte, zero beyond

@@ -67,6 +67,14 @@ constexpr uint32_t SPAN_LARGE_FROM = 256u << 20;
 #define VBZ_KEYSPAN_KB 8
 #endif
 constexpr uint32_t KEYSPAN_BYTES = VBZ_KEYSPAN_KB << 10, KEYSPAN_LARGE_FROM = 1u << 20;
+// ... and half of it in calls with shared tables, which are a matter of latency: a control-byte span behind the first has no
+// checkpoints for its sequence chain (the trailer describes the frame's first sequences section), and the decoder's wavefront walks
+// the ~55 sequences per kilobyte one after the other -- 110 k cycles for a span of 6 KB, the longest wavefront of a decompress call
+// (profiles/r05_experiments.md)
+#ifndef VBZ_KEYSPAN_SHARED_KB
+#define VBZ_KEYSPAN_SHARED_KB 4
+#endif
+constexpr uint32_t KEYSPAN_BYTES_SHARED = VBZ_KEYSPAN_SHARED_KB << 10;
 __host__ __device__ constexpr uint32_t keyspan_bytes_for(uint32_t K) { return K >= KEYSPAN_LARGE_FROM ? 2u * KEYSPAN_BYTES : KEYSPAN_BYTES; }
 __host__ __device__ constexpr uint32_t span_bytes_for(uint32_t N) { return N >= SPAN_LARGE_FROM ? SPAN_BYTES_LARGE : SPAN_BYTES_SMALL; }
 #ifndef VBZ_STEP_LANE
@@ -1320,7 +1328,7 @@ __device__ __forceinline__ void span_cut(uint32_t N, uint32_t K, uint32_t shspan
     shared = shspan != 0 && K != 0 && D >= SHSPAN_MIN_REGION;
     const uint32_t SB = shared ? (N >= SPAN_LARGE_FROM ? SHSPAN_BYTES_LARGE : shspan) : span_bytes_for(N);
     // (with shared tables the call is a matter of latency, whatever the length of the control-byte region: short spans)
-    const uint32_t KB = shspan != 0 ? KEYSPAN_BYTES : keyspan_bytes_for(K);
+    const uint32_t KB = shspan != 0 ? KEYSPAN_BYTES_SHARED : keyspan_bytes_for(K);
     keyN = K == 0 ? 0u : (K + KB - 1) / KB;
     dataN = D ? (D + SB - 1) / SB : 0u;
     if (N == 0) dataN = 1;  // the empty frame
@@ -3094,7 +3102,7 @@ uint32_t zstd_span_shared_bytes(uint64_t stream_bytes) { return stream_bytes < S
 
 uint32_t zstd_span_max_spans(uint64_t stream_bytes, uint32_t n_reads)
 {
-    const uint64_t v = stream_bytes / (KEYSPAN_BYTES / 2) + 4ull * n_reads + 1;  // spans are cut evenly: none is below half its limit
+    const uint64_t v = stream_bytes / (KEYSPAN_BYTES_SHARED / 2) + 4ull * n_reads + 1;  // spans are cut evenly: none is below half its limit
     return v > 0x7FFFFFF0ull ? 0u : (uint32_t)v;
 }
 
