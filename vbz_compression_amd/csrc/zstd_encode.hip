@@ -2653,8 +2653,8 @@ __global__ __launch_bounds__(1024) void zstd_span_plan_kernel(uint32_t n, const 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) { carry_b = 0; carry_c = 0; }
     if (regions) {   // histograms and tickets of the shared-table launch start at zero
-        for (uint64_t i = tid; i < (uint64_t)n * SPANREGION_ZEROED; i += 1024)
-            reinterpret_cast<uint32_t*>(regions + i / SPANREGION_ZEROED)[i % SPANREGION_ZEROED] = 0;
+        for (uint32_t r = (uint32_t)tid >> 8; r < n; r += 4)   // (a quarter of the workgroup per read: no divisions)
+            for (uint32_t wd = (uint32_t)tid & 255u; wd < SPANREGION_ZEROED; wd += 256) reinterpret_cast<uint32_t*>(regions + r)[wd] = 0;
     }
     __syncthreads();
     for (uint32_t base = 0; base < n; base += 1024) {
