@@ -113,7 +113,10 @@ constexpr uint32_t SPAN_TREE = 32;     // ... and carries that table's descripti
 // the device at once -- there the longest wavefront is the call's latency --; no beyond: a batch of large buffers is a matter of
 // throughput, where three launches one after the other lose against one launch in which every span builds its own table (measured:
 // eight 40 MB buffers per call, zstd_encode 0.38 -> 0.49 ms with shared tables and spans of 32 KB; profiles/r05_experiments.md).
-constexpr uint32_t SHSPAN_BYTES = 8u << 10, SHSPAN_BATCH_FROM = 64u << 20;   // (of the bound on the call's stream bytes)
+// (tools/time_small_batch.py, reads of 100 k samples, compress / decompress ms per call with and without: 8 reads 0.125 / 0.142 against
+// 0.160 / 0.174, 32 reads 0.156 / 0.180 against 0.185 / 0.199, 100 reads 0.247 / 0.324 against 0.276 / 0.291, 200 reads 0.372 / 0.585 against
+// 0.388 / 0.417: from ~2 000 spans on every treeless span's reading of the tree is throughput lost, not latency hidden.)
+constexpr uint32_t SHSPAN_BYTES = 8u << 10, SHSPAN_BATCH_FROM = 20u << 20;   // (of the bound on the call's stream bytes)
 constexpr uint32_t SHSPAN_BYTES_LARGE = 4u * SPAN_BLOCK;  // reads of SPAN_LARGE_FROM bytes of stream and more
 constexpr uint32_t SHSPAN_MIN_REGION = 2u * SHSPAN_BYTES;
 
