@@ -259,6 +259,32 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(ReadBatch b, uint32_t h
     if (threadIdx.x == 0) b.result[r] = n + hdr;
 }
 
+// The single-buffer API's hand-back (vbz_api.hip run_one): one workgroup copies a read's result -- `*result` bytes at `src`, if they are
+// no error code and fit `host_cap` -- straight into pinned HOST memory, writes the result word there and then raises the flag the
+// host polls: no device-to-host copy call, no stream synchronisation on the way back.  host[0] = result, host[1] = bytes copied,
+// host[2] = flag (the call's sequence number), the bytes from host + 16 on.
+__global__ __launch_bounds__(1024) void hand_back_kernel(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq)
+{
+    const uint32_t r = *result;
+    uint32_t n = 0;
+    if (r < E_FIRST && r <= host_cap) n = r;
+    uint8_t* d = reinterpret_cast<uint8_t*>(host + 16);
+    const uint32_t nv = n >> 4;
+    for (uint32_t i = threadIdx.x; i < nv; i += 1024) {   // (src is the context's own allocation: 16-byte aligned)
+        const uint4 v = *reinterpret_cast<const uint4*>(src + 16ull * i);
+        *reinterpret_cast<uint4*>(d + 16ull * i) = v;
+    }
+    for (uint32_t i = (nv << 4) + threadIdx.x; i < n; i += 1024) d[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host[0] = r;
+        host[1] = n;
+        __threadfence_system();
+        __hip_atomic_store(&host[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- synthetic workload -----------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x)
 {
@@ -359,6 +385,12 @@ hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* sr
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(parse_sized_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, src, src_off, src_size, dst_cap, gate_in, pay_off,
                        pay_size, orig_size, gate);
+    return hipGetLastError();
+}
+
+hipError_t launch_hand_back(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq, hipStream_t s)
+{
+    hipLaunchKernelGGL(hand_back_kernel, dim3(1), dim3(1024), 0, s, result, src, host, host_cap, seq);
     return hipGetLastError();
 }
 

@@ -87,6 +87,7 @@ struct vbz_gpu_ctx
     bool trace = false;        // VBZ_HIP_TRACE=1: synchronise after every launch group and name it on stderr (to find a faulting kernel)
     void* pinned = nullptr;
     size_t pinned_cap = 0;
+    uint32_t one_seq = 0;      // the single-buffer API's hand-back flag: a number per call (run_one)
     bool profiling = false;
     std::vector<PendingEvent> pending;
     std::vector<ProfEntry> prof;
@@ -1228,6 +1229,8 @@ vbz_size_t device_failure()
     return VBZ_OUT_OF_MEMORY_ERROR;
 }
 
+constexpr uint32_t ONE_PINNED_MAX = 1u << 20;   // reads / results up to this size go through pinned memory (run_one)
+
 struct OneMeta  // device-side descriptors of a one-read batch
 {
     uint64_t src_off, dst_off;
@@ -1242,14 +1245,27 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     vbz_gpu_ctx* c = lease.c;
     if (!c) return device_failure();
     DeviceGuard dg(c->device);
-    if (!ensure(c, c->one_in, (size_t)src_size + 64) || !ensure(c, c->one_out, (size_t)dev_cap + 64) ||
-        !ensure(c, c->one_meta, sizeof(OneMeta)))
-        return VBZ_OUT_OF_MEMORY_ERROR;
-    if (!c->pinned) {
-        if (hipHostMalloc(&c->pinned, 256, hipHostMallocDefault) != hipSuccess) return VBZ_OUT_OF_MEMORY_ERROR;
-        c->pinned_cap = 256;
+    // Device buffers: one_in = [OneMeta | 64 bytes | the read], one_out = the result.  Pinned host memory: [OneMeta | pad to 256 | the
+    // read on its way in | 16 words of hand-back header + the result on its way out] -- reads and results of up to ONE_PINNED_MAX go
+    // through it: ONE host-to-device copy from pinned memory (descriptors and read together), and on the way back no copy call and no
+    // stream synchronisation at all: hand_back_kernel writes the result into the pinned area and raises a flag this thread polls
+    // (a synchronisation costs 10-20 us, the two copies of a pageable call as much again; 100 KB over the link 2 us).  Larger calls
+    // keep the plain copies (a host memcpy of megabytes costs more than it saves: DESIGN 4.7).
+    const bool small_in = src_size <= ONE_PINNED_MAX, small_out = (compress ? dev_cap : dst_cap) <= ONE_PINNED_MAX;
+    const size_t in_off = 256, out_off = in_off + (small_in ? (((size_t)src_size + 63) & ~(size_t)63) : 0);
+    const uint32_t out_cap = small_out ? (compress ? dev_cap : dst_cap) : 0u;
+    const size_t pin_need = out_off + 64 + out_cap + 64;
+    if (!ensure(c, c->one_in, (size_t)src_size + 512) || !ensure(c, c->one_out, (size_t)dev_cap + 64)) return VBZ_OUT_OF_MEMORY_ERROR;
+    if (c->pinned_cap < pin_need) {
+        if (c->pinned) (void)hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_cap = 0;
+        const size_t want = std::max<size_t>(pin_need, 1u << 20);
+        if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) return VBZ_OUT_OF_MEMORY_ERROR;
+        c->pinned_cap = want;
     }
-    OneMeta* hm = (OneMeta*)c->pinned;
+    uint8_t* pin = (uint8_t*)c->pinned;
+    OneMeta* hm = (OneMeta*)pin;
     hm->src_off = 0;
     hm->dst_off = 0;
     hm->src_size = src_size;
@@ -1257,18 +1273,24 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     hm->result = VBZ_DEVICE_ERROR;
     hm->pad = 0;
     hipStream_t s = c->stream;
+    uint8_t* din = (uint8_t*)c->one_in.p;       // device: the descriptors, then the read at + 256
     bool ok = true;
-    if (src_size) ok &= hipMemcpyAsync(c->one_in.p, src, src_size, hipMemcpyHostToDevice, s) == hipSuccess;
-    ok &= hipMemcpyAsync(c->one_meta.p, hm, sizeof(OneMeta), hipMemcpyHostToDevice, s) == hipSuccess;
+    if (small_in) {
+        if (src_size) memcpy(pin + in_off, src, src_size);
+        ok &= hipMemcpyAsync(din, pin, in_off + src_size, hipMemcpyHostToDevice, s) == hipSuccess;
+    } else {
+        ok &= hipMemcpyAsync(din, pin, sizeof(OneMeta), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok &= hipMemcpyAsync(din + in_off, src, src_size, hipMemcpyHostToDevice, s) == hipSuccess;
+    }
     if (!ok) {
         set_error(c, "host to device copy failed");
         return device_failure();
     }
-    OneMeta* dm = (OneMeta*)c->one_meta.p;
+    OneMeta* dm = (OneMeta*)din;
     vbz_gpu_batch bt;
     memset(&bt, 0, sizeof bt);
     bt.n_reads = 1;
-    bt.src = c->one_in.p;
+    bt.src = din + in_off;
     bt.src_off = &dm->src_off;
     bt.src_size = &dm->src_size;
     bt.src_bytes = src_size;
@@ -1280,19 +1302,51 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     int rc = compress ? compress_batch_impl(c, &bt, o, sized) : decompress_batch_impl(c, &bt, o, sized);
     if (rc != 0) return device_failure();
     uint32_t result = VBZ_DEVICE_ERROR;
-    // (result, synchronise, bytes, synchronise.  Both copies behind ONE synchronisation -- the result word and a guess of the bytes into
-    // pinned staging, then a memcpy -- was measured for results up to 1 MB: 0.204 against 0.200 ms per vbz_compress call of a 100 k-sample
-    // read: the second round trip is not what the call waits for.)
-    if (hipMemcpyAsync(&hm->result, &dm->result, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-        hipStreamSynchronize(s) != hipSuccess) {
-        set_error(c, "kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
-        return device_failure();
+    uint32_t have = 0;   // bytes of the result that have arrived in pinned memory
+    volatile uint32_t* hb = (volatile uint32_t*)(pin + out_off);
+    if (small_out) {
+        const uint32_t seq = ++c->one_seq ? c->one_seq : ++c->one_seq;   // (never 0: what the flag holds between calls)
+        hb[2] = 0;
+        if (launch_hand_back(&dm->result, (const uint8_t*)c->one_out.p, (uint32_t*)(pin + out_off), out_cap, seq, s) != hipSuccess) {
+            set_error(c, "hand-back launch failed: %s", hipGetErrorString(hipGetLastError()));
+            return device_failure();
+        }
+        // poll the flag; now and then ask the stream whether it is still alive (a faulting kernel never raises the flag)
+        bool done = false;
+        for (uint64_t spin = 0; !done; ++spin) {
+            if (__atomic_load_n((const uint32_t*)&hb[2], __ATOMIC_ACQUIRE) == seq) {
+                done = true;
+                break;
+            }
+            if ((spin & 0xFFFu) == 0xFFFu) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) {   // the stream has drained: the flag is there, or the launch chain failed
+                    done = __atomic_load_n((const uint32_t*)&hb[2], __ATOMIC_ACQUIRE) == seq;
+                    break;
+                }
+                if (q != hipErrorNotReady) break;
+            }
+        }
+        if (!done) {
+            (void)hipStreamSynchronize(s);
+            set_error(c, "kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
+            return device_failure();
+        }
+        result = hb[0];
+        have = hb[1];
+    } else {
+        if (hipMemcpyAsync(&hm->result, &dm->result, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            set_error(c, "kernel execution failed: %s", hipGetErrorString(hipGetLastError()));
+            return device_failure();
+        }
+        result = hm->result;
     }
-    result = hm->result;
     if (result == VBZ_DEVICE_ERROR) return device_failure();
     if (result >= VBZ_FIRST_ERROR) return result;
     if (result > dst_cap) return VBZ_DESTINATION_SIZE_ERROR;
-    if (result && (hipMemcpyAsync(dst, c->one_out.p, result, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)) {
+    if (have) memcpy(dst, pin + out_off + 64, have);
+    if (result > have && (hipMemcpyAsync((uint8_t*)dst + have, (const uint8_t*)c->one_out.p + have, result - have, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                          hipStreamSynchronize(s) != hipSuccess)) {
         set_error(c, "device to host copy failed");
         return device_failure();
     }
