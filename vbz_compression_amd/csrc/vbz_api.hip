@@ -748,12 +748,13 @@ int validate_descriptors(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, ReadBatch* rb)
     return 0;
 }
 
-int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+// own_descriptors: the table is the library's own (the single-buffer API: one read, slots it has just allocated) -- nothing to validate
+int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized, bool own_descriptors = false)
 {
     const uint32_t n = bt->n_reads;
     if (n == 0) return 0;
     ReadBatch rb = to_rb(bt);
-    if (validate_descriptors(c, bt, &rb) != 0) return -1;
+    if (!own_descriptors && validate_descriptors(c, bt, &rb) != 0) return -1;
     const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n, false);
     if (by_shape || !routing_applies(c, o, bt->src_bytes, n)) return compress_group(c, rb, bt->src_bytes, o, sized, by_shape);
     Routed r;
@@ -770,14 +771,14 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     return rc;
 }
 
-int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized)
+int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized, bool own_descriptors = false)
 {
     const uint32_t n = bt->n_reads;
     c->last_frames = 0;
     if (n == 0) return 0;
     hipStream_t s = c->stream;
     ReadBatch rb = to_rb(bt);
-    if (validate_descriptors(c, bt, &rb) != 0) return -1;
+    if (!own_descriptors && validate_descriptors(c, bt, &rb) != 0) return -1;
     if (sized) {  // vbz.cpp:332-366: strip the header, the original size becomes the exact destination size
         if (!ensure(c, c->meta, (size_t)n * 24 + 512)) return -1;
         MetaCarver mc(c->meta.p);
@@ -1299,7 +1300,7 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     bt.dst_cap = &dm->dst_cap;
     bt.dst_bytes = dev_cap;
     bt.result = &dm->result;
-    int rc = compress ? compress_batch_impl(c, &bt, o, sized) : decompress_batch_impl(c, &bt, o, sized);
+    int rc = compress ? compress_batch_impl(c, &bt, o, sized, true) : decompress_batch_impl(c, &bt, o, sized, true);
     if (rc != 0) return device_failure();
     uint32_t result = VBZ_DEVICE_ERROR;
     uint32_t have = 0;   // bytes of the result that have arrived in pinned memory
