@@ -689,6 +689,61 @@ def test_c_abi_cross_codec_round_trips():
                             assert g.tobytes() == r.tobytes()   # no entropy stage: byte-identical output
 
 
+def test_single_buffer_calls_across_the_pinned_staging_boundaries():
+    """vbz_compress / vbz_decompress stage reads and results of up to 1 MB through pinned host memory and take the result back through
+    a flag the calling thread polls (vbz_api.hip run_one, hand_back_kernel); larger ones use plain copies.  Sizes on both sides of the
+    boundary (for the input, for the result, for the worst-case slot), empty and tiny reads, an incompressible read whose result is
+    larger than its input, error verdicts -- from four threads at once, several hundred calls each: every result byte for byte what
+    the oracle says, and what the batched entry points write."""
+    import threading
+
+    import gpu_util as G
+    from vbz_compression_amd import _lib, vbz
+
+    rng = np.random.default_rng(77)
+    go, oo = _lib.CompressionOptions(True, 2, 1, 1), O.options(True, 2, 1, 1)
+    sizes = [0, 1, 7, 300, 5000, 100000, 262000, 262144, 262200, 466000, 466100, 524288, 524300, 700000]   # samples: 1 MB = 524 288
+    reads = [O.synth_signal(5, 900 + i, n) for i, n in enumerate(sizes)]
+    reads.append(rng.integers(-32768, 32767, 300000, dtype=np.int16))       # noise: the frame is larger than half the input
+    reads.append(rng.integers(-32768, 32767, 520000, dtype=np.int16))       # ... and larger than 1 MB from an input below it
+    batched = [G.compress([a], go)[0] for a in reads]     # (a call of its own each: the launch paths go by the shape of the call)
+    errors = []
+
+    def work(k):
+        try:
+            for rep in range(3):
+                for i in range(k, len(reads), 4):
+                    a = reads[i]
+                    g = vbz.compress_raw(a, go)
+                    if isinstance(g, int) or g.tobytes() != batched[i].tobytes():
+                        errors.append((i, "compress differs from the batched call"))
+                        continue
+                    back = vbz.decompress_raw(g, a.nbytes, go)
+                    if isinstance(back, int) or back.tobytes() != a.tobytes():
+                        errors.append((i, "round trip"))
+                    ref = O.compress(a, oo)
+                    back = vbz.decompress_raw(ref, a.nbytes, go)
+                    if isinstance(back, int) or back.tobytes() != a.tobytes():
+                        errors.append((i, "reference frame"))
+                    if a.nbytes >= 16:   # error verdicts come back through the same flag
+                        bad = vbz.decompress_raw(g[: len(g) // 2], a.nbytes, go)
+                        want = O.decompress(g[: len(g) // 2], a.nbytes, oo)
+                        if not isinstance(bad, int) and (isinstance(want, int) or want.tobytes() != bad.tobytes()):
+                            errors.append((i, "truncated frame accepted"))
+                        small = vbz.decompress_raw(g, a.nbytes - 2, go)
+                        if not isinstance(small, int):
+                            errors.append((i, "a destination that is too small"))
+        except Exception as e:  # noqa: BLE001
+            errors.append(("exception", repr(e)))
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_c_abi_calls_from_many_threads_overlap():
     """The reference's calls are re-entrant and stateless; its callers parallelise by calling from many threads
     (SURVEY 8b "Threading").  Here a call borrows one of a pool of contexts, so concurrent calls must (a) stay correct
