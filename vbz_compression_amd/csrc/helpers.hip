@@ -67,8 +67,11 @@ __global__ __launch_bounds__(1024) void plan_scratch_kernel(uint32_t n, const ui
 // the segment tables (and the grids) for -- the arena's extent; reads may alias their source bytes, so the sizes can add up to
 // more: a read whose segments would not fit keeps ONE segment and gets gate_out[i] = E_OOM (a per-read error instead of
 // writes behind the tables); gate_out[i] is the input gate otherwise (0 without one).
+// sp (sp.off != nullptr; n <= 1024 only): the scratch plan of plan_scratch_kernel for the same reads in the same launch -- a call of few
+// reads is a chain of short dependent launches, and this one saves two of them (the plan and the copy of the gates in front of it):
+// sp.gate[i] = gate_out[i], or E_OOM for a read whose scratch slot does not fit.
 __global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32_t* size, uint32_t unit, const uint32_t* gate, uint32_t max_segs,
-                                                        uint32_t* seg_first, uint32_t* gate_out)
+                                                        uint32_t* seg_first, uint32_t* gate_out, ScratchPlan sp)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
@@ -111,6 +114,38 @@ __global__ __launch_bounds__(1024) void seg_plan_kernel(uint32_t n, const uint32
         __syncthreads();
     }
     if (tid == 0) seg_first[n] = carry_s;
+    if (sp.off == nullptr) return;
+    // ---- the scratch plan (plan_scratch_kernel's arithmetic; n <= 1024: thread i has just written gate_out[i] itself)
+    __shared__ uint64_t ssum[16];
+    __syncthreads();
+    const uint32_t i = (uint32_t)tid;
+    uint64_t slot = 0;
+    uint32_t g = 0;
+    bool gated = false;
+    if (i < n) {
+        g = gate_out[i];
+        gated = g >= GATE_SKIP;
+        const bool empty = gated && g != E_OOM;
+        const uint64_t bound = empty ? 0 : ((uint64_t)size[i] * sp.num + sp.den - 1) / sp.den + 8;
+        slot = ((bound + 15) & ~15ull) + 48;
+    }
+    uint64_t inc = slot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) ssum[w] = inc;
+    __syncthreads();
+    uint64_t pre = 0;
+    for (int k = 0; k < w; ++k) pre += ssum[k];
+    if (i < n) {
+        const uint64_t o = pre + inc - slot;
+        sp.off[i] = o + 16;
+        const uint64_t cc = slot - 32;
+        sp.cap[i] = cc > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)cc;
+        sp.gate[i] = gated ? g : ((o + slot > sp.limit) ? E_OOM : 0u);
+    }
 }
 
 // ---- per-read routing (vbz_api.hip): the reads of `min_bytes` raw bytes and more, in batch order, at most max_reads of them and
@@ -350,9 +385,11 @@ hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mu
 }
 
 hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t max_segs, uint32_t* seg_first,
-                           uint32_t* gate_out, hipStream_t s)
+                           uint32_t* gate_out, const ScratchPlan* scratch, hipStream_t s)
 {
-    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, s, n, size, unit_bytes, gate, max_segs, seg_first, gate_out);
+    ScratchPlan sp = {};
+    if (scratch && n <= 1024) sp = *scratch;
+    hipLaunchKernelGGL(seg_plan_kernel, dim3(1), dim3(1024), 0, s, n, size, unit_bytes, gate, max_segs, seg_first, gate_out, sp);
     return hipGetLastError();
 }
 

@@ -330,7 +330,9 @@ struct SegTables
 };
 
 // segment tables for a batch whose raw bytes span `raw_arena_bytes`; sizes (device) are the reads' raw byte counts
-int plan_segments(vbz_gpu_ctx* c, uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint64_t raw_arena_bytes, uint32_t unit, SegTables* t)
+// scratch (nullable): the group's scratch plan in the same launch (calls of up to 1024 reads: *scratch_done says whether it was)
+int plan_segments(vbz_gpu_ctx* c, uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint64_t raw_arena_bytes, uint32_t unit, SegTables* t,
+                  const ScratchPlan* scratch = nullptr, bool* scratch_done = nullptr)
 {
     const uint64_t segs = raw_arena_bytes / unit + n + 1;
     if (segs > 0x7FFFFFFFull) {
@@ -346,7 +348,8 @@ int plan_segments(vbz_gpu_ctx* c, uint32_t n, const uint32_t* raw_size, const ui
     t->off = mc.take<uint64_t>(segs);
     t->run = mc.take<uint32_t>(segs);
     Timed tm(c, "seg_plan");
-    HIPCHK(c, launch_seg_plan(n, raw_size, unit, gate, t->max_segs, t->first, t->gate, c->stream), "seg_plan launch");
+    HIPCHK(c, launch_seg_plan(n, raw_size, unit, gate, t->max_segs, t->first, t->gate, scratch, c->stream), "seg_plan launch");
+    if (scratch_done) *scratch_done = scratch != nullptr && n <= 1024;
     return 0;
 }
 
@@ -382,7 +385,30 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         return 0;
     }
     SegTables seg;
-    if (segmented && plan_segments(c, n, bt->src_size, rb_in.gate, bt->src_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
+    // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207): the scratch slots are planned with the segments when they can be
+    const bool both_stages = o->integer_size != 0 && o->zstd_compression_level != 0;
+    uint32_t num = 1, den = 1;
+    size_t scratch_need = 0;
+    uint64_t* svb_off = nullptr;
+    uint32_t *svb_cap = nullptr, *svb_size = nullptr, *gate = nullptr, *deep_d = nullptr;
+    bool scratch_planned = false;
+    MetaCarver mc(nullptr);
+    if (both_stages) {
+        svb_factor(o->integer_size, o->perform_delta_zig_zag, &num, &den);
+        scratch_need = (size_t)(((unsigned __int128)bt->src_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
+        if (!ensure(c, c->scratch, scratch_need)) return -1;
+        if (!ensure(c, c->meta, (size_t)n * 40 + 256)) return -1;
+        mc = MetaCarver(c->meta.p);
+        svb_off = mc.take<uint64_t>(n);
+        svb_cap = mc.take<uint32_t>(n);
+        svb_size = mc.take<uint32_t>(n);
+        gate = mc.take<uint32_t>(n);
+        deep_d = mc.take<uint32_t>(n);
+    }
+    const ScratchPlan splan = { num, den, c->scratch.cap, svb_off, svb_cap, gate };
+    if (segmented && plan_segments(c, n, bt->src_size, rb_in.gate, bt->src_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg,
+                                   both_stages ? &splan : nullptr, &scratch_planned) != 0)
+        return -1;
     if (segmented) rb.gate = seg.gate;   // (E_OOM for a read whose segments do not fit the tables)
     if (o->integer_size != 0 && o->zstd_compression_level == 0) {  // vbz.cpp:171-192: svb straight into dst
         Timed t(c, "svb_encode");
@@ -398,23 +424,11 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         HIPCHK(c, launch_zstd_encode(rb, bt->src_size, 0, nullptr, hdr, nullptr, nullptr, nullptr, c->trailers, nullptr, nullptr, false, false, nullptr, s), "zstd_encode launch");
         return 0;
     }
-    // svb into scratch, then the entropy stage into dst (vbz.cpp:163-207)
-    uint32_t num, den;
-    svb_factor(o->integer_size, o->perform_delta_zig_zag, &num, &den);
     // the long-repeat matcher (every level: the reference's libzstd matches at every level; its workspace is the top of the
     // destination slots)
     const bool matcher = !segmented && c->zero_run_sequences && c->long_repeats;
-    const size_t scratch_need = (size_t)(((unsigned __int128)bt->src_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
-    if (!ensure(c, c->scratch, scratch_need)) return -1;
-    if (!ensure(c, c->meta, (size_t)n * 40 + 256)) return -1;
-    MetaCarver mc(c->meta.p);
-    uint64_t* svb_off = mc.take<uint64_t>(n);
-    uint32_t* svb_cap = mc.take<uint32_t>(n);
-    uint32_t* svb_size = mc.take<uint32_t>(n);
-    uint32_t* gate = mc.take<uint32_t>(n);
-    uint32_t* deep_d = mc.take<uint32_t>(n);
-    if (rb.gate) HIPCHK(c, hipMemcpyAsync(gate, rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
-    {
+    if (!scratch_planned) {
+        if (rb.gate) HIPCHK(c, hipMemcpyAsync(gate, rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
         Timed t(c, "plan_scratch");
         HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, rb.gate != nullptr, s), "plan launch");
     }
@@ -565,10 +579,23 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
         return 0;
     }
     SegTables seg;
-    if (segmented && plan_segments(c, n, rb.dst_cap, rb.gate, dst_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg) != 0) return -1;
+    // (both stages: the scratch slots are planned with the segments when they can be -- two launches less for a call of few reads)
+    const bool both_stages = o->integer_size != 0 && o->zstd_compression_level != 0;
+    uint32_t num = 1, den = 1;
+    size_t scratch_need = 0;
+    if (both_stages) {
+        svb_factor(o->integer_size, false, &num, &den);  // any code length may appear in a foreign stream
+        scratch_need = (size_t)(((unsigned __int128)dst_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
+        if (!ensure(c, c->scratch, scratch_need)) return -1;
+    }
+    const ScratchPlan splan = { num, den, c->scratch.cap, svb_off, svb_cap, gate };
+    bool scratch_planned = false;
+    if (segmented && plan_segments(c, n, rb.dst_cap, rb.gate, dst_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg, both_stages ? &splan : nullptr,
+                                   &scratch_planned) != 0)
+        return -1;
     const bool gate_in = segmented || rb.gate != nullptr;
     if (gate_in) {   // (the caller's gate; E_OOM for a read whose segments do not fit the tables)
-        HIPCHK(c, hipMemcpyAsync(gate, segmented ? seg.gate : rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
+        if (!scratch_planned) HIPCHK(c, hipMemcpyAsync(gate, segmented ? seg.gate : rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
         rb.gate = gate;
     }
     if (o->zstd_compression_level == 0) {
@@ -590,11 +617,7 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
     }
     // entropy stage into scratch (sized for the largest svb stream the expected output can have),
     // then svb decode into dst (vbz.cpp:234-299)
-    uint32_t num, den;
-    svb_factor(o->integer_size, false, &num, &den);  // any code length may appear in a foreign stream
-    const size_t scratch_need = (size_t)(((unsigned __int128)dst_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
-    if (!ensure(c, c->scratch, scratch_need)) return -1;
-    {
+    if (!scratch_planned) {
         Timed t(c, "plan_scratch");
         HIPCHK(c, launch_plan_scratch(n, rb.dst_cap, num, den, c->scratch.cap, svb_off, svb_cap, gate, gate_in, s), "plan launch");
     }

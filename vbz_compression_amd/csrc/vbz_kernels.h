@@ -223,8 +223,18 @@ hipError_t launch_plan_scratch(uint32_t n, const uint32_t* raw_size, uint32_t mu
 // (seg_first[n] = total); reads whose gate is an error get one segment.  max_segs = the size of the caller's segment tables
 // (and grids): reads whose segments would not fit them (sources that alias each other can add up to more than the arena)
 // keep one segment and get gate_out[i] = E_OOM; gate_out[i] = gate[i] (or 0) otherwise.  gate_out may be gate.
+// scratch (nullable; used when n <= 1024): the scratch plan of launch_plan_scratch for the same reads in the same launch -- off / cap as
+// there, gate[i] = gate_out[i] or E_OOM for a read whose slot does not fit.
+struct ScratchPlan
+{
+    uint32_t num, den;
+    uint64_t limit;
+    uint64_t* off;
+    uint32_t* cap;
+    uint32_t* gate;
+};
 hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t max_segs, uint32_t* seg_first,
-                           uint32_t* gate_out, hipStream_t s);
+                           uint32_t* gate_out, const ScratchPlan* scratch, hipStream_t s);
 // per-read routing: see route_reads_kernel (helpers.hip).  raw_size[i] = the read's raw (decoded) byte count.
 hipError_t launch_route_reads(const ReadBatch& b, const uint32_t* raw_size, uint32_t min_bytes, uint32_t max_reads, uint64_t max_bytes, uint32_t* gate_small,
                               uint64_t* l_src_off, uint32_t* l_src_size, uint64_t* l_dst_off, uint32_t* l_dst_cap, uint32_t* l_gate, uint32_t* l_map,
