@@ -5,7 +5,7 @@ kernel with its start (relative to the chain's first kernel), duration and the g
     rocprofv3 --kernel-trace -f csv -d gpurun_out/chain -- python3 bench.py --workload config4 --buffers 1 --steps 5
     python3 tools/launch_chain.py gpurun_out/chain
 
-A chain starts at plan_scratch_kernel; encode chains contain zstd_encode_kernel, decode chains zstd_decode_kernel."""
+A chain starts at a call's first planning launch; encode chains contain zstd_encode_kernel, decode chains zstd_decode_kernel."""
 import csv
 import glob
 import sys
@@ -21,7 +21,9 @@ for s, e, name in rows:
     short = name.replace("vbzhip::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     if "vbzhip" not in name:
         continue
-    if "plan_scratch_kernel" in name or cur is None:
+    # a call's chain begins with its planning launches (descriptor check, segment plan, scratch plan: whichever comes first)
+    starter = any(k in name for k in ("validate_batch_kernel", "seg_plan_kernel", "plan_scratch_kernel"))
+    if cur is None or (starter and any(("zstd_" in k or "svb_" in k or "hand_back" in k) for _, _, k in cur)):
         cur = []
         chains.append(cur)
     cur.append((s, e, short))

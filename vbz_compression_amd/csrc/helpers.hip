@@ -294,25 +294,34 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(ReadBatch b, uint32_t h
     if (threadIdx.x == 0) b.result[r] = n + hdr;
 }
 
-// The single-buffer API's hand-back (vbz_api.hip run_one): one workgroup copies a read's result -- `*result` bytes at `src`, if they are
-// no error code and fit `host_cap` -- straight into pinned HOST memory, writes the result word there and then raises the flag the
-// host polls: no device-to-host copy call, no stream synchronisation on the way back.  host[0] = result, host[1] = bytes copied,
-// host[2] = flag (the call's sequence number), the bytes from host + 16 on.
-__global__ __launch_bounds__(1024) void hand_back_kernel(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq)
+// The single-buffer API's hand-back (vbz_api.hip run_one): HAND_BACK_WGS workgroups copy a read's result -- `*result` bytes at `src`, if
+// they are no error code and fit `host_cap` -- straight into pinned HOST memory (one workgroup alone moved 84 KB over the link in 9.5 us:
+// the writes a CU keeps in flight, not the link, set that rate); the workgroup that finishes last (a ticket in device memory, which
+// it takes back to zero for the next call) writes the result word and then raises the flag the host polls: no device-to-host copy
+// call, no stream synchronisation on the way back.  host[0] = result, host[1] = bytes copied, host[2] = flag (the call's sequence
+// number), the bytes from host + 16 on.
+constexpr uint32_t HAND_BACK_WGS = 16;
+__global__ __launch_bounds__(256) void hand_back_kernel(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq,
+                                                        uint32_t* ticket)
 {
+    __shared__ uint32_t last_s;
     const uint32_t r = *result;
     uint32_t n = 0;
     if (r < E_FIRST && r <= host_cap) n = r;
     uint8_t* d = reinterpret_cast<uint8_t*>(host + 16);
     const uint32_t nv = n >> 4;
-    for (uint32_t i = threadIdx.x; i < nv; i += 1024) {   // (src is the context's own allocation: 16-byte aligned)
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nv; i += HAND_BACK_WGS * 256u) {   // (src is the context's own allocation: 16-byte aligned)
         const uint4 v = *reinterpret_cast<const uint4*>(src + 16ull * i);
         *reinterpret_cast<uint4*>(d + 16ull * i) = v;
     }
-    for (uint32_t i = (nv << 4) + threadIdx.x; i < n; i += 1024) d[i] = src[i];
+    if (blockIdx.x == 0)
+        for (uint32_t i = (nv << 4) + threadIdx.x; i < n; i += 256) d[i] = src[i];
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) last_s = atomicAdd(ticket, 1u) == HAND_BACK_WGS - 1u ? 1u : 0u;
+    __syncthreads();
+    if (last_s && threadIdx.x == 0) {
+        *ticket = 0;
         host[0] = r;
         host[1] = n;
         __threadfence_system();
@@ -425,9 +434,9 @@ hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* sr
     return hipGetLastError();
 }
 
-hipError_t launch_hand_back(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq, hipStream_t s)
+hipError_t launch_hand_back(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq, uint32_t* ticket, hipStream_t s)
 {
-    hipLaunchKernelGGL(hand_back_kernel, dim3(1), dim3(1024), 0, s, result, src, host, host_cap, seq);
+    hipLaunchKernelGGL(hand_back_kernel, dim3(HAND_BACK_WGS), dim3(256), 0, s, result, src, host, host_cap, seq, ticket);
     return hipGetLastError();
 }
 

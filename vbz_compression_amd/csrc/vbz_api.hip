@@ -1331,7 +1331,7 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     if (small_out) {
         const uint32_t seq = ++c->one_seq ? c->one_seq : ++c->one_seq;   // (never 0: what the flag holds between calls)
         hb[2] = 0;
-        if (launch_hand_back(&dm->result, (const uint8_t*)c->one_out.p, (uint32_t*)(pin + out_off), out_cap, seq, s) != hipSuccess) {
+        if (launch_hand_back(&dm->result, (const uint8_t*)c->one_out.p, (uint32_t*)(pin + out_off), out_cap, seq, &dm->pad, s) != hipSuccess) {
             set_error(c, "hand-back launch failed: %s", hipGetErrorString(hipGetLastError()));
             return device_failure();
         }

@@ -250,7 +250,8 @@ hipError_t launch_parse_sized(uint32_t n, const uint8_t* src, const uint64_t* sr
 // E_DESTINATION_SIZE (destination slot outside [0, dst_bytes)); 64-bit arithmetic
 // The single-buffer API's hand-back: `*result` bytes at `src` (if no error code and <= host_cap) into pinned host memory at host + 16
 // words, the result word to host[0], the bytes copied to host[1], then host[2] = seq (system-scope release): what the host polls.
-hipError_t launch_hand_back(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq, hipStream_t s);
+// ticket: one zeroed word of device memory the launch's workgroups count themselves on (left at zero).
+hipError_t launch_hand_back(const uint32_t* result, const uint8_t* src, uint32_t* host, uint32_t host_cap, uint32_t seq, uint32_t* ticket, hipStream_t s);
 hipError_t launch_validate_batch(uint32_t n, const uint64_t* src_off, const uint32_t* src_size, uint64_t src_bytes, const uint64_t* dst_off,
                                  const uint32_t* dst_cap, uint64_t dst_bytes, uint32_t* gate, hipStream_t s);
 // integer_size == 0 && level == 0: per-read copy (reference vbz/vbz.cpp:130-133)
