@@ -257,6 +257,19 @@ def test_whole_suite_on_the_large_read_path():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+def test_svb_suites_with_the_scan_launches():
+    """The segmented svb kernels of a call with few segments add up the lengths in front of a segment by themselves; a call with
+    more than 1024 segments (32 MB of samples) gets scan launches between the passes instead.  VBZ_HIP_SEG_SELF_MAX=0 gives every
+    call the scan launches: the bit-exact svb tests, the known answers and the error verdicts must not notice (the default is what
+    test_whole_suite_on_the_large_read_path runs)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VBZ_HIP_SEGMENTED="1", VBZ_HIP_SEG_SELF_MAX="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "svb or c_abi_known_answers or c_abi_error or batch_ragged or unaligned_arena or descriptor_tables"],
+                       capture_output=True, text=True, timeout=3000, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_whole_suite_on_the_one_wavefront_path():
     """The other way round: small batches -- most of what the other tests send -- take the large-read path by default (a call
     with a handful of reads cannot fill the device with one wavefront per read), so the kernels of the headline workload, one

@@ -457,17 +457,78 @@ __device__ __forceinline__ bool seg_locate(const uint32_t* seg_first, uint32_t n
     return true;
 }
 
-template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY>
+// SELF (calls whose segment tables are small: SEG_SELF_MAX): no scan launch between the passes -- a workgroup adds up what the segments
+// of its read in front of it have announced by itself (a few loads per thread, the values sit in the L2), and a read's first
+// workgroup does what the scan kernel's first thread does (the read's result).  A call of few reads is a chain of short dependent
+// launches: each one saved is 4.5 us.  The loads grow with the square of the table (1024 segments: 4 MB out of the L2 per pass).
+constexpr uint32_t SEG_SELF_MAX = 1024;
+static uint32_t seg_self_max()
+{
+    static const uint32_t v = [] {
+        const char* e = getenv("VBZ_HIP_SEG_SELF_MAX");   // 0: always the scan launches
+        return e ? (uint32_t)strtoul(e, nullptr, 10) : SEG_SELF_MAX;
+    }();
+    return v;
+}
+
+// all 256 threads: { sum of arr[lo .. mid), sum of arr[lo .. hi) }, lo <= mid <= hi
+__device__ __forceinline__ void seg_sums(const uint32_t* arr, uint32_t lo, uint32_t mid, uint32_t hi, uint64_t* sums_s, uint64_t& before, uint64_t& total)
+{
+    uint64_t a = 0, t = 0;
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += WG) {
+        const uint32_t v = arr[i];
+        t += v;
+        a += i < mid ? v : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        a += __shfl_xor(a, d, 64);
+        t += __shfl_xor(t, d, 64);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sums_s[2 * (threadIdx.x >> 6)] = a;
+        sums_s[2 * (threadIdx.x >> 6) + 1] = t;
+    }
+    __syncthreads();
+    before = sums_s[0] + sums_s[2] + sums_s[4] + sums_s[6];
+    total = sums_s[1] + sums_s[3] + sums_s[5] + sums_s[7];
+}
+
+template <int ELEM, bool ZZ, bool I16ZZ, bool COUNT_ONLY, bool SELF = false>
 __global__ __launch_bounds__(WG) void svb_seg_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, const uint32_t* seg_first,
                                                             uint32_t* seg_bytes, const uint64_t* seg_off)
 {
     constexpr int SEG = WG * Vpl<ELEM>::value * SEG_TILES;
     __shared__ __attribute__((aligned(16))) uint8_t stage[COUNT_ONLY ? 16 : EncStage<ELEM, I16ZZ>::value];
     __shared__ uint32_t wsum[4];
+    __shared__ uint64_t sums_s[8];
     uint32_t r, k;
     if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
     const int tid = threadIdx.x;
     if (COUNT_ONLY && tid == 0) seg_bytes[blockIdx.x] = 0;
+    uint64_t self_off = 0;
+    if (SELF && !COUNT_ONLY) {
+        // the data offset of this segment, and (first workgroup of the read) the read's result: svb_seg_encode_scan_kernel's work
+        uint64_t total;
+        seg_sums(seg_bytes, seg_first[r], blockIdx.x, seg_first[r + 1], sums_s, self_off, total);
+        if (k == 0 && tid == 0 && !(b.gate && b.gate[r] == GATE_SKIP)) {
+            uint32_t res;
+            if (b.gate && b.gate[r] >= E_FIRST) res = b.gate[r];
+            else {
+                const uint32_t size0 = b.src_size[r];
+                res = svb_encode_check<ELEM, I16ZZ>(size0, b.dst_cap[r], hdr, strict_cap);
+                if (!res) {
+                    res = hdr + ((size0 / ELEM + 3u) >> 2) + (uint32_t)total;
+                    if (hdr) {
+                        uint8_t* o4 = b.dst + b.dst_off[r];
+                        for (int j = 0; j < 4; ++j) o4[j] = (uint8_t)(size0 >> (8 * j));
+                    }
+                }
+            }
+            b.result[r] = res;
+        }
+    }
     if (b.gate && b.gate[r] >= GATE_SKIP) return;
     const uint32_t size = b.src_size[r];
     if (svb_encode_check<ELEM, I16ZZ>(size, b.dst_cap[r], hdr, strict_cap)) return;
@@ -482,7 +543,7 @@ __global__ __launch_bounds__(WG) void svb_seg_encode_kernel(ReadBatch b, uint32_
         const uint64_t bytes = svb_encode_range<ELEM, ZZ, I16ZZ, true>(in, first, end, nullptr, nullptr, stage, wsum);
         if (tid == 0) seg_bytes[blockIdx.x] = (uint32_t)bytes;
     } else {
-        (void)svb_encode_range<ELEM, ZZ, I16ZZ, false>(in, first, end, out, out + keyLen + seg_off[blockIdx.x], stage, wsum);
+        (void)svb_encode_range<ELEM, ZZ, I16ZZ, false>(in, first, end, out, out + keyLen + (SELF ? self_off : seg_off[blockIdx.x]), stage, wsum);
     }
 }
 
@@ -697,25 +758,51 @@ __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
 // segment its data offset and decides the read's verdict (the stream is good iff the announced total equals the data
 // bytes present -- the same predicate streamvbyte_validate_stream computes); zig-zag streams then need the delta total
 // of every segment (pass 2, decode without storing) and a second scan before the storing pass.
-template <int ELEM, bool ZZ, bool I16ZZ, int MODE>
+// SELF (see svb_seg_encode_kernel): no scan launches -- MODE 2 / 0 workgroups add up the announced lengths (seg_val, left by MODE 1)
+// in front of them and over the whole read (the verdict: good iff the total equals the bytes present), MODE 2 leaves its delta
+// totals in seg_run_io and MODE 0 adds those up too; a read's first MODE 0 workgroup writes the read's result.
+template <int ELEM, bool ZZ, bool I16ZZ, int MODE, bool SELF = false>
 __global__ __launch_bounds__(WG) void svb_seg_decode_kernel(ReadBatch b, const uint32_t* seg_first, uint32_t* seg_val, const uint64_t* seg_pos,
-                                                            const uint32_t* seg_run)
+                                                            uint32_t* seg_run_io)
 {
+    const uint32_t* seg_run = seg_run_io;
     constexpr int SEG = WG * Vpl<ELEM>::value * SEG_TILES;
     constexpr int STAGE = MODE == 1 ? 16 : WG * Vpl<ELEM>::value * 4 + 48;
     __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
     __shared__ uint32_t wsum[4];
+    __shared__ uint64_t sums_s[8];
     uint32_t r, k;
     if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
     const int tid = threadIdx.x;
-    if (MODE != 0 && tid == 0) seg_val[blockIdx.x] = 0;
+    if (MODE != 0 && tid == 0) (SELF && MODE == 2 ? seg_run_io : seg_val)[blockIdx.x] = 0;
+    uint64_t self_pos = 0, self_total = 0, self_run = 0;
+    if (SELF && MODE != 1) {
+        seg_sums(seg_val, seg_first[r], blockIdx.x, seg_first[r + 1], sums_s, self_pos, self_total);
+        if (MODE == 0 && ZZ) {
+            uint64_t dummy;
+            seg_sums(seg_run, seg_first[r], blockIdx.x, seg_first[r + 1], sums_s, self_run, dummy);
+        }
+        if (MODE == 0 && k == 0 && tid == 0 && !(b.gate && b.gate[r] == GATE_SKIP)) {   // svb_seg_decode_scan_kernel<.., VERDICT>'s first thread
+            uint32_t res0;
+            if (b.gate && b.gate[r] >= E_FIRST) res0 = b.gate[r];
+            else if (b.src_size[r] >= E_FIRST) res0 = b.src_size[r];
+            else if (!svb_decode_check<ELEM, I16ZZ>(b.src_size[r], b.dst_cap[r], res0)) {
+                const uint32_t count0 = b.dst_cap[r] / ELEM;
+                const uint32_t dataBytes0 = b.src_size[r] - ((count0 + 3u) >> 2);
+                res0 = self_total == dataBytes0 ? count0 * ELEM : E_STREAM;
+            }
+            b.result[r] = res0;
+        }
+    }
     if (b.gate && b.gate[r] >= GATE_SKIP) return;
     const uint32_t in_size = b.src_size[r];
     if (in_size >= E_FIRST) return;
     const uint32_t out_size = b.dst_cap[r];
     uint32_t res;
     if (svb_decode_check<ELEM, I16ZZ>(in_size, out_size, res)) return;
-    if (MODE != 1 && b.result[r] >= E_FIRST) return;  // the scan found the stream malformed
+    if (SELF) {
+        if (MODE != 1 && self_total != (uint64_t)(in_size - ((out_size / ELEM + 3u) >> 2))) return;   // the stream is malformed
+    } else if (MODE != 1 && b.result[r] >= E_FIRST) return;  // the scan found the stream malformed
     const uint32_t count = out_size / ELEM;
     const uint32_t keyLen = (count + 3u) >> 2;
     const uint32_t first = k * (uint32_t)SEG;
@@ -723,12 +810,12 @@ __global__ __launch_bounds__(WG) void svb_seg_decode_kernel(ReadBatch b, const u
     const uint32_t end = count - first > (uint32_t)SEG ? first + SEG : count;
     const uint8_t* in = b.src + b.src_off[r];
     const uint32_t dataBytes = in_size - keyLen;
-    uint64_t pos = MODE == 1 ? 0 : seg_pos[blockIdx.x];
-    uint32_t run = (MODE == 0 && ZZ) ? seg_run[blockIdx.x] : 0u;
+    uint64_t pos = MODE == 1 ? 0 : (SELF ? self_pos : seg_pos[blockIdx.x]);
+    uint32_t run = (MODE == 0 && ZZ) ? (SELF ? (uint32_t)self_run : seg_run[blockIdx.x]) : 0u;
     const uint64_t pos0 = pos;
     (void)svb_decode_range<ELEM, ZZ, I16ZZ, MODE>(in, in + keyLen, dataBytes, count, first, end, pos, run, b.dst + b.dst_off[r], stage, wsum);
     if (MODE == 1 && tid == 0) seg_val[blockIdx.x] = (uint32_t)(pos - pos0);
-    if (MODE == 2 && tid == 0) seg_val[blockIdx.x] = run;
+    if (MODE == 2 && tid == 0) (SELF ? seg_run_io : seg_val)[blockIdx.x] = run;
 }
 
 // one workgroup per read.  VERDICT: exclusive scan of the announced data bytes -> seg_pos, and the read's result;
@@ -1068,10 +1155,15 @@ hipError_t launch_svb_encode_seg(const ReadBatch& b, int integer_size, bool zigz
 {
     if (b.n_reads == 0) return hipSuccess;
     const uint32_t sc = strict_cap ? 1u : 0u;
+    const bool self = max_segs <= seg_self_max();
 #define X(E, Z, I)                                                                                                                   \
     hipLaunchKernelGGL((svb_seg_encode_kernel<E, Z, I, true>), dim3(max_segs), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off);  \
-    hipLaunchKernelGGL((svb_seg_encode_scan_kernel<E, I>), dim3(b.n_reads), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off);    \
-    hipLaunchKernelGGL((svb_seg_encode_kernel<E, Z, I, false>), dim3(max_segs), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off)
+    if (self) {                                                                                                                      \
+        hipLaunchKernelGGL((svb_seg_encode_kernel<E, Z, I, false, true>), dim3(max_segs), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off); \
+    } else {                                                                                                                         \
+        hipLaunchKernelGGL((svb_seg_encode_scan_kernel<E, I>), dim3(b.n_reads), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off);    \
+        hipLaunchKernelGGL((svb_seg_encode_kernel<E, Z, I, false>), dim3(max_segs), dim3(WG), 0, s, b, hdr, sc, seg_first, seg_bytes, seg_off); \
+    }
     VBZ_SVB_DISPATCH(X);
 #undef X
     return hipGetLastError();
@@ -1081,14 +1173,20 @@ hipError_t launch_svb_decode_seg(const ReadBatch& b, int integer_size, bool zigz
                                  uint32_t* seg_val, uint64_t* seg_pos, uint32_t* seg_run, hipStream_t s)
 {
     if (b.n_reads == 0) return hipSuccess;
+    const bool self = max_segs <= seg_self_max();
 #define X(E, Z, I)                                                                                                                          \
     hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 1>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);             \
-    hipLaunchKernelGGL((svb_seg_decode_scan_kernel<E, I, true>), dim3(b.n_reads), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);       \
-    if (Z) {                                                                                                                                \
-        hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 2>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);         \
-        hipLaunchKernelGGL((svb_seg_decode_scan_kernel<E, I, false>), dim3(b.n_reads), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);  \
-    }                                                                                                                                       \
-    hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 0>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run)
+    if (self) {                                                                                                                             \
+        if (Z) hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 2, true>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run); \
+        hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 0, true>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);   \
+    } else {                                                                                                                                \
+        hipLaunchKernelGGL((svb_seg_decode_scan_kernel<E, I, true>), dim3(b.n_reads), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);   \
+        if (Z) {                                                                                                                            \
+            hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 2>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);     \
+            hipLaunchKernelGGL((svb_seg_decode_scan_kernel<E, I, false>), dim3(b.n_reads), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run); \
+        }                                                                                                                                   \
+        hipLaunchKernelGGL((svb_seg_decode_kernel<E, Z, I, 0>), dim3(max_segs), dim3(WG), 0, s, b, seg_first, seg_val, seg_pos, seg_run);         \
+    }
     VBZ_SVB_DISPATCH(X);
 #undef X
     return hipGetLastError();
