@@ -257,6 +257,36 @@ def test_whole_suite_on_the_large_read_path():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+def test_segment_tables_either_side_of_the_self_prefix_bound():
+    """Calls of up to 1024 segments (16 384 int16 samples each) add up the lengths in front of a segment inside the segment's workgroup,
+    larger calls get scan launches: one read of ~1000 segments, one of ~1100, and two reads in one call that share a table of ~1000
+    (the second read's sums start in the middle of the table) -- svb bytes identical to the oracle's, the round trip exact, and a
+    stream cut short refused with the oracle's verdict on both sides of the bound."""
+    rng = np.random.default_rng(77)
+    o = (True, 2, 0, 0)   # zig-zag + svb, no entropy stage: the bytes are the reference's
+    go, oo = _lib.CompressionOptions(*o), O.options(*o)
+
+    def signal(n):
+        a = np.cumsum(rng.integers(-300, 300, n)).astype(np.int64)
+        a[rng.integers(0, n, n // 50)] += rng.integers(-30000, 30000, n // 50)   # (two-byte deltas here and there)
+        return a.astype(np.int16)
+
+    for sizes in ([1000 * 16384 - 5], [1100 * 16384 + 7], [640 * 16384 + 11, 355 * 16384 - 3]):
+        reads = [signal(n) for n in sizes]
+        got = G.compress(reads, go)
+        for a, g in zip(reads, got):
+            want = O.compress(a, oo)
+            assert not isinstance(g, int) and g.tobytes() == want.tobytes()
+        back = G.decompress(got, [a.nbytes for a in reads], go)
+        for a, b in zip(reads, back):
+            assert not isinstance(b, int) and b.tobytes() == a.tobytes()
+        cut = [g[: len(g) - 3] for g in got]
+        back = G.decompress(cut, [a.nbytes for a in reads], go)
+        for c, a, b in zip(cut, reads, back):
+            want = O.decompress(c, a.nbytes, oo)
+            assert isinstance(want, int) and isinstance(b, int) and b == want, (hex(b) if isinstance(b, int) else "decoded", hex(want))
+
+
 def test_svb_suites_with_the_scan_launches():
     """The segmented svb kernels of a call with few segments add up the lengths in front of a segment by themselves; a call with
     more than 1024 segments (32 MB of samples) gets scan launches between the passes instead.  VBZ_HIP_SEG_SELF_MAX=0 gives every
