@@ -99,4 +99,4 @@ def decompress_raw(data, nbytes, opts, sized=False):
     n = fn(data.ctypes.data if data.size else None, data.nbytes, out.ctypes.data, nbytes, ctypes.byref(opts))
     if _lib.is_error(n):
         return int(n)
-    return out[:n].copy()
+    return out[:n]   # (a view of the buffer the library wrote: no second copy of a large result)
