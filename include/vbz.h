@@ -25,7 +25,7 @@
  *     A compressed buffer may end in zstd skippable frames with hints for this library's parallel decoder, which
  *     libzstd skips (RFC 8878 3.1.2): checkpoints of the sequences section (magic 0x184D2A5B, <= 272 bytes) and, behind
  *     reads of half a megabyte or more (and behind every read of a small batch), an index of the frame's spans (magic
- *     0x184D2A5C, 8 bytes per 8-64 KB of content: not bounded by a constant).  vbz_gpu_set_trailers / VBZ_HIP_TRAILERS=0
+ *     0x184D2A5C, 8 bytes per span of 4 - 32 KB of content, 256 KB in very large frames: not bounded by a constant).  vbz_gpu_set_trailers / VBZ_HIP_TRAILERS=0
  *     writes plain single frames.
  *   - the decoder reads RFC 8878 frames only.  zstd's legacy frame formats (v0.2 ... v0.7, magic 0xFD2FB522 ... 27), which
  *     a libzstd built with ZSTD_LEGACY_SUPPORT also decodes, are VBZ_ZSTD_ERROR here (no vbz writer ever produced them;

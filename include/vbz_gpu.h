@@ -92,7 +92,7 @@ VBZ_EXPORT const char* vbz_gpu_last_error(vbz_gpu_ctx* ctx);
 /* Decoder hints behind the zstd frame.  By default a compressed buffer may end in zstd SKIPPABLE frames (RFC 8878 3.1.2;
  * libzstd, hence the reference's vbz_decompress, ignores them): checkpoints of the sequences section (magic 0x184D2A5B,
  * <= 272 bytes) and, for reads of half a megabyte or more (and for every read of a small batch), an index of the frame's spans (magic
- * 0x184D2A5C, 8 bytes per 8-64 KB of content; bit 31 of its span count says that the data bytes share one Huffman table: spans that
+ * 0x184D2A5C, 8 bytes per span of 4 - 32 KB of content, 256 KB in very large frames; bit 31 of its span count says that the data bytes share one Huffman table: spans that
  * begin with a treeless block).  This library's decoder uses them to decode one frame on many lanes / wavefronts and verifies
  * them; without them it decodes the same frames, more slowly.  enable = 0 writes plain single zstd frames (for consumers
  * that insist on consumed == source size after ONE frame); the compression itself (run sequences included) is unchanged.
