@@ -989,6 +989,68 @@ def test_full_size_device_round_trip_properties():
     assert abs(gsum / osum - 1.0) < 0.01, (gsum, osum)                   # T2: size within 1 % of the oracle's on the sample
 
 
+def test_two_contexts_in_flight_do_not_disturb_each_other():
+    """INTEGRATION.md section 4 tells a caller with a queue of batches to keep two contexts busy at once, each on a stream of its own.
+    Two contexts code different batches (one of ordinary reads, one with large reads among them) back to back without any
+    synchronisation in between, three rounds: each must write exactly the bytes it writes when it has the device to itself, and decode
+    its own input back -- nothing of a context (scratch, plans, tables, the hand-over words) may be shared with another."""
+    import torch
+    from vbz_compression_amd import batch
+
+    dev = torch.device("cuda", 0)
+    ctxs = [batch.GpuCodec(0), batch.GpuCodec(0)]
+    opts = ctxs[0].options(True, 2, 1, 1)
+    L = ctxs[0].L
+
+    def make(c, first, n, stretch):
+        with torch.cuda.stream(c.stream):
+            lens = c.synth_lengths(5, first, n)
+            if stretch:   # a few long reads among the others: per-read routing, its second stream and its join
+                lens[7] = 700000
+                lens[n // 2] = 1300001
+            sizes = lens.to(torch.int64) * 2
+            off, total = batch.layout(sizes.cpu(), 64)
+            caps = torch.tensor([L.vbz_max_compressed_size(int(s), ctypes.byref(opts)) for s in sizes.cpu().tolist()], dtype=torch.int64)
+            coff, ctotal = batch.layout(caps, 64)
+            raw = torch.zeros(total, dtype=torch.uint8, device=dev)
+            off = off.to(dev)
+            c.synth_signal(5, first, raw, off, lens)
+            return dict(n=n, raw=raw, off=off, size=sizes.to(torch.int32).to(dev), coff=coff.to(dev), cap=caps.to(torch.int32).to(dev),
+                        csize=torch.zeros(n, dtype=torch.int32, device=dev), comp=torch.zeros(ctotal, dtype=torch.uint8, device=dev),
+                        back=torch.zeros(total, dtype=torch.uint8, device=dev), res=torch.zeros(n, dtype=torch.int32, device=dev))
+
+    work = [make(ctxs[0], 0, 3000, False), make(ctxs[1], 50000, 2500, True)]
+
+    def step(c, B):
+        with torch.cuda.stream(c.stream):
+            c.compress(B["raw"], B["off"], B["size"], B["comp"], B["coff"], B["cap"], B["csize"], opts)
+            c.decompress(B["comp"], B["coff"], B["csize"], B["back"], B["off"], B["size"], B["res"], opts)
+
+    alone = []
+    for c, B in zip(ctxs, work):   # each context with the device to itself
+        step(c, B)
+        torch.cuda.synchronize()
+        assert bool((B["res"] == B["size"]).all()) and torch.equal(B["raw"], B["back"])
+        alone.append((B["comp"].clone(), B["csize"].clone()))
+    for _ in range(3):             # both in flight, nothing waits for anything
+        for B in work:
+            B["comp"].zero_()
+            B["back"].zero_()
+        torch.cuda.synchronize()
+        for k in range(2):
+            for c, B in zip(ctxs, work):
+                step(c, B)
+        torch.cuda.synchronize()
+        for B, (comp, csize) in zip(work, alone):
+            assert torch.equal(B["csize"], csize)
+            assert bool((B["res"] == B["size"]).all()) and torch.equal(B["raw"], B["back"])
+            for i in (0, 7, B["n"] // 2, B["n"] - 1):   # the frames themselves (the slots' unused tails are scratch)
+                o, z = int(B["coff"][i]), int(csize[i])
+                assert torch.equal(B["comp"][o : o + z], comp[o : o + z])
+    for c in ctxs:
+        c.close()
+
+
 def test_zstd_encoder_tables_match_host_statement():
     """The wave-parallel table construction on the device (bitonic sort, package-merge, FSE-coded weights) must give the
     tree description that its serial host statement gives for the same bytes (zstd_entropy.h: huf_build_pm, checked for
