@@ -28,5 +28,9 @@ rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/c4fetch" -- python3 bench.py --worklo
 rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/c4write" -- python3 bench.py --workload config4 --no-cpu --steps 3 --warmup 1 > "$out/c4write.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -f csv -d "$out/c4sq1" -- python3 bench.py --workload config4 --no-cpu --steps 3 --warmup 1 > "$out/c4sq1.log" 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC -f csv -d "$out/c4sq2" -- python3 bench.py --workload config4 --no-cpu --steps 3 --warmup 1 > "$out/c4sq2.log" 2>&1
+# per-call latencies of the large-read path and the aggregate rate with two contexts in flight
+python3 tools/time_one_read.py 10000 100000 400000 2>&1 | grep samples > "$out/one_read.txt"
+python3 tools/time_large.py 2>&1 | grep case > "$out/time_large.txt"
+python3 tools/two_in_flight.py --reads 32768 2>&1 | grep "reads per batch" > "$out/two_in_flight.txt"
 ls -R "$out" | head -60
 cat "$out/bench.json"
