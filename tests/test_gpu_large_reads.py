@@ -257,6 +257,43 @@ def test_whole_suite_on_the_large_read_path():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+@pytest.mark.parametrize("kind,count,o", [("int16", 800_000_000, (True, 2, 1, 1)), ("int16", 1_000_000_000, (True, 2, 1, 1)), ("uint32", 1_000_000_000, (False, 4, 3, 0))])
+def test_one_read_near_the_size_type_limit(kind, count, o):
+    """vbz_size_t is 32 bits: the largest read the interface can describe is the one whose worst-case size still fits it.  int16 reads of
+    800 M and 1 000 M samples (1.6 / 2.0 GB; the destination slot of the second, vbz_max_compressed_size, is 4.27 GB -- 28 MB below
+    2^32 -- and its svb stream 2.5 GB: byte positions beyond 2^31) and one uint32 buffer of 1 000 M values (4.0 GB of input), generated
+    on the device: the round trip is exact on the device, and the reference's decoder (oracle + libzstd) reads the frame -- spans,
+    index trailer and all."""
+    c = G.codec()
+    dev = c.device
+    opts = c.options(*o)
+    size = o[1]
+    nbytes = count * size
+    with torch.cuda.stream(c.stream):
+        off = torch.zeros(1, dtype=torch.int64, device=dev)
+        lens = torch.tensor([count], dtype=torch.int32, device=dev)
+        raw = torch.zeros(nbytes + 64, dtype=torch.uint8, device=dev)
+        (c.synth_u32 if kind == "uint32" else c.synth_signal)(5, 3, raw, off, lens)
+        cap = c.L.vbz_max_compressed_size(nbytes, ctypes.byref(opts))
+        assert not _lib.is_error(cap) and cap > nbytes
+        comp = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+        back = torch.zeros_like(raw)
+        size32 = torch.tensor([nbytes], dtype=torch.int64).to(torch.int32).to(dev)
+        cap32 = torch.tensor([cap], dtype=torch.int64).to(torch.int32).to(dev)
+        csize = torch.zeros(1, dtype=torch.int32, device=dev)
+        res = torch.zeros(1, dtype=torch.int32, device=dev)
+        c.compress(raw, off, size32, comp, off, cap32, csize, opts)
+        c.decompress(comp, off, csize, back, off, size32, res, opts)
+    torch.cuda.synchronize()
+    cs, rs = int(csize[0]) & 0xFFFFFFFF, int(res[0]) & 0xFFFFFFFF
+    assert rs == nbytes and torch.equal(raw, back), (hex(cs), hex(rs))
+    assert 2.2 < nbytes / cs < 2.7
+    want = O.decompress(comp[:cs].cpu().numpy(), nbytes, O.options(*o))
+    assert not isinstance(want, int) and bool((torch.from_numpy(want.view(np.uint8)) == raw[:nbytes].cpu()).all())
+    del raw, comp, back
+    torch.cuda.empty_cache()
+
+
 def test_segment_tables_either_side_of_the_self_prefix_bound():
     """Calls of up to 1024 segments (16 384 int16 samples each) add up the lengths in front of a segment inside the segment's workgroup,
     larger calls get scan launches: one read of ~1000 segments, one of ~1100, and two reads in one call that share a table of ~1000
