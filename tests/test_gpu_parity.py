@@ -1051,6 +1051,66 @@ def test_two_contexts_in_flight_do_not_disturb_each_other():
         c.close()
 
 
+def test_batched_contexts_on_threads_of_their_own():
+    """Four host threads, each with a context of its own created ON that thread, run batched compress / decompress calls at the same
+    time (ctypes releases the interpreter lock inside a call): per-process state of the library -- the sequence tables it builds
+    once, the kernel images, the pool the single-buffer API keeps -- must not care.  Every thread checks its own round trips and a
+    frame of each round against the oracle."""
+    import threading
+
+    import torch
+    from vbz_compression_amd import batch
+
+    errors = []
+
+    # (the helper functions of gpu_util drive ONE shared context; this test needs one per thread: the plain tensor interface)
+    def worker(k):
+        try:
+            c = batch.GpuCodec(0)
+            o = [(True, 2, 1, 1), (True, 2, 1, 0), (False, 4, 3, 0), (True, 2, 3, 1)][k]
+            opts = c.options(*o)
+            size = o[1]
+            dev = c.device
+            with torch.cuda.stream(c.stream):
+                for rnd in range(5):
+                    n = 300 + 50 * k
+                    lens = c.synth_lengths(5 + k, 1000 * rnd, n)
+                    if rnd == 2:
+                        lens[5] = 400000
+                    sizes = lens.to(torch.int64) * size
+                    off, total = batch.layout(sizes.cpu(), 64)
+                    caps = torch.tensor([c.L.vbz_max_compressed_size(int(z), ctypes.byref(opts)) for z in sizes.cpu().tolist()], dtype=torch.int64)
+                    coff, ctotal = batch.layout(caps, 64)
+                    raw = torch.zeros(total, dtype=torch.uint8, device=dev)
+                    off = off.to(dev)
+                    (c.synth_u32 if size == 4 else c.synth_signal)(5 + k, 1000 * rnd, raw, off, lens)
+                    comp = torch.zeros(ctotal, dtype=torch.uint8, device=dev)
+                    coff = coff.to(dev)
+                    csize = torch.zeros(n, dtype=torch.int32, device=dev)
+                    back = torch.zeros_like(raw)
+                    res = torch.zeros(n, dtype=torch.int32, device=dev)
+                    size32 = sizes.to(torch.int32).to(dev)
+                    c.compress(raw, off, size32, comp, coff, caps.to(torch.int32).to(dev), csize, opts)
+                    c.decompress(comp, coff, csize, back, off, size32, res, opts)
+                    c.stream.synchronize()
+                    assert bool((res == size32).all()) and torch.equal(raw, back), "round trip in thread %d round %d" % (k, rnd)
+                    i = 5
+                    o0, z0 = int(off[i]), int(sizes[i])
+                    f = comp[int(coff[i]) : int(coff[i]) + int(csize[i])].cpu().numpy()
+                    want = O.decompress(f, z0, O.options(*o))
+                    assert not isinstance(want, int) and want.view(np.uint8).tobytes() == raw[o0 : o0 + z0].cpu().numpy().tobytes()
+            c.close()
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_zstd_encoder_tables_match_host_statement():
     """The wave-parallel table construction on the device (bitonic sort, package-merge, FSE-coded weights) must give the
     tree description that its serial host statement gives for the same bytes (zstd_entropy.h: huf_build_pm, checked for
