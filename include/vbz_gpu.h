@@ -102,7 +102,8 @@ VBZ_EXPORT void vbz_gpu_set_trailers(vbz_gpu_ctx* ctx, int enable);
 VBZ_EXPORT int vbz_gpu_synchronize(vbz_gpu_ctx* ctx);
 
 /* Both return 0 when the batch was queued, negative on a launch/allocation failure (see
- * vbz_gpu_last_error).  Per-read failures are reported in batch->result, not here. */
+ * vbz_gpu_last_error; -2: options this library does not know, or declared arena extents beyond 2^46 bytes, refused before
+ * anything is sized by them).  Per-read failures are reported in batch->result, not here. */
 VBZ_EXPORT int vbz_gpu_compress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch,
                                       const struct CompressionOptions* options, int sized);
 VBZ_EXPORT int vbz_gpu_decompress_batch(vbz_gpu_ctx* ctx, const vbz_gpu_batch* batch,

@@ -989,6 +989,55 @@ def test_full_size_device_round_trip_properties():
     assert abs(gsum / osum - 1.0) < 0.01, (gsum, osum)                   # T2: size within 1 % of the oracle's on the sample
 
 
+def test_declared_extents_that_no_device_holds():
+    """src_bytes / dst_bytes size the library's scratch.  A declared extent beyond 2^46 bytes is refused before any arithmetic is done with
+    it (-2, a message); one that is merely more than the device has is an allocation failure (-1) that leaves neither the context nor
+    the calling thread's HIP state damaged: the next call -- and the caller's own next HIP call -- work."""
+    import torch
+    from vbz_compression_amd import batch
+
+    c = batch.GpuCodec(0)
+    dev = c.device
+    opts = c.options(True, 2, 1, 1)
+    a = O.synth_signal(5, 1, 50000)
+    n = 4
+    with torch.cuda.stream(c.stream):
+        raw = torch.from_numpy(np.tile(a.view(np.uint8), n).copy()).to(dev)
+        off = torch.arange(n, dtype=torch.int64, device=dev) * a.nbytes
+        size32 = torch.full((n,), a.nbytes, dtype=torch.int32, device=dev)
+        cap = c.L.vbz_max_compressed_size(a.nbytes, ctypes.byref(opts))
+        coff = torch.arange(n, dtype=torch.int64, device=dev) * ((cap + 63) // 64 * 64)
+        comp = torch.zeros(int(coff[-1]) + cap + 64, dtype=torch.uint8, device=dev)
+        cap32 = torch.full((n,), cap, dtype=torch.int32, device=dev)
+        csize = torch.zeros(n, dtype=torch.int32, device=dev)
+
+        def call(src_bytes, dst_bytes, decompress=False):
+            b = c._batch(raw, off, size32, comp, coff, cap32, csize)
+            b.src_bytes, b.dst_bytes = src_bytes, dst_bytes
+            fn = c.L.vbz_gpu_decompress_batch if decompress else c.L.vbz_gpu_compress_batch
+            rc = fn(c.ctx, ctypes.byref(b), ctypes.byref(opts), 0)
+            torch.cuda.synchronize()
+            return rc
+
+        assert call(raw.numel(), comp.numel()) == 0
+        good = csize.clone()
+        assert int(good[0]) > 0
+        for sb, db in ((1 << 62, comp.numel()), (raw.numel(), 1 << 62), ((1 << 64) - 1, (1 << 64) - 1), ((1 << 46) + 1, comp.numel())):
+            for dec in (False, True):
+                csize.zero_()
+                assert call(sb, db, dec) == -2
+                assert b"not plausible" in c.L.vbz_gpu_last_error(c.ctx)
+                assert int(csize.abs().sum()) == 0          # nothing ran
+        csize.zero_()                                      # (a torch call of the same thread: the runtime's last error must be clean)
+        assert call(1 << 45, 1 << 45) == -1                 # more than any device has: the allocation fails, nothing else
+        assert b"hipMalloc" in c.L.vbz_gpu_last_error(c.ctx)
+        probe = torch.zeros(16, device=dev) + 1            # the caller's own HIP work goes on
+        assert float(probe.sum()) == 16.0
+        csize.zero_()
+        assert call(raw.numel(), comp.numel()) == 0 and torch.equal(csize, good)
+    c.close()
+
+
 def test_two_contexts_in_flight_do_not_disturb_each_other():
     """INTEGRATION.md section 4 tells a caller with a queue of batches to keep two contexts busy at once, each on a stream of its own.
     Two contexts code different batches (one of ordinary reads, one with large reads among them) back to back without any

@@ -117,9 +117,10 @@ bool ensure(vbz_gpu_ctx* c, DevBuf& b, size_t bytes)
         b.cap = 0;
     }
     size_t want = bytes + bytes / 8 + 4096;
-    hipError_t e = hipMalloc(&b.p, want);
+    hipError_t e = bytes > ((size_t)1 << 60) ? hipErrorOutOfMemory : hipMalloc(&b.p, want);
     if (e != hipSuccess) {
         set_error(c, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        (void)hipGetLastError();   // (the runtime keeps the failure as the thread's last error: the caller's next HIP call must not trip over it)
         b.p = nullptr;
         return false;
     }
@@ -771,6 +772,16 @@ int validate_descriptors(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, ReadBatch* rb)
     return 0;
 }
 
+// The arena extents a caller declares size the scratch: a value no device could hold is refused before any arithmetic is done with it
+// (scratch bounds are a few times the extent: 2^46 bytes keeps every product inside 64 bits).
+constexpr uint64_t EXTENT_MAX = 1ull << 46;
+bool plausible_extents(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
+{
+    if (bt->src_bytes <= EXTENT_MAX && bt->dst_bytes <= EXTENT_MAX) return true;
+    set_error(c, "declared arena extents are not plausible (src_bytes %llu, dst_bytes %llu)", (unsigned long long)bt->src_bytes, (unsigned long long)bt->dst_bytes);
+    return false;
+}
+
 // own_descriptors: the table is the library's own (the single-buffer API: one read, slots it has just allocated) -- nothing to validate
 int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized, bool own_descriptors = false)
 {
@@ -970,6 +981,7 @@ int vbz_gpu_compress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compre
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
     }
+    if (!plausible_extents(c, bt)) return -2;
     return compress_batch_impl(c, bt, o, sized);
 }
 
@@ -981,6 +993,7 @@ int vbz_gpu_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Comp
         set_error(c, "unsupported options (integer_size=%u version=%u)", o->integer_size, o->vbz_version);
         return -2;
     }
+    if (!plausible_extents(c, bt)) return -2;
     return decompress_batch_impl(c, bt, o, sized);
 }
 
@@ -1017,6 +1030,7 @@ int vbz_gpu_zstd_decompress_batch(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
 {
     if (!c || !bt) return -1;
     DeviceGuard dg(c->device);
+    if (!plausible_extents(c, bt)) return -2;
     return zstd_frames(c, to_rb(bt), E_ZSTD, bt->dst_bytes, nullptr);
 }
 
