@@ -1028,6 +1028,11 @@ def test_declared_extents_that_no_device_holds():
                 assert call(sb, db, dec) == -2
                 assert b"not plausible" in c.L.vbz_gpu_last_error(c.ctx)
                 assert int(csize.abs().sum()) == 0          # nothing ran
+        for field in ("src", "src_off", "src_size", "dst", "dst_off", "dst_cap", "result"):   # a NULL table or arena: refused, not dereferenced
+            b = c._batch(raw, off, size32, comp, coff, cap32, csize)
+            setattr(b, field, None)
+            assert c.L.vbz_gpu_compress_batch(c.ctx, ctypes.byref(b), ctypes.byref(opts), 0) == -2
+            assert b"NULL" in c.L.vbz_gpu_last_error(c.ctx)
         csize.zero_()                                      # (a torch call of the same thread: the runtime's last error must be clean)
         assert call(1 << 45, 1 << 45) == -1                 # more than any device has: the allocation fails, nothing else
         assert b"hipMalloc" in c.L.vbz_gpu_last_error(c.ctx)

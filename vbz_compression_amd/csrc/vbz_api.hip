@@ -777,6 +777,11 @@ int validate_descriptors(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, ReadBatch* rb)
 constexpr uint64_t EXTENT_MAX = 1ull << 46;
 bool plausible_extents(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
 {
+    if (bt->n_reads != 0 && (!bt->src_off || !bt->src_size || !bt->dst_off || !bt->dst_cap || !bt->result || (!bt->src && bt->src_bytes != 0) ||
+                             (!bt->dst && bt->dst_bytes != 0))) {
+        set_error(c, "a table or arena pointer of the batch is NULL");
+        return false;
+    }
     if (bt->src_bytes <= EXTENT_MAX && bt->dst_bytes <= EXTENT_MAX) return true;
     set_error(c, "declared arena extents are not plausible (src_bytes %llu, dst_bytes %llu)", (unsigned long long)bt->src_bytes, (unsigned long long)bt->dst_bytes);
     return false;
