@@ -255,6 +255,7 @@ struct DeviceGuard
         hipError_t e__ = (expr);                                                   \
         if (e__ != hipSuccess) {                                                   \
             set_error((c), "%s failed: %s", (what), hipGetErrorString(e__));      \
+            (void)hipGetLastError(); /* reported here: not left for the caller's next HIP call to trip over */ \
             return -1;                                                             \
         }                                                                          \
     } while (0)
@@ -1304,7 +1305,11 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
         c->pinned = nullptr;
         c->pinned_cap = 0;
         const size_t want = std::max<size_t>(pin_need, 1u << 20);
-        if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) return VBZ_OUT_OF_MEMORY_ERROR;
+        if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            c->pinned = nullptr;
+            return VBZ_OUT_OF_MEMORY_ERROR;
+        }
         c->pinned_cap = want;
     }
     uint8_t* pin = (uint8_t*)c->pinned;
