@@ -291,40 +291,67 @@ def usable_cpus():
     return n, note
 
 
-# kernels behind the library's timed labels (vbz_api.hip `Timed`), as rocprofv3 names them
+# The library's timed labels (vbz_api.hip `Timed`) and the kernels behind each, as rocprofv3 names them (prefix match).  Every kernel of
+# libvbz_hip.so must appear here: `profile_tables` refuses a committed profile in which a library kernel holding more than 1 % of the
+# library's time belongs to no label (round 5's line dropped zstd_plan_kernel that way and under-reported the encode traffic).
 LABEL_KERNELS = {
-    "zstd_decode": ("zstd_decode_kernel", "fast_scan_kernel", "fast_weights_kernel", "fast_streams_kernel", "fast_runs_kernel"),
-    "zstd_encode": ("zstd_encode_kernel", "zstd_pack_kernel"),
+    "svb_encode": ("svb_encode_kernel", "svb_seg_encode"),
+    "zstd_encode": ("zstd_plan_kernel", "zstd_pack_kernel", "zstd_encode_kernel", "zstd_span_", "period_probe_kernel"),
+    "zstd_decode": ("fast_scan_kernel", "fast_weights_kernel", "fast_streams_kernel", "fast_runs_kernel", "zstd_decode_kernel", "ref_chain_kernel",
+                    "zstd_dspan_"),
+    "svb_decode": ("svb_decode_kernel", "svb_seg_decode"),
+    "plan_scratch": ("plan_scratch_kernel",),
+    "route": ("route_", "seg_plan_kernel", "validate_batch_kernel", "parse_sized_kernel", "hand_back_kernel", "copy_bytes_kernel"),
 }
+# kernels in a profile of `python bench.py` that are NOT the library's: the generator, torch's fills / compares / reductions, runtime copies
+NOT_LIBRARY = ("at::native::", "synth_", "__amd_rocclr", "void at::", "Cijk_", "rccl", "nccl")
+ENCODE_LABELS, DECODE_LABELS = ("svb_encode", "zstd_encode"), ("zstd_decode", "svb_decode")
 
 
-def committed_traffic(kernels):
-    """HBM bytes per launch of each of `kernels` from the newest rocprofv3 PMC summary committed under profiles/
-    (tools/summarize_profile.py: separate --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 read correction).
-    bench.py cannot run the profiler on itself.  Returns ({kernel: bytes}, file, reads per launch of the profiled run):
-    traffic is proportional to the number of reads, so the caller scales it to this run's batch when the two differ."""
+def kernel_label(name):
+    for label, prefixes in LABEL_KERNELS.items():
+        if any(name.startswith(p) for p in prefixes):
+            return label
+    return None
+
+
+def profile_tables():
+    """Per-kernel launch time and HBM traffic of the newest rocprofv3 summary pair committed under profiles/ (tools/summarize_profile.py:
+    `--kernel-trace --stats`, and separate `--pmc FETCH_SIZE` / `WRITE_SIZE` passes with the gfx950 read correction): bench.py cannot run
+    the profiler on itself.  Returns ({kernel: {"label", "ms", "hbm_bytes"}}, file tag, reads per launch of the profiled run) for the main
+    launches (per-read routing's small-grid second group is listed apart by the summariser and left out).  Raises if a library kernel with
+    more than 1 % of the library's time has no label."""
     import csv
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
-    for path in reversed(files):
-        found = {}
-        for r in csv.DictReader(open(path)):
-            if "second launch group" in r["kernel"]:   # (per-read routing's small-grid launches: tools/summarize_profile.py)
+    for tpath in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))):
+        if "config" in os.path.basename(tpath):
+            continue
+        spath = tpath.replace("_hbm_traffic.csv", "_kernel_stats.csv")
+        if not os.path.exists(spath):
+            continue
+        rows = {}
+        for r in csv.DictReader(open(spath)):
+            k = r["kernel"]
+            if "second launch group" in k or any(k.startswith(p) for p in NOT_LIBRARY):
                 continue
-            for k in kernels:
-                # one timed label of the library may cover several launches (the batched decoder, the staged encoder): their
-                # traffic adds up (every one of them runs once per call)
-                if any(r["kernel"].startswith(p) for p in LABEL_KERNELS.get(k, (k + "_kernel",))):
-                    found[k] = found.get(k, 0) + int(float(r["hbm_MB_per_launch"]) * 1e6)
-        if found:
-            reads = 8192
-            try:
-                with open(path.replace("_hbm_traffic.csv", "_bench.json")) as f:
-                    reads = int(json.load(f)["config"]["reads_per_step"])
-            except (OSError, KeyError, ValueError):
-                pass
-            return found, os.path.basename(path), reads
+            rows[k] = {"label": kernel_label(k), "ms": float(r["avg_ms"]), "total_ms": float(r["total_ms"]), "hbm_bytes": None}
+        for r in csv.DictReader(open(tpath)):
+            k = r["kernel"]
+            if k in rows:
+                rows[k]["hbm_bytes"] = int(float(r["hbm_MB_per_launch"]) * 1e6)
+        lib_total = sum(v["total_ms"] for v in rows.values()) or 1.0
+        orphans = [k for k, v in rows.items() if v["label"] is None and v["total_ms"] > 0.01 * lib_total]
+        if orphans:
+            raise SystemExit("bench.py: %s holds kernels with more than 1 %% of the library's time that LABEL_KERNELS attributes to no label: %s"
+                             % (os.path.basename(spath), orphans))
+        reads = 8192
+        try:
+            with open(tpath.replace("_hbm_traffic.csv", "_bench.json")) as f:
+                reads = int(json.load(f)["config"]["reads_per_step"])
+        except (OSError, KeyError, ValueError):
+            pass
+        return rows, os.path.basename(tpath).replace("_hbm_traffic.csv", ""), reads
     return {}, None, None
 
 
@@ -621,31 +648,39 @@ def run_rank(args):
                 "note": "zstd level 0 through the same batched entry points (byte-identical to the reference's level-0 output); "
                         "algorithmic bytes per direction = raw + svb stream"}}
 
-        # ---- roofline: algorithmic bytes = (2 + c) per sample per direction, c = 2 / ratio.  `achieved` is
-        # quoted for the direction that holds the dominant kernel (largest total time): that direction's algorithmic bytes
-        # over the summed average launch durations of its kernels (HIP events the library records around every launch
-        # on its stream).  Dividing by the dominant kernel alone would credit it with the other kernels' work.
-        per_launch = {k: v[1] / max(v[0], 1) for k, v in prof.items()}
-        enc_k = [k for k in per_launch if k in ("plan_scratch", "svb_encode", "zstd_encode", "vbz_encode")]
-        dec_k = [k for k in per_launch if k in ("svb_decode", "zstd_decode", "vbz_decode", "parse_sized")]
-        # plan_scratch runs in both directions: charge its per-launch time to each
+        # ---- roofline: algorithmic bytes = (2 + c) per sample per direction, c = 2 / ratio.  `achieved` is quoted for the
+        # direction that holds the dominant kernel (largest total time): that direction's algorithmic bytes over the WALL time of the
+        # direction's launch sequence (HIP events on the codec's stream around the compress / the decompress call of every timed step).
+        # Since round 6 a call runs its reads as two halves on two streams, so the library's per-label launch times overlap and their sum
+        # is no longer a duration; the events around the call are.  Dividing by the dominant kernel alone would credit it with the other
+        # kernels' work (reported as `dominant_kernel_alone`).
+        per_launch = {k: v[1] / max(v[0], 1) * (v[0] / args.steps) for k, v in prof.items()}   # ms per step under each label (a label may be launched once per half)
+        enc_k = [k for k in per_launch if k in ENCODE_LABELS]
+        dec_k = [k for k in per_launch if k in DECODE_LABELS]
         spl = samples / args.steps  # samples per launch
         c = 2.0 / ratio
         alg_dir = (2.0 + c) * spl
-        t_enc = sum(per_launch[k] for k in enc_k) * 1e-3
-        t_dec = (sum(per_launch[k] for k in dec_k) + per_launch.get("plan_scratch", 0.0)) * 1e-3
-        dom = max((k for k in per_launch if k != "plan_scratch"), key=lambda k: prof[k][1])
+        t_enc = enc_ms / args.steps * 1e-3
+        t_dec = dec_ms / args.steps * 1e-3
+        dom = max((k for k in per_launch if k in ENCODE_LABELS + DECODE_LABELS), key=lambda k: prof[k][1])
         dom_dir = "encode" if dom in enc_k else "decode"
         t_dom_dir = t_enc if dom_dir == "encode" else t_dec
         achieved = alg_dir / t_dom_dir / 1e9
-        traffic_map, traffic_src, traffic_reads = committed_traffic([k for k in per_launch if k != "plan_scratch"])
+        ktab, traffic_src, traffic_reads = profile_tables()
         scale = (n / traffic_reads) if traffic_reads else 1.0
-        dir_traffic = None
-        names = [k for k in (enc_k if dom_dir == "encode" else dec_k) if k != "plan_scratch"]
-        if names and all(k in traffic_map for k in names):
-            dir_traffic = int(sum(traffic_map[k] for k in names) * scale)
-            if traffic_reads != n:
-                traffic_src = "%s, scaled from %d to %d reads per launch" % (traffic_src, traffic_reads, n)
+        dir_labels = ENCODE_LABELS if dom_dir == "encode" else DECODE_LABELS
+
+        def label_traffic(labels):
+            rows = [v for v in ktab.values() if v["label"] in labels and v["hbm_bytes"] is not None]
+            return int(sum(v["hbm_bytes"] for v in rows) * scale) if rows else None
+
+        dir_traffic = label_traffic(dir_labels)
+        if traffic_src and traffic_reads != n:
+            traffic_src = "%s, scaled from %d to %d reads per launch" % (traffic_src, traffic_reads, n)
+        # per kernel, from that committed profile: launch time, HBM bytes (PMC) and the HBM rate the kernel actually sustained
+        per_kernel = {k: {"label": v["label"], "ms": round(v["ms"], 4), "hbm_GB": None if v["hbm_bytes"] is None else round(v["hbm_bytes"] / 1e9, 3),
+                          "hbm_GBps": None if v["hbm_bytes"] is None or v["ms"] <= 0 else round(v["hbm_bytes"] / 1e9 / (v["ms"] * 1e-3), 1)}
+                      for k, v in ktab.items() if v["label"] in ENCODE_LABELS + DECODE_LABELS and v["ms"] >= 0.02}
         roof = {
             "bound": "hbm",
             "kernel": dom,
@@ -655,21 +690,27 @@ def run_rank(args):
             "unit": "GB/s",
             "frac": round(achieved / PEAK_HBM_GBS, 5),
             "traffic": dir_traffic,
-            "traffic_source": traffic_src,
+            "traffic_source": traffic_src and ("profiles/%s_hbm_traffic.csv: every kernel of the direction's labels (%s)" % (traffic_src, "+".join(dir_labels))),
+            "traffic_over_algorithmic": None if not dir_traffic else round(dir_traffic / alg_dir, 3),
             "algorithmic_bytes_per_launch": int(alg_dir),
             "algorithmic_bytes_per_sample": round(2.0 + c, 4),
             "avg_launch_ms": round(t_dom_dir * 1e3, 4),
-            "definition": "SURVEY 8d: (2 + c) bytes per int16 sample per direction; achieved = that x samples per launch / sum of the "
-                          "average launch durations of the direction's kernels (%s)" % "+".join(names),
+            "definition": "SURVEY 8d: (2 + c) bytes per int16 sample per direction; achieved = that x samples per call / wall time of the direction's "
+                          "launch sequence (HIP events on the codec's stream around the %s call; its kernels: %s)"
+                          % ("compress" if dom_dir == "encode" else "decompress", "+".join(dir_labels)),
             "per_direction": {
-                "encode": {"achieved": round(alg_dir / t_enc / 1e9, 2), "frac": round(alg_dir / t_enc / 1e9 / PEAK_HBM_GBS, 5), "ms": round(t_enc * 1e3, 4)},
-                "decode": {"achieved": round(alg_dir / t_dec / 1e9, 2), "frac": round(alg_dir / t_dec / 1e9 / PEAK_HBM_GBS, 5), "ms": round(t_dec * 1e3, 4)},
+                "encode": {"achieved": round(alg_dir / t_enc / 1e9, 2), "frac": round(alg_dir / t_enc / 1e9 / PEAK_HBM_GBS, 5), "ms": round(t_enc * 1e3, 4),
+                           "traffic": label_traffic(ENCODE_LABELS)},
+                "decode": {"achieved": round(alg_dir / t_dec / 1e9, 2), "frac": round(alg_dir / t_dec / 1e9 / PEAK_HBM_GBS, 5), "ms": round(t_dec * 1e3, 4),
+                           "traffic": label_traffic(DECODE_LABELS)},
             },
             "end_to_end": {"achieved": round(2 * alg_dir / (elapsed / args.steps) / 1e9, 2),
                            "frac": round(2 * alg_dir / (elapsed / args.steps) / 1e9 / PEAK_HBM_GBS, 5),
                            "note": "encode + decode algorithmic bytes over the wall time of a step"},
             "dominant_kernel_alone": {"achieved": round(alg_dir / (per_launch[dom] * 1e-3) / 1e9, 2),
-                                      "note": "the literal per-kernel formula; flatters the kernel when its direction has other launches"},
+                                      "note": "the literal per-label formula (the label's launches of a step, summed); flatters the kernel: its direction has other launches"},
+            "per_kernel": per_kernel,
+            "per_kernel_source": traffic_src and "profiles/%s_kernel_stats.csv + _hbm_traffic.csv (rocprofv3 --kernel-trace --stats; --pmc FETCH_SIZE / WRITE_SIZE, gfx950 read correction)" % traffic_src.split(",")[0],
         }
         out = {
             "metric": METRIC,
@@ -703,7 +744,7 @@ def run_rank(args):
             "ratio": round(ratio, 4),
             "encode_MBps": round(raw_bytes / (enc_ms * 1e-3) / 1e6, 1),
             "decode_MBps": round(raw_bytes / (dec_ms * 1e-3) / 1e6, 1),
-            "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},
+            "kernels_ms_per_launch": {k: round(v, 4) for k, v in per_launch.items()},   # per STEP under each label (summed over a call's halves: they overlap)
             "roofline": roof,
         }
         if stage:
