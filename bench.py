@@ -758,6 +758,21 @@ def run_rank(args):
             torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu and not fixed_job:
             out["decode_reference_frames"] = decode_reference_frames(codec)
+        if world == 1 and not args.no_configs and not fixed_job:
+            # BASELINE configs[0] and configs[3] in the same line: short runs of `--workload config1` / `config4`
+            # (8 buffers per call, and one) on this process's codec; the full lines are what those workloads print on their own
+            cfg = {}
+            for key, wl, nb in (("config1", "config1", 1), ("config4", "config4", 8), ("config4_one_buffer", "config4", 1)):
+                r = measure_large(wl, nb, 10, 2, codec, dev, rank, world, coll_dev, barrier, coll, cpu=(key == "config4" and not args.no_cpu), cpu_seconds=3.0)
+                cfg[key] = {"workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                            "encode_ms": r["encode_ms"], "decode_ms": r["decode_ms"], "ratio": r["ratio"],
+                            "roofline_frac": r["roofline"]["frac"], "roofline_per_direction": r["roofline"]["per_direction"]}
+                if "host_api" in r:
+                    cfg[key]["host_api"] = {k: r["host_api"][k] for k in ("vbz_compress_ms", "vbz_decompress_ms")}
+                if "cpu_baseline" in r:
+                    cfg[key]["cpu_baseline"] = {k: r["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "one_thread", "ratio")}
+                torch.cuda.empty_cache()
+            out["configs"] = cfg
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline()
             if "single_socket" in out["cpu_baseline"]:
@@ -770,6 +785,12 @@ def run_rank(args):
 
 
 def run_large(args, codec, dev, rank, world, coll_dev, barrier, coll):
+    out = measure_large(args.workload, args.buffers, args.steps, args.warmup, codec, dev, rank, world, coll_dev, barrier, coll, cpu=not args.no_cpu)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def measure_large(workload, buffers, steps, warmup, codec, dev, rank, world, coll_dev, barrier, coll, cpu=True, cpu_seconds=6.0):
     """BASELINE.json configs[3] (`--workload config4`: uint32, no zig-zag, level 3, 10 M-element buffers) and configs[0]
     (`--workload config1`: one 400 k-sample int16 read): batches of few, large buffers, which the library spreads over many
     workgroups (segmented svb kernels, one wavefront per span of the entropy stage)."""
@@ -778,6 +799,12 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier, coll):
     from vbz_compression_amd import _lib, batch, shard, vbz
 
     L = codec.L
+
+    class A:   # (the body below was written against the argument namespace)
+        pass
+
+    args = A()
+    args.workload, args.buffers, args.steps, args.warmup, args.no_cpu = workload, buffers, steps, warmup, not cpu
     if args.workload == "config4":
         elem, zz, level, ver, count, nbuf, kind = 4, False, 3, 0, 10_000_000, args.buffers, "u32"
         name = "configs[3]: uint32, no zig-zag, zstd level 3 (UD=32020,5,0,0,4,0,3), %d buffer(s) of 10M elements per step" % nbuf
@@ -843,7 +870,7 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier, coll):
         dec_ms += evm[i].elapsed_time(eve[i])
         prev = eve[i]
     if rank != 0:
-        return
+        return None
     per_launch = {k: v[1] / max(v[0], 1) for k, v in prof.items()}
     # per direction: elem + c bytes per value ("for uint32 config: 4 + c4 per element per direction")
     c = elem / ratio
@@ -912,11 +939,11 @@ def run_large(args, codec, dev, rank, world, coll_dev, barrier, coll):
                            "note": "one buffer per call through include/vbz.h, pageable host memory in and out, buffers reused by the caller"}
     if world == 1 and not args.no_cpu:
         if kind == "u32":
-            out["cpu_baseline"] = cpu_baseline_u32(max(nbuf, usable_cpus()[0]), count)
+            out["cpu_baseline"] = cpu_baseline_u32(max(nbuf, usable_cpus()[0]), count, min_seconds=cpu_seconds)
         else:
             out["cpu_baseline"] = cpu_baseline(min_seconds=4.0, n_reads=16384)
             out["cpu_baseline"]["note"] = "reads of ~100k samples of the same generator (a single 400k read is one core's work: see one_thread)"
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def main():
@@ -936,6 +963,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-resident (PCIe-inclusive) leg")
     ap.add_argument("--no-stages", action="store_true", help="skip the svb-only stage line")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short configs[0] / configs[3] runs of the default line")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         if not args.dry_run:

@@ -13,12 +13,12 @@ out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
 python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
-rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -- python3 bench.py --no-cpu --no-pcie --no-stages > "$out/kt.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/fetch" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/write" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/write.log" 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d "$out/kt" -- python3 bench.py --no-cpu --no-pcie --no-stages --no-configs > "$out/kt.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE -f csv -d "$out/fetch" -- python3 bench.py --no-cpu --no-pcie --no-stages --no-configs --steps 3 --warmup 1 > "$out/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE -f csv -d "$out/write" -- python3 bench.py --no-cpu --no-pcie --no-stages --no-configs --steps 3 --warmup 1 > "$out/write.log" 2>&1
 # SQ counters (instruction mix, stalls, LDS conflicts), two more separate passes
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -f csv -d "$out/sq1" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/sq1.log" 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC -f csv -d "$out/sq2" -- python3 bench.py --no-cpu --no-pcie --no-stages --steps 3 --warmup 1 > "$out/sq2.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES -f csv -d "$out/sq1" -- python3 bench.py --no-cpu --no-pcie --no-stages --no-configs --steps 3 --warmup 1 > "$out/sq1.log" 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC -f csv -d "$out/sq2" -- python3 bench.py --no-cpu --no-pcie --no-stages --no-configs --steps 3 --warmup 1 > "$out/sq2.log" 2>&1
 # the large-read path (BASELINE configs[3]: uint32 buffers of 10 M elements): bench lines, kernel stats, traffic, SQ counters
 python3 bench.py --workload config4 --no-cpu > "$out/bench_config4.json" 2> "$out/bench_config4.err"
 python3 bench.py --workload config4 --buffers 1 --no-cpu > "$out/bench_config4_one_buffer.json" 2>> "$out/bench_config4.err"

@@ -57,6 +57,14 @@ struct vbz_gpu_ctx
     int routing = 1;       // VBZ_HIP_ROUTING=0: by batch shape only (2: experiment, the second group is not launched)
     vbz_gpu_ctx* large = nullptr;   // per-read routing: the second group's own stream and buffers (it runs beside the first group)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // A large batch on the one-workgroup path is coded as TWO HALVES on two streams (split_batch): the upper half on this child context
+    vbz_gpu_ctx* half = nullptr;
+    hipEvent_t ev_hfork = nullptr, ev_hjoin = nullptr, ev_hstagger = nullptr;
+    DevBuf splitmeta;          // the scratch plan of the whole batch (slot offsets, capacities, gates), shared by the two halves
+    uint32_t split_min = 16384;   // VBZ_HIP_SPLIT_MIN: batches of this many reads and more are split (0: never)
+    int split_stagger = 0;        // VBZ_HIP_SPLIT_STAGGER=1: the upper half starts behind the lower half's first large launch (measured: 548 GB/s
+                                  // against 565 when both halves start together -- the device interleaves the two queues by itself)
+    bool last_split = false;      // vbz_gpu_decode_paths: the last decompress call ran as halves
     // single-buffer API staging
     DevBuf one_in, one_out, one_meta;
     DevBuf dbg;       // per-read phase timers (VBZ_HIP_PHASE_TIMING=1)
@@ -370,9 +378,20 @@ ReadBatch to_rb(const vbz_gpu_batch* bt)
     return rb;
 }
 
+// The scratch plan of a batch made ONCE for both halves of a split call (split_batch): the group then takes its slots from here
+// instead of planning its own, and its scratch is the planning context's.
+struct Preplanned
+{
+    void* scratch = nullptr;
+    uint64_t* svb_off = nullptr;
+    uint32_t *svb_cap = nullptr, *gate = nullptr;
+    hipEvent_t after_first = nullptr;   // recorded on the group's stream behind its first large launch (the other half may wait for it)
+};
+
 // One launch group of a compress call: the reads of rb_in (those whose gate is closed left alone), on the one-workgroup path or
 // on the large-read path.  src_bytes: extent of the raw bytes of the group's reads.
-int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, const CompressionOptions* o, int sized, bool segmented)
+int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, const CompressionOptions* o, int sized, bool segmented,
+                   const Preplanned* pre = nullptr)
 {
     const uint32_t n = rb_in.n_reads;
     if (n == 0) return 0;
@@ -398,7 +417,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
     if (both_stages) {
         svb_factor(o->integer_size, o->perform_delta_zig_zag, &num, &den);
         scratch_need = (size_t)(((unsigned __int128)bt->src_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
-        if (!ensure(c, c->scratch, scratch_need)) return -1;
+        if (!pre && !ensure(c, c->scratch, scratch_need)) return -1;
         if (!ensure(c, c->meta, (size_t)n * 40 + 256)) return -1;
         mc = MetaCarver(c->meta.p);
         svb_off = mc.take<uint64_t>(n);
@@ -406,7 +425,14 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         svb_size = mc.take<uint32_t>(n);
         gate = mc.take<uint32_t>(n);
         deep_d = mc.take<uint32_t>(n);
+        if (pre) {   // (both stages, one-workgroup path: what split_batch asks for)
+            svb_off = pre->svb_off;
+            svb_cap = pre->svb_cap;
+            gate = pre->gate;
+            scratch_planned = true;
+        }
     }
+    void* const scratch_base = pre ? pre->scratch : c->scratch.p;
     const ScratchPlan splan = { num, den, c->scratch.cap, svb_off, svb_cap, gate };
     if (segmented && plan_segments(c, n, bt->src_size, rb_in.gate, bt->src_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg,
                                    both_stages ? &splan : nullptr, &scratch_planned) != 0)
@@ -435,7 +461,7 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         HIPCHK(c, launch_plan_scratch(n, bt->src_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, rb.gate != nullptr, s), "plan launch");
     }
     ReadBatch a = rb;
-    a.dst = (uint8_t*)c->scratch.p;
+    a.dst = (uint8_t*)scratch_base;
     a.dst_off = svb_off;
     a.dst_cap = svb_cap;
     a.result = svb_size;
@@ -461,8 +487,9 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
                    "svb_encode launch");
         if (matcher && c->long_repeats == 3) (void)hipMemsetAsync(deep_d, 0, 4ull * n, s);
     }
+    if (pre && pre->after_first) HIPCHK(c, hipEventRecord(pre->after_first, s), "event record");
     ReadBatch z = rb;
-    z.src = (const uint8_t*)c->scratch.p;
+    z.src = (const uint8_t*)scratch_base;
     z.src_off = svb_off;
     z.src_size = svb_size;
     if (segmented) {  // few, large reads: one wavefront per span of a stream, then compaction
@@ -563,7 +590,8 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
 
 // One launch group of a decompress call: the reads of rb_in (dst_cap = the exact decoded byte counts; those whose gate is closed
 // left alone), on the one-workgroup path or on the large-read path.  dst_bytes: extent of the decoded bytes of the group.
-int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes, const CompressionOptions* o, bool segmented)
+int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes, const CompressionOptions* o, bool segmented,
+                     const Preplanned* pre = nullptr)
 {
     const uint32_t n = rb_in.n_reads;
     if (n == 0) return 0;
@@ -588,14 +616,22 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
     if (both_stages) {
         svb_factor(o->integer_size, false, &num, &den);  // any code length may appear in a foreign stream
         scratch_need = (size_t)(((unsigned __int128)dst_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
-        if (!ensure(c, c->scratch, scratch_need)) return -1;
+        if (!pre && !ensure(c, c->scratch, scratch_need)) return -1;
     }
     const ScratchPlan splan = { num, den, c->scratch.cap, svb_off, svb_cap, gate };
     bool scratch_planned = false;
+    void* const scratch_base = pre ? pre->scratch : c->scratch.p;
+    if (pre) {   // (both stages, one-workgroup path: split_batch) -- slots and gates planned once for the whole batch
+        svb_off = pre->svb_off;
+        svb_cap = pre->svb_cap;
+        gate = pre->gate;
+        rb.gate = gate;
+        scratch_planned = true;
+    }
     if (segmented && plan_segments(c, n, rb.dst_cap, rb.gate, dst_bytes, svb_seg_unit_bytes((int)o->integer_size), &seg, both_stages ? &splan : nullptr,
                                    &scratch_planned) != 0)
         return -1;
-    const bool gate_in = segmented || rb.gate != nullptr;
+    const bool gate_in = !pre && (segmented || rb.gate != nullptr);
     if (gate_in) {   // (the caller's gate; E_OOM for a read whose segments do not fit the tables)
         if (!scratch_planned) HIPCHK(c, hipMemcpyAsync(gate, segmented ? seg.gate : rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
         rb.gate = gate;
@@ -624,7 +660,7 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
         HIPCHK(c, launch_plan_scratch(n, rb.dst_cap, num, den, c->scratch.cap, svb_off, svb_cap, gate, gate_in, s), "plan launch");
     }
     ReadBatch z = rb;
-    z.dst = (uint8_t*)c->scratch.p;
+    z.dst = (uint8_t*)scratch_base;
     z.dst_off = svb_off;
     z.dst_cap = svb_cap;
     z.result = svb_size;
@@ -666,9 +702,10 @@ int decompress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t dst_bytes,
         // decode it and then fail in the svb stage with a stream error
         if (zstd_frames(c, z, E_STREAM, dst_bytes, dbg) != 0) return -1;
     }
+    if (pre && pre->after_first) HIPCHK(c, hipEventRecord(pre->after_first, s), "event record");
     dbg_end(c, n, "zstd_decode: parse flush seqtables chain place huftable header queue | general sequences: flush tables records literals matches", dbg);
     ReadBatch d = rb;
-    d.src = (const uint8_t*)c->scratch.p;
+    d.src = (const uint8_t*)scratch_base;
     d.src_off = svb_off;
     d.src_size = svb_size;
     d.gate = gate;
@@ -762,6 +799,131 @@ int route_join(vbz_gpu_ctx* c, const Routed& r, uint32_t* result)
     return 0;
 }
 
+
+// ---- two halves of a batch in flight -------------------------------------------------------------------------------------
+// One launch sequence per batch leaves the device to ONE kind of kernel at a time: instruction-bound launches (svb, packing) and
+// latency-bound ones (planning, the stream decoder) each run alone, and every launch ends in a tail of partly idle CUs.  Two contexts
+// coding alternate batches on streams of their own measured 572 GB/s where one reaches 545 (profiles/r05r_two_in_flight.txt).  The
+// same inside ONE call: descriptors are validated, the sized headers parsed, long reads routed and the scratch slots of ALL reads
+// planned once on the context's stream; then the reads are cut at the midpoint of the table, the lower half goes on on this
+// stream, the upper half on a child context's stream (its own per-read tables; the scratch arena and its plan are shared -- every
+// per-read table is an array, so a half is a pointer offset), and the child's stream is joined before the call returns.  A read's
+// bytes do not depend on its neighbours, so the output is what the unsplit call writes (tests/test_gpu_split.py: sha256).
+bool split_applies(const vbz_gpu_ctx* c, const CompressionOptions* o, uint32_t n)
+{
+    return c->split_min != 0 && n >= c->split_min && o->integer_size != 0 && o->zstd_compression_level != 0 && !half_codec(o) && !c->phase_timing && !c->trace;
+}
+
+struct Split
+{
+    uint32_t h = 0;              // reads [0, h) stay on the context, [h, n) go to the child
+    Preplanned lo, hi;
+};
+
+// raw_size: the reads' raw (decoded) byte counts; num / den as the group would have chosen them
+int split_plan(vbz_gpu_ctx* c, const ReadBatch& rb, const uint32_t* raw_size, uint64_t raw_bytes, uint32_t num, uint32_t den, Split* sp)
+{
+    const uint32_t n = rb.n_reads;
+    if (!c->half) {
+        c->half = vbz_gpu_create(c->device, nullptr);
+        if (!c->half || hipEventCreateWithFlags(&c->ev_hfork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_hjoin, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_hstagger, hipEventDisableTiming) != hipSuccess) {
+            set_error(c, "could not create the context of a batch's upper half");
+            return -1;
+        }
+        c->half->routing = 0;
+        c->half->split_min = 0;
+        c->half->segmented = 0;
+    }
+    vbz_gpu_ctx* k = c->half;
+    k->trailers = c->trailers;
+    k->zero_run_sequences = c->zero_run_sequences;
+    k->long_repeats = c->long_repeats;
+    k->staged_encode = c->staged_encode;
+    k->fast_decode = c->fast_decode;
+    k->ref_chains = c->ref_chains;
+    k->fuse_svb = c->fuse_svb;
+    k->profiling = c->profiling;
+    const size_t scratch_need = (size_t)(((unsigned __int128)raw_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
+    if (!ensure(c, c->scratch, scratch_need) || !ensure(c, c->splitmeta, (size_t)n * 16 + 256)) return -1;
+    MetaCarver mc(c->splitmeta.p);
+    uint64_t* svb_off = mc.take<uint64_t>(n);
+    uint32_t* svb_cap = mc.take<uint32_t>(n);
+    uint32_t* gate = mc.take<uint32_t>(n);
+    hipStream_t s = c->stream;
+    if (rb.gate) HIPCHK(c, hipMemcpyAsync(gate, rb.gate, 4ull * n, hipMemcpyDeviceToDevice, s), "gate copy");
+    {
+        Timed t(c, "plan_scratch");
+        HIPCHK(c, launch_plan_scratch(n, raw_size, num, den, c->scratch.cap, svb_off, svb_cap, gate, rb.gate != nullptr, s), "plan launch");
+    }
+    sp->h = n / 2;
+    sp->lo.scratch = sp->hi.scratch = c->scratch.p;
+    sp->lo.svb_off = svb_off;
+    sp->lo.svb_cap = svb_cap;
+    sp->lo.gate = gate;
+    sp->hi.svb_off = svb_off + sp->h;
+    sp->hi.svb_cap = svb_cap + sp->h;
+    sp->hi.gate = gate + sp->h;
+    if (c->split_stagger) sp->lo.after_first = c->ev_hstagger;
+    HIPCHK(c, hipEventRecord(c->ev_hfork, s), "event record");
+    HIPCHK(c, hipStreamWaitEvent(k->stream, c->ev_hfork, 0), "stream wait");
+    return 0;
+}
+
+ReadBatch upper_half(const ReadBatch& rb, uint32_t h)
+{
+    ReadBatch u = rb;
+    u.n_reads = rb.n_reads - h;
+    u.src_off += h;
+    u.src_size += h;
+    u.dst_off += h;
+    u.dst_cap += h;
+    u.result += h;
+    if (u.gate) u.gate += h;
+    return u;
+}
+
+// the upper half's stream is joined whatever happened in between (it may still be writing the caller's arenas)
+int split_join(vbz_gpu_ctx* c)
+{
+    HIPCHK(c, hipEventRecord(c->ev_hjoin, c->half->stream), "event record");
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_hjoin, 0), "stream wait");
+    if (c->error.empty() && !c->half->error.empty()) c->error = c->half->error;
+    return 0;
+}
+
+int compress_split(vbz_gpu_ctx* c, const ReadBatch& rb, uint64_t src_bytes, const CompressionOptions* o, int sized)
+{
+    uint32_t num, den;
+    svb_factor(o->integer_size, o->perform_delta_zig_zag, &num, &den);
+    Split sp;
+    if (split_plan(c, rb, rb.src_size, src_bytes, num, den, &sp) != 0) return -1;
+    ReadBatch lo = rb;
+    lo.n_reads = sp.h;
+    int rc = compress_group(c, lo, src_bytes, o, sized, false, &sp.lo);
+    if (rc == 0 && c->split_stagger && hipStreamWaitEvent(c->half->stream, c->ev_hstagger, 0) != hipSuccess) rc = -1;
+    if (rc == 0) rc = compress_group(c->half, upper_half(rb, sp.h), src_bytes, o, sized, false, &sp.hi);
+    if (split_join(c) != 0) rc = -1;
+    return rc;
+}
+
+int decompress_split(vbz_gpu_ctx* c, const ReadBatch& rb, uint64_t dst_bytes, const CompressionOptions* o)
+{
+    uint32_t num, den;
+    svb_factor(o->integer_size, false, &num, &den);
+    Split sp;
+    if (split_plan(c, rb, rb.dst_cap, dst_bytes, num, den, &sp) != 0) return -1;
+    ReadBatch lo = rb;
+    lo.n_reads = sp.h;
+    int rc = decompress_group(c, lo, dst_bytes, o, false, &sp.lo);
+    if (rc == 0 && c->split_stagger && hipStreamWaitEvent(c->half->stream, c->ev_hstagger, 0) != hipSuccess) rc = -1;
+    if (rc == 0) rc = decompress_group(c->half, upper_half(rb, sp.h), dst_bytes, o, false, &sp.hi);
+    if (split_join(c) != 0) rc = -1;
+    c->last_split = rc == 0;
+    return rc;
+}
+
 // The caller's descriptor table is untrusted (vbz_gpu.h): one thread per read checks its slots against the declared arenas before any
 // other kernel forms an address from them; the verdicts are the gate every launch group of the call starts from.
 int validate_descriptors(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, ReadBatch* rb)
@@ -796,7 +958,9 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     ReadBatch rb = to_rb(bt);
     if (!own_descriptors && validate_descriptors(c, bt, &rb) != 0) return -1;
     const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n, false);
-    if (by_shape || !routing_applies(c, o, bt->src_bytes, n)) return compress_group(c, rb, bt->src_bytes, o, sized, by_shape);
+    const bool split = !by_shape && split_applies(c, o, n);
+    if (by_shape || !routing_applies(c, o, bt->src_bytes, n))
+        return split ? compress_split(c, rb, bt->src_bytes, o, sized) : compress_group(c, rb, bt->src_bytes, o, sized, by_shape);
     Routed r;
     if (route(c, rb, bt->src_size, &r) != 0) return -1;
     ReadBatch small = rb;
@@ -805,7 +969,7 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     // returns -- it may still be writing the caller's arenas -- and its error message becomes the context's
     int rc = 0;
     if (c->routing != 2 && compress_group(c->large, r.large, ROUTE_MAX_BYTES, o, sized, true) != 0) rc = -1;
-    if (rc == 0 && compress_group(c, small, bt->src_bytes, o, sized, false) != 0) rc = -1;
+    if (rc == 0 && (split ? compress_split(c, small, bt->src_bytes, o, sized) : compress_group(c, small, bt->src_bytes, o, sized, false)) != 0) rc = -1;
     if (rc != 0 && c->error.empty() && !c->large->error.empty()) c->error = c->large->error;
     if (route_join(c, r, bt->result) != 0) rc = -1;
     return rc;
@@ -835,14 +999,17 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         rb.gate = gate;
     }
     const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n, true);
-    if (by_shape || !routing_applies(c, o, bt->dst_bytes, n)) return decompress_group(c, rb, bt->dst_bytes, o, by_shape);
+    const bool split = !by_shape && split_applies(c, o, n);
+    c->last_split = false;
+    if (by_shape || !routing_applies(c, o, bt->dst_bytes, n))
+        return split ? decompress_split(c, rb, bt->dst_bytes, o) : decompress_group(c, rb, bt->dst_bytes, o, by_shape);
     Routed r;
     if (route(c, rb, rb.dst_cap, &r) != 0) return -1;   // by the decoded size
     ReadBatch small = rb;
     small.gate = r.gate_small;
     int rc = 0;   // (as in compress_batch_impl: the second stream is joined whatever happens)
     if (c->routing != 2 && decompress_group(c->large, r.large, ROUTE_MAX_BYTES, o, true) != 0) rc = -1;
-    if (rc == 0 && decompress_group(c, small, bt->dst_bytes, o, false) != 0) rc = -1;
+    if (rc == 0 && (split ? decompress_split(c, small, bt->dst_bytes, o) : decompress_group(c, small, bt->dst_bytes, o, false)) != 0) rc = -1;
     if (rc != 0 && c->error.empty() && !c->large->error.empty()) c->error = c->large->error;
     if (route_join(c, r, bt->result) != 0) rc = -1;
     return rc;
@@ -903,6 +1070,8 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_SPLIT_MIN")) c->split_min = (uint32_t)strtoul(e, nullptr, 10);   // 0: a batch is never coded as two halves
+    if (const char* e = getenv("VBZ_HIP_SPLIT_STAGGER")) c->split_stagger = atoi(e);
 #ifdef VBZ_EXPERIMENTS
     if (const char* e = getenv("VBZ_HIP_PHASE_TIMING")) c->phase_timing = atoi(e);   // timed instantiations of the entropy kernels
     if (const char* e = getenv("VBZ_HIP_LONG_REPEATS")) c->long_repeats = atoi(e);   // 2: probe only, 3: second launch only
@@ -951,9 +1120,12 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs, &c->splitmeta })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
+    if (c->half) vbz_gpu_destroy(c->half);
+    for (hipEvent_t e : { c->ev_hfork, c->ev_hjoin, c->ev_hstagger })
+        if (e) (void)hipEventDestroy(e);
     if (c->side.fork) (void)hipEventDestroy(c->side.fork);
     if (c->side.join) (void)hipEventDestroy(c->side.join);
     if (c->side.stream) (void)hipStreamDestroy(c->side.stream);
@@ -1113,6 +1285,7 @@ void vbz_gpu_profile_enable(vbz_gpu_ctx* c, int enable)
     if (!c) return;
     if (!enable) drain_profile(c);
     c->profiling = enable != 0;
+    if (c->half) vbz_gpu_profile_enable(c->half, enable);
 }
 
 int vbz_gpu_decode_span_paths(vbz_gpu_ctx* c, uint32_t* by_spans)
@@ -1130,9 +1303,21 @@ int vbz_gpu_decode_span_paths(vbz_gpu_ctx* c, uint32_t* by_spans)
     return (int)c->last_span_frames;
 }
 
+static int decode_paths_one(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked);
+
 int vbz_gpu_decode_paths(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)
 {
     if (!c) return -1;
+    uint32_t b0 = 0, w0 = 0, b1 = 0, w1 = 0;
+    const int n0 = decode_paths_one(c, &b0, &w0);
+    const int n1 = (n0 >= 0 && c->last_split && c->half) ? decode_paths_one(c->half, &b1, &w1) : 0;   // (the upper half of a split call)
+    if (batched) *batched = b0 + b1;
+    if (walked) *walked = w0 + w1;
+    return (n0 < 0 || n1 < 0) ? -1 : n0 + n1;
+}
+
+static int decode_paths_one(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)
+{
     DeviceGuard guard(c->device);
     if (batched) *batched = 0;
     if (walked) *walked = 0;
@@ -1169,12 +1354,28 @@ void vbz_gpu_profile_reset(vbz_gpu_ctx* c)
     if (!c) return;
     drain_profile(c);
     c->prof.clear();
+    if (c->half) vbz_gpu_profile_reset(c->half);
 }
 
 int vbz_gpu_profile_read(vbz_gpu_ctx* c, const char** names, uint32_t* launches, double* total_ms, int cap)
 {
     if (!c) return 0;
     drain_profile(c);
+    if (c->half) {   // the upper halves of split calls: their launches count under the same labels
+        drain_profile(c->half);
+        for (auto& h : c->half->prof) {
+            bool found = false;
+            for (auto& e : c->prof)
+                if (strcmp(e.name, h.name) == 0) {
+                    e.launches += h.launches;
+                    e.ms += h.ms;
+                    found = true;
+                    break;
+                }
+            if (!found) c->prof.push_back(h);
+        }
+        c->half->prof.clear();
+    }
     int k = 0;
     for (auto& e : c->prof) {
         if (k < cap) {
