@@ -50,6 +50,54 @@ def test_svb_int16_zigzag_encode_bit_exact():
         assert _same(g, want), len(a)
 
 
+def test_svb_int16_zigzag_whole_tile_pairs_and_their_fallback():
+    """The int16 zig-zag encoder codes pairs of whole tiles (4096 samples) in a loop of its own (svb_kernels.hip: I16Pairs) whose stage
+    buffers hold 3/2 bytes per value; a pair that needs more ends that loop and the tile-by-tile loop codes the rest.  Quiet signal
+    (one byte per value), noise (two), wrap-around deltas, and reads that change from one to the other inside and at the edges of a
+    pair -- through the svb stage alone (level 0 of the product: byte-identical to the reference, sse3.h:406-466) and through the
+    whole compress path with its histogram hand-over and probe, unaligned destinations included."""
+    import gpu_util as G
+    from vbz_compression_amd import _lib
+
+    rng = np.random.default_rng(606)
+    T = 2048
+
+    def quiet(n):
+        return (300 + np.cumsum(rng.integers(-40, 41, n))).astype(np.int16)
+
+    def noise(n):
+        return rng.integers(-32768, 32768, n).astype(np.int16)
+
+    def border(n):   # values whose zig-zag sits at the one-byte / two-byte border: 127, -128 | 128, -129
+        return np.cumsum(rng.choice(np.array([127, -128, 128, -129, 0, 1, -1]), n)).astype(np.int16)
+
+    reads = [quiet(20 * T + 77), noise(9 * T + 5), border(13 * T), quiet(2 * T), quiet(3 * T - 1), quiet(4 * T + 1),
+             np.concatenate([quiet(5 * T), noise(3 * T), quiet(6 * T + 9)]),          # the loop ends on the noisy pair, the rest goes tile by tile
+             np.concatenate([quiet(T), noise(T // 2), quiet(7 * T + T // 2)]),        # a pair that is half noise still fits
+             np.concatenate([noise(2 * T), quiet(8 * T)]),
+             np.concatenate([quiet(6 * T), border(6 * T + 3), noise(100)]),
+             np.full(10 * T, -32768, np.int16), np.tile(np.array([32767, -32768], np.int16), 5 * T),
+             np.arange(0, 12 * T, dtype=np.int64).astype(np.int16)]
+    got = G.svb_compress(reads, 2, True)
+    for a, g in zip(reads, got):
+        assert _same(g, O.svb_compress(a, 2, True, 0)), len(a)
+    for align in (64, 1):   # (1: data sections that start anywhere -- the partly owned first 16 bytes)
+        old = G.DST_ALIGN
+        G.DST_ALIGN = align
+        try:
+            for level in (0, 1):
+                opts = _lib.CompressionOptions(True, 2, level, 1)
+                frames = G.compress(reads, opts, sized=True)
+                for a, f in zip(reads, frames):
+                    assert not isinstance(f, int), f
+                    if level == 0:
+                        assert _same(f, O.compress(a, O.options(True, 2, 0, 1), sized=True)), len(a)
+                    else:
+                        assert O.decompress(f, a.nbytes, O.options(True, 2, 1, 1), sized=True).tobytes() == a.tobytes(), len(a)
+        finally:
+            G.DST_ALIGN = old
+
+
 def test_svb_int16_zigzag_decode_bit_exact():
     import gpu_util as G
 

@@ -119,6 +119,213 @@ __device__ __forceinline__ void cnt_count16(uint32_t* h, const uint4& v)
     }
 }
 
+// ---- pairs of whole int16 zig-zag tiles (round 6) --------------------------------------------------------------------------------------
+// The tile loop of svb_encode_range issues ~185 wave-level VALU instructions per 512 samples of a wavefront, most of them the 4-cycle
+// kind (tools/valu_rate.hip: compares, selects, v_bfe, DPP), and four workgroup barriers per tile: the kernel sat on instruction issue
+// at 4.6 ms per 65 536 reads where its 21.4 GB would take 3.5 at a copy's rate.  Whole tiles of int16 samples -- all but the ends of a
+// read -- now go through this loop, two tiles (4096 samples) per trip:
+//   * the samples stay PACKED (two per register) from the load to the byte stores: delta and zig-zag as before (v_pk_*), then the eight
+//     high bytes of a lane's values are gathered into two registers (v_perm_b32) and "is this byte non-zero" is byte-parallel
+//     arithmetic on four values at once -- (((h & 0x7f7f7f7f) + 0x7f7f7f7f) | h) & 0x80808080 --; one multiplication turns the four
+//     flags into the key byte (bits 0, 2, 4, 6), another into their prefix sums (a byte each: where each value's bytes go, and the
+//     lane's byte count), instead of eight compares and a dozen selects;
+//   * ONE workgroup scan for both tiles: their byte counts ride in the two halves of one register (a tile has at most 4096 bytes);
+//   * byte emission as before (two ds_write_b8 per value, a one-byte value's zero high byte overwritten by the next value's low byte),
+//     but straight from the packed registers (ds_write_b8_d16_hi for the odd values) at offsets cut out of the prefix-sum register;
+//   * two stage buffers used in turn, so that the bytes that do not fill a 16-byte chunk move to the OTHER buffer while this one is
+//     being flushed: two barriers per trip (eight before, for two tiles), and every thread of the workgroup has a chunk to flush.
+// Same bytes, same probe and histogram hand-over (the flush is the old one); tests/test_gpu_parity.py holds both to the oracle.
+template <bool PROBE, bool CNT>
+struct I16Pairs
+{
+    // one stage buffer: the kept bytes + two tiles at 3/2 bytes per value (signal: 1.01; all of 2 would be 8 KB, and a workgroup's LDS
+    // decides how many of them a CU holds).  A pair that does not fit ends the loop: the tile loop of svb_encode_range codes the rest.
+#ifndef VBZ_ENC_BUF_BYTES
+#define VBZ_ENC_BUF_BYTES (2 * WG * 8 * 3 / 2 + 32)
+#endif
+    static constexpr uint32_t TILE = WG * 8, BUF = VBZ_ENC_BUF_BYTES;
+    const uint8_t* in;
+    uint8_t* keys;
+    uint8_t* gal;
+    uint8_t* stage;      // two buffers of BUF bytes; [0] is the one the caller's own loop uses
+    uint32_t* wsum;      // 8 words
+    PeriodProbe* pp;
+    CntLds* CL;
+    uint32_t A, hmode;
+    bool cnt_on;
+    uint32_t probe_p0;
+
+    // zig-zag of the wrap-around deltas of a lane's eight samples, packed (sse3.h:432-440); pw's top half = the sample in front
+    static __device__ __forceinline__ void zz4(const uint4& q, uint32_t pw, uint32_t Z[4])
+    {
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const uint32_t w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t prevw = __builtin_amdgcn_alignbit(w[k], k ? w[k - 1] : pw, 16);
+            const s16x2 d = __builtin_bit_cast(s16x2, w[k]) - __builtin_bit_cast(s16x2, prevw);
+            Z[k] = __builtin_bit_cast(uint32_t, (s16x2)((d << (s16x2)1) ^ (d >> (s16x2)15)));
+        }
+    }
+    // flags (bit 0 of every byte) "value j of four needs two bytes", from the packed values Za (values 0, 1) and Zb (values 2, 3)
+    static __device__ __forceinline__ uint32_t flags4(uint32_t Za, uint32_t Zb)
+    {
+        const uint32_t h = __builtin_amdgcn_perm(Zb, Za, 0x07050301u);   // the four high bytes
+        return ((((h & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | h) & 0x80808080u) >> 7;
+    }
+    // a lane's 8 .. 16 data bytes at s (LDS): both bytes of every value are written, a one-byte value's zero high byte is overwritten by
+    // the next value's low byte (a later instruction of this lane); only the lane's LAST value must not touch the byte behind it
+    static __device__ __forceinline__ void emit8(uint8_t* s, const uint32_t Z[4], uint32_t ps0, uint32_t ps1)
+    {
+        const uint32_t Y0 = Z[0] >> 8, Y1 = Z[1] >> 8, Y2 = Z[2] >> 8, Y3 = Z[3] >> 8;
+        s[1] = (uint8_t)Y0;
+        uint8_t* t = s + (ps0 & 0xFFu);
+        t[1] = (uint8_t)(Z[0] >> 16);
+        s[0] = (uint8_t)Z[0];   // (behind a store that may alias s[1]: the two are not to be fused into one unaligned 16-bit store, which is slow)
+        t[2] = (uint8_t)(Y0 >> 16);
+        t = s + ((ps0 >> 8) & 0xFFu);
+        t[2] = (uint8_t)Z[1];
+        t[3] = (uint8_t)Y1;
+        t = s + ((ps0 >> 16) & 0xFFu);
+        t[3] = (uint8_t)(Z[1] >> 16);
+        t[4] = (uint8_t)(Y1 >> 16);
+        uint8_t* const s4 = s + (ps0 >> 24);
+        s4[4] = (uint8_t)Z[2];
+        s4[5] = (uint8_t)Y2;
+        t = s4 + (ps1 & 0xFFu);
+        t[5] = (uint8_t)(Z[2] >> 16);
+        t[6] = (uint8_t)(Y2 >> 16);
+        t = s4 + ((ps1 >> 8) & 0xFFu);
+        t[6] = (uint8_t)Z[3];
+        t[7] = (uint8_t)Y3;
+        t = s4 + ((ps1 >> 16) & 0xFFu);
+        t[7] = (uint8_t)(Z[3] >> 16);
+        if (Z[3] >> 24) t[8] = (uint8_t)(Y3 >> 16);
+    }
+
+    // one 16-byte chunk of the stage leaves for gal + F + 16 c (the flush of svb_encode_range, chunk by chunk)
+    __device__ __forceinline__ void flush_chunk(const uint8_t* buf, uint64_t F, uint32_t c, int wv)
+    {
+        uint8_t* g = gal + F + 16ull * c;
+        if (F == 0 && c == 0 && A != 0) {
+            for (uint32_t j = A; j < 16; ++j) g[j] = buf[j];
+            if (CNT && cnt_on)
+                for (uint32_t j = A; j < 16; ++j) atomicAdd(&CL->hA[wv][buf[j]], 1u);
+            return;
+        }
+        const uint4 v = *reinterpret_cast<const uint4*>(buf + 16u * c);
+        *reinterpret_cast<uint4*>(g) = v;
+        if (CNT && cnt_on) {
+            const uint32_t cq = (uint32_t)(F >> 4) + c - (A ? 1u : 0u);
+            if (((cq >> 6) & 3u) == 0u) cnt_count16(CL->hA[wv], v);
+            else if (hmode == 2u) cnt_count16(CL->hB, v);
+        }
+        if (PROBE && probe_p0) {
+            const uint32_t h = probe_hash(v.x);
+            if (pp->val[h] == v.x) {
+                const uint64_t rel = F + 16ull * c - A;
+                const uint32_t j = pp->idx[h], k = j >> 2, sh = j & 3u;
+                const uint32_t c0 = __builtin_amdgcn_alignbyte(pp->ctx[k + 1], pp->ctx[k], sh), c1 = __builtin_amdgcn_alignbyte(pp->ctx[k + 2], pp->ctx[k + 1], sh);
+                const uint32_t c2 = __builtin_amdgcn_alignbyte(pp->ctx[k + 3], pp->ctx[k + 2], sh), c3 = __builtin_amdgcn_alignbyte(pp->ctx[k + 4], pp->ctx[k + 3], sh);
+                if (rel >= (uint64_t)probe_p0 + j + PROBE_MIN_D && rel < 0xFFFFFFFFull && c0 == v.x && c1 == v.y && c2 == v.z && c3 == v.w)
+                    atomicMin(&pp->best, (uint32_t)rel - (probe_p0 + j));
+            }
+        }
+    }
+
+    // tiles t0, t0 + TILE, ... while two whole ones are left; the bytes [F, P) the caller holds at the head of stage buffer 0 are
+    // taken over and handed back the same way.  Returns the first value not coded.  All 256 threads; the caller's next barrier
+    // orders the last LDS writes.
+    static __device__ __forceinline__ uint64_t uniform64(uint64_t v)
+    {
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+    }
+    __device__ __forceinline__ uint32_t run(uint32_t t0_in, uint32_t end_in, uint64_t& F_io, uint64_t& P_io)
+    {
+        const int tid = threadIdx.x, lane = tid & 63;
+        // workgroup-uniform state, held in scalar registers
+        uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0_in);
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)end_in);
+        uint64_t F = uniform64(F_io), P = uniform64(P_io);
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t m0 = wv > 0 ? 0xFFFFFFFFu : 0u, m1 = wv > 1 ? 0xFFFFFFFFu : 0u, m2 = wv > 2 ? 0xFFFFFFFFu : 0u;
+        uint32_t cur = 0;   // the stage buffer this trip writes
+        const uint8_t* ip = in + ((size_t)t0 + (size_t)tid * 8) * 2;
+        uint8_t* kp = keys + ((t0 + (uint32_t)tid * 8) >> 2);
+        // lane 0 of a wavefront: the aligned dword in front of its samples -- its top half is the sample in front (samples start 16-byte
+        // aligned here, and the read's very first value has nothing in front of it)
+        auto prev_of = [&](const uint8_t* p, bool first_value) -> uint32_t {
+            return (lane == 0 && !first_value) ? *reinterpret_cast<const uint32_t*>(p - 4) : 0u;
+        };
+        uint4 na = *reinterpret_cast<const uint4*>(ip), nb = *reinterpret_cast<const uint4*>(ip + TILE * 2);
+        uint32_t npa = prev_of(ip, t0 == 0 && tid == 0), npb = prev_of(ip + TILE * 2, false);
+        uint32_t par = 0;
+        while (end - t0 >= 2u * TILE) {
+            const uint4 qa = na, qb = nb;
+            const uint32_t pa = npa, pb = npb;
+            if (end - t0 >= 4u * TILE) {   // the next pair's samples are requested a trip ahead
+                na = *reinterpret_cast<const uint4*>(ip + TILE * 4);
+                nb = *reinterpret_cast<const uint4*>(ip + TILE * 6);
+                npa = prev_of(ip + TILE * 4, false);
+                npb = prev_of(ip + TILE * 6, false);
+            }
+            uint32_t ZA[4], ZB[4];
+            {
+                uint32_t pw = wave_prev_lane_u32(qa.w);
+                if (lane == 0) pw = pa;
+                zz4(qa, pw, ZA);
+                pw = wave_prev_lane_u32(qb.w);
+                if (lane == 0) pw = pb;
+                zz4(qb, pw, ZB);
+            }
+            const uint32_t fa0 = flags4(ZA[0], ZA[1]), fa1 = flags4(ZA[2], ZA[3]), fb0 = flags4(ZB[0], ZB[1]), fb1 = flags4(ZB[2], ZB[3]);
+            // key bytes: flag j of four to bit 2 j (codes 0 / 1 only); prefix sums of the flags, a byte each
+            const uint32_t ka = ((fa0 * 0x01041040u) >> 24) | (((fa1 * 0x01041040u) >> 24) << 8);
+            const uint32_t kb = ((fb0 * 0x01041040u) >> 24) | (((fb1 * 0x01041040u) >> 24) << 8);
+            const uint32_t pa0 = fa0 * 0x01010101u, pa1 = fa1 * 0x01010101u, pb0 = fb0 * 0x01010101u, pb1 = fb1 * 0x01010101u;
+            {
+                const uint16_t k0 = (uint16_t)ka, k1 = (uint16_t)kb;
+                __builtin_memcpy(kp, &k0, 2);
+                __builtin_memcpy(kp + TILE / 4, &k1, 2);
+            }
+            // one scan for both tiles: tile A's byte count in the low half, tile B's in the high half
+            const uint32_t L = (8u + (pa0 >> 24) + (pa1 >> 24)) | ((8u + (pb0 >> 24) + (pb1 >> 24)) << 16);
+            const uint32_t inc = wave_incl_scan_u32(L);
+            uint32_t* ws = wsum + par;
+            if (lane == 63) ws[wv] = inc;
+            wg_lds_barrier();   // (also: the previous trip's kept bytes stand in this trip's buffer, its flush has read the other one)
+            const uint4 s4 = *reinterpret_cast<const uint4*>(ws);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s4.x + s4.y + s4.z + s4.w));
+            const uint32_t ex = (s4.x & m0) + (s4.y & m1) + (s4.z & m2) + inc - L;
+            const uint32_t R = (uint32_t)(P - F), totA = tot & 0xFFFFu, totB = tot >> 16;
+            if (R + totA + totB + 1u > BUF) break;   // (workgroup-uniform; nothing of this pair is in the stage -- its control bytes are written again)
+            uint8_t* const buf = stage + cur * BUF;
+            emit8(buf + R + (ex & 0xFFFFu), ZA, pa0, pa1);
+            emit8(buf + R + totA + (ex >> 16), ZB, pb0, pb1);
+            wg_lds_barrier();
+            const uint32_t endidx = R + totA + totB, nch = endidx >> 4, rem = endidx & 15u;
+            if ((uint32_t)tid < nch) flush_chunk(buf, F, (uint32_t)tid, wv);
+            if ((uint32_t)tid + WG < nch) flush_chunk(buf, F, (uint32_t)tid + WG, wv);
+            if ((uint32_t)tid + 2 * WG < nch) flush_chunk(buf, F, (uint32_t)tid + 2 * WG, wv);   // (only when most values take two bytes)
+            if ((uint32_t)tid < rem) stage[(cur ^ 1u) * BUF + tid] = buf[16u * nch + tid];   // the bytes short of a chunk: to the other buffer
+            F += 16ull * nch;
+            P += totA + totB;
+            cur ^= 1u;
+            par ^= 4u;
+            t0 += 2u * TILE;
+            ip += TILE * 4;
+            kp += TILE / 2;
+        }
+        wg_lds_barrier();   // the last flush has read its buffer, the kept bytes stand in stage[cur]
+        if (cur != 0) {
+            if ((uint32_t)tid < (uint32_t)(P - F)) stage[tid] = stage[BUF + tid];
+        }
+        F_io = F;
+        P_io = P;
+        return t0;
+    }
+};
+
 // Values [first, end) of a read of n values (first a multiple of the tile size): control bytes to keys[first/4 ...),
 // data bytes to data[0 ...) -- `data` is where this range's data bytes start, any alignment; only bytes of the range
 // are touched.  COUNT_ONLY: nothing is written, the data byte count is all that is wanted.  Returns the data bytes
@@ -161,7 +368,21 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
         const uint32_t i0 = first + (uint32_t)tid * VPL;
         if (in_aligned && i0 < end && end - i0 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i0 * ELEM);
     }
+    constexpr bool FAST = I16ZZ && !COUNT_ONLY;   // pairs of whole int16 tiles take svb_i16zz_pairs (below)
+    bool fast_done = !FAST || !in_aligned;
     for (uint32_t t0 = first; t0 < end; t0 += TILE) {
+        if (FAST && !fast_done && (!PROBE || t0 != first)) {
+            // (with PROBE the read's first tile goes through the loop below, which builds the probe table from it)
+            fast_done = true;
+            if (end - t0 >= 2u * (uint32_t)TILE) {
+                I16Pairs<PROBE, CNT> fp = { in, keys, gal, stage, wsum, pp, CL, A, hmode, cnt_on, probe_p0 };
+                t0 = fp.run(t0, end, F, P);
+                if (t0 >= end) break;
+                const uint32_t i0 = t0 + (uint32_t)tid * VPL;
+                qnext = make_uint4(0u, 0u, 0u, 0u);
+                if (i0 < end && end - i0 >= (uint32_t)VPL) qnext = *reinterpret_cast<const uint4*>(in + (size_t)i0 * ELEM);
+            }
+        }
         const uint32_t i0 = t0 + (uint32_t)tid * VPL;
         const int valid = i0 >= end ? 0 : (end - i0 >= (uint32_t)VPL ? VPL : (int)(end - i0));
         const bool full = in_aligned && end - t0 >= (uint32_t)TILE;
@@ -379,17 +600,21 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
 template <int ELEM, bool I16ZZ>
 struct EncStage
 {
-    static constexpr int value = WG * Vpl<ELEM>::value * (I16ZZ ? 2 : 4) + 32;
+    // (int16 zig-zag: the two buffers of I16Pairs; the tile loop of svb_encode_range uses the head of the first, one tile's worst case)
+    static constexpr int value = I16ZZ ? 2 * (int)I16Pairs<false, false>::BUF : WG * Vpl<ELEM>::value * 4 + 32;
 };
 
 template <bool CNT> struct CntLdsOf { typedef CntLds type; };
 template <> struct CntLdsOf<false> { struct type { uint32_t none; }; };
 
+#ifndef VBZ_SVBENC_WAVES
+#define VBZ_SVBENC_WAVES 1
+#endif
 template <int ELEM, bool ZZ, bool I16ZZ, bool PROBE, bool CNT = false>
-__global__ __launch_bounds__(WG) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, uint32_t* period_hint, EncPlan* pre)
+__global__ __launch_bounds__(WG, VBZ_SVBENC_WAVES) void svb_encode_kernel(ReadBatch b, uint32_t hdr, uint32_t strict_cap, uint32_t* period_hint, EncPlan* pre)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage[EncStage<ELEM, I16ZZ>::value];
-    __shared__ uint32_t wsum[4];
+    __shared__ __attribute__((aligned(16))) uint32_t wsum[8];   // (I16Pairs uses two sets of four in turn)
     __shared__ PeriodProbe probe;   // (only the PROBE instantiations refer to it)
     __shared__ __attribute__((aligned(16))) typename CntLdsOf<CNT>::type cntl[1];   // (only the CNT instantiations have one)
 
@@ -501,7 +726,7 @@ __global__ __launch_bounds__(WG) void svb_seg_encode_kernel(ReadBatch b, uint32_
 {
     constexpr int SEG = WG * Vpl<ELEM>::value * SEG_TILES;
     __shared__ __attribute__((aligned(16))) uint8_t stage[COUNT_ONLY ? 16 : EncStage<ELEM, I16ZZ>::value];
-    __shared__ uint32_t wsum[4];
+    __shared__ __attribute__((aligned(16))) uint32_t wsum[8];   // (I16Pairs uses two sets of four in turn)
     __shared__ uint64_t sums_s[8];
     uint32_t r, k;
     if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
