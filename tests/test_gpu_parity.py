@@ -98,6 +98,44 @@ def test_svb_int16_zigzag_whole_tile_pairs_and_their_fallback():
             G.DST_ALIGN = old
 
 
+def test_svb_int16_zigzag_decoder_pipeline_and_its_hand_over():
+    """The int16 zig-zag decoder decodes pairs of whole tiles as a pipeline (svb_kernels.hip: I16DecPairs: the pair after the one being
+    decoded is planned and its bytes requested a trip ahead) and hands over to the tile loop -- which decides every verdict -- where a
+    pair is not of its kind: codes of 3 / 4 bytes (the reference's SIMD body keeps their low 16 bits, sse3.h:510-514), more bytes than a
+    stage buffer holds (noise), a stream shorter or longer than its control bytes announce.  Samples or the oracle's error, either way."""
+    import gpu_util as G
+
+    rng = np.random.default_rng(607)
+    T = 2048
+
+    def quiet(n):
+        return (300 + np.cumsum(rng.integers(-40, 41, n))).astype(np.int16)
+
+    def noise(n):
+        return rng.integers(-32768, 32768, n).astype(np.int16)
+
+    cases = []
+    for a in (quiet(20 * T + 77), noise(9 * T + 5), quiet(2 * T), quiet(4 * T), quiet(4 * T + 1), quiet(6 * T - 1),
+              np.concatenate([quiet(5 * T), noise(3 * T), quiet(6 * T + 9)]), np.concatenate([noise(2 * T), quiet(8 * T)]),
+              np.concatenate([quiet(T), noise(T // 2), quiet(7 * T + T // 2)])):
+        st = O.svb_compress(a, 2, True, 0)
+        cases.append((st, a.nbytes))
+        cases += [(st[:-1], a.nbytes), (st[:-3000], a.nbytes), (np.concatenate([st, np.zeros(2, np.uint8)]), a.nbytes), (st, a.nbytes - 2), (st, a.nbytes + 2)]
+    a = quiet(16 * T)
+    st = O.svb_compress(a, 2, True, 0)
+    K = (len(a) + 3) // 4
+    for value in (0, 7, 2 * T - 1, 2 * T, 4 * T + 3, 9 * T + 1000, 16 * T - 1):   # one wide code somewhere: first pair, a boundary, the last pair
+        for code in (2, 3):
+            w = st.copy()
+            w[value >> 2] |= code << (2 * (value & 3))
+            grown = np.concatenate([w, rng.integers(0, 256, 3, dtype=np.uint8)])   # (with the bytes the wider code announces)
+            cases += [(w, a.nbytes), (grown[: len(w) + code - (1 if (st[value >> 2] >> (2 * (value & 3))) & 1 else 0)], a.nbytes)]
+    got = G.svb_decompress([c[0] for c in cases], [c[1] for c in cases], 2, True)
+    for (stream, nbytes), g in zip(cases, got):
+        want = O.svb_decompress(stream, nbytes, 2, True, 0)
+        assert _same(g, want), (len(stream), nbytes)
+
+
 def test_svb_int16_zigzag_decode_bit_exact():
     import gpu_util as G
 

@@ -812,6 +812,160 @@ __global__ __launch_bounds__(WG) void svb_seg_encode_scan_kernel(ReadBatch b, ui
 // ------------------------------------------------------------------------------------------------
 // decode
 // ------------------------------------------------------------------------------------------------
+// ---- pairs of whole int16 zig-zag tiles, decoded two loads ahead (round 6) --------------------------------------------------------------
+// The tile loop of svb_decode_range asks memory twice per tile, one request behind the other: the control bytes, then -- where the
+// scan of their lengths says the tile's data bytes start -- the data bytes; with eight workgroups per CU that chain of round trips, not
+// the 21.4 GB the launch moves, is what its 4.7 ms per 65 536 reads were (the fewer instructions and barriers of rounds 2 - 5 all
+// measured +- 0).  Whole tiles of int16 values with one- and two-byte codes -- everything but the ends of a read this library or the
+// reference wrote -- go through this loop, two tiles per trip, as a pipeline: a trip PLANS the pair after the one it decodes (scan of
+// the lengths the control bytes announce: where its data bytes stand), REQUESTS that pair's data bytes into registers and the control
+// bytes of the pair after it, then decodes the pair whose bytes the trip before left in LDS, and last moves the requested bytes into
+// the other stage buffer.  Every request has a whole trip to arrive, and a trip has two barriers (ten before, for two tiles).  The
+// lengths of both tiles ride in the halves of one register through one scan; the delta sums need a scan each (16-bit wrap-around).
+// A pair that is not of that kind (3- or 4-byte codes, a stream shorter than announced, more bytes than a stage buffer holds) ends
+// the loop before anything of it is touched, and the tile loop -- which decides every verdict -- goes on from there.
+struct I16DecPairs
+{
+    static constexpr uint32_t TILE = WG * 8, BUF = 2 * WG * 8 * 3 / 2 + 48;   // a stage buffer: two tiles at 3/2 bytes per value + alignment slack
+    static constexpr uint32_t WS_LEN = 0, WS_DELTA = 8, WS_FLAG = 24, WS_WORDS = 28;   // LDS words: 2 x 4 length sums, 2 x 8 delta sums, the flag
+    const uint8_t* in;        // control bytes
+    const uint8_t* data;
+    uint32_t dataBytes;
+    uint8_t* out;             // 16-byte aligned
+    uint8_t* stage;           // two buffers of BUF bytes
+    uint32_t* ws;             // WS_WORDS words, 16-byte aligned
+
+    static __device__ __forceinline__ uint32_t announced(uint32_t k) { return 8u + (uint32_t)__popc(k & 0x5555u) + 2u * (uint32_t)__popc(k & 0xAAAAu); }
+
+    // a lane's eight values (codes 0 / 1) from the bytes at buf[o ...]: inclusive sums of the un-zig-zagged deltas (mod 2^32; the caller keeps 16 bits)
+    static __device__ __forceinline__ uint32_t decode8(const uint8_t* buf, uint32_t o, uint32_t keybits, uint32_t s[8])
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t two = (keybits >> (2 * k)) & 1u;
+            const uint32_t lo = buf[o], hi = buf[o + 1];
+            uint32_t v = lo | (two ? hi << 8 : 0u);
+            o += 1u + two;
+            v = (v >> 1) ^ (0u - (v & 1u));   // sse3.h:516-523
+            acc += v;
+            s[k] = acc;
+        }
+        return acc;
+    }
+
+    // pairs from t0 on while two whole tiles are left; pos / run as in svb_decode_range.  Returns the first value not decoded (a multiple of
+    // the tile size from t0).  All 256 threads; ends with a barrier.
+    __device__ __forceinline__ uint32_t run(uint32_t t0_in, uint32_t end_in, uint64_t& pos_io, uint32_t& run_io)
+    {
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const uint32_t m0 = wv > 0 ? 0xFFFFFFFFu : 0u, m1 = wv > 1 ? 0xFFFFFFFFu : 0u, m2 = wv > 2 ? 0xFFFFFFFFu : 0u;
+        const uint32_t end = (uint32_t)__builtin_amdgcn_readfirstlane((int)end_in);
+        uint32_t tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0_in);   // the pair the next trip plans
+        uint64_t posn = I16Pairs<false, false>::uniform64(pos_io);              // ... and where its data bytes start
+        uint32_t rn = (uint32_t)__builtin_amdgcn_readfirstlane((int)run_io);
+        auto load_keys = [&](uint32_t t, uint32_t& ka, uint32_t& kb) {
+            const uint8_t* kp = in + ((t + (uint32_t)tid * 8u) >> 2);
+            uint16_t a, b;
+            __builtin_memcpy(&a, kp, 2);
+            __builtin_memcpy(&b, kp + TILE / 4, 2);
+            ka = a;
+            kb = b;
+        };
+        bool more = end - tn >= 2u * TILE, have = false;
+        uint32_t kna = 0, knb = 0;
+        if (more) load_keys(tn, kna, knb);
+        if (tid == 0) ws[WS_FLAG] = 0;
+        uint32_t cur = 0, par = 0;
+        uint32_t kca = 0, kcb = 0, exC = 0, totC = 0, misC = 0, tc = 0;   // the pair in the stage
+        while (more || have) {
+            uint32_t Ln = 0, incn = 0;
+            if (more) {
+                Ln = announced(kna) | (announced(knb) << 16);
+                incn = wave_incl_scan_u32(Ln);
+                if (lane == 63) ws[WS_LEN + par * 4 + wv] = incn;
+                if (__any(((kna | knb) & 0xAAAAu) != 0) && lane == 0) ws[WS_FLAG] = 1;   // codes of 3 or 4 bytes: not for this loop
+            }
+            wg_lds_barrier();
+            uint32_t exN = 0, totN = 0, misN = 0, kn2a = 0, kn2b = 0;
+            uint4 d0 = make_uint4(0u, 0u, 0u, 0u), d1 = d0;
+            bool more2 = false;
+            if (more) {
+                const uint4 s4 = *reinterpret_cast<const uint4*>(ws + WS_LEN + par * 4);
+                totN = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s4.x + s4.y + s4.z + s4.w));
+                exN = (s4.x & m0) + (s4.y & m1) + (s4.z & m2) + incn - Ln;
+                const uint32_t bad = (uint32_t)__builtin_amdgcn_readfirstlane((int)ws[WS_FLAG]);
+                const uint32_t bytes = (totN & 0xFFFFu) + (totN >> 16);
+                misN = (uint32_t)((uintptr_t)(data + posn) & 15u);
+                if (bad || posn + bytes > dataBytes || misN + bytes + 16u > BUF) {
+                    more = false;   // (workgroup-uniform) the tile loop takes it from here
+                } else {
+                    const uint8_t* ga = data + posn - misN;
+                    const uint32_t nch = (misN + bytes + 15u) >> 4;
+                    if ((uint32_t)tid < nch) d0 = *reinterpret_cast<const uint4*>(ga + 16u * (uint32_t)tid);
+                    if ((uint32_t)tid + WG < nch) d1 = *reinterpret_cast<const uint4*>(ga + 16u * ((uint32_t)tid + WG));
+                    more2 = end - tn >= 4u * TILE;
+                    if (more2) load_keys(tn + 2u * TILE, kn2a, kn2b);
+                }
+            }
+            uint32_t sA[8], sB[8], accA = 0, accB = 0, incA = 0, incB = 0;
+            if (have) {
+                const uint8_t* buf = stage + cur * BUF;
+                accA = decode8(buf, misC + (exC & 0xFFFFu), kca, sA);
+                accB = decode8(buf, misC + (totC & 0xFFFFu) + (exC >> 16), kcb, sB);
+                incA = wave_incl_scan_u32(accA);
+                incB = wave_incl_scan_u32(accB);
+                if (lane == 63) {
+                    ws[WS_DELTA + par * 8 + wv] = incA;
+                    ws[WS_DELTA + par * 8 + 4 + wv] = incB;
+                }
+            }
+            wg_lds_barrier();
+            if (have) {
+                const uint4 a4 = *reinterpret_cast<const uint4*>(ws + WS_DELTA + par * 8), b4 = *reinterpret_cast<const uint4*>(ws + WS_DELTA + par * 8 + 4);
+                const uint32_t totA = a4.x + a4.y + a4.z + a4.w, totB = b4.x + b4.y + b4.z + b4.w;
+                const uint32_t baseA = rn + (a4.x & m0) + (a4.y & m1) + (a4.z & m2) + incA - accA;
+                const uint32_t baseB = rn + totA + (b4.x & m0) + (b4.y & m1) + (b4.z & m2) + incB - accB;
+                uint32_t w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = ((baseA + sA[2 * k]) & 0xFFFFu) | ((baseA + sA[2 * k + 1]) << 16);
+                uint8_t* op = out + ((size_t)tc + (size_t)tid * 8) * 2;
+                *reinterpret_cast<uint4*>(op) = make_uint4(w[0], w[1], w[2], w[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = ((baseB + sB[2 * k]) & 0xFFFFu) | ((baseB + sB[2 * k + 1]) << 16);
+                *reinterpret_cast<uint4*>(op + TILE * 2) = make_uint4(w[0], w[1], w[2], w[3]);
+                rn = (uint32_t)__builtin_amdgcn_readfirstlane((int)(rn + totA + totB));
+            }
+            have = more;
+            if (more) {   // the requested bytes into the other buffer: the next trip decodes them
+                cur ^= 1u;
+                uint8_t* nb = stage + cur * BUF;
+                const uint32_t bytes = (totN & 0xFFFFu) + (totN >> 16), nch = (misN + bytes + 15u) >> 4;
+                if ((uint32_t)tid < nch) *reinterpret_cast<uint4*>(nb + 16u * (uint32_t)tid) = d0;
+                if ((uint32_t)tid + WG < nch) *reinterpret_cast<uint4*>(nb + 16u * ((uint32_t)tid + WG)) = d1;
+                kca = kna;
+                kcb = knb;
+                exC = exN;
+                totC = totN;
+                misC = misN;
+                tc = tn;
+                posn += bytes;
+                tn += 2u * TILE;
+                kna = kn2a;
+                knb = kn2b;
+                more = more2;
+            }
+            par ^= 1u;
+        }
+        wg_lds_barrier();
+        pos_io = posn;
+        run_io = rn;
+        return tn;
+    }
+};
+
+
 // (per-read validation of the decoders: svb_decode_check in svb_wave.h, shared with the wave decoder)
 // MODE 0: decode values [first, end) of a stream of `count` values whose data bytes start at data[pos] and whose delta
 //         chain stands at `run`; store them.  MODE 1: only add up the data bytes the control bytes announce.
@@ -829,7 +983,12 @@ __device__ __forceinline__ bool svb_decode_range(const uint8_t* in, const uint8_
     uint64_t pos = pos_io;   // data bytes consumed so far
     uint32_t run = run_io;   // running value of the delta chain
     bool good = true;
-    for (uint32_t t0 = first; t0 < end; t0 += TILE) {
+    uint32_t t_start = first;
+    if (I16ZZ && MODE == 0 && out_aligned && end - first >= 2u * (uint32_t)TILE) {   // pairs of whole tiles: I16DecPairs
+        I16DecPairs dp = { in, data, dataBytes, out, stage, wsum };
+        t_start = dp.run(first, end, pos, run);
+    }
+    for (uint32_t t0 = t_start; t0 < end; t0 += TILE) {
         const uint32_t i0 = t0 + (uint32_t)tid * VPL;
         const int valid = i0 >= end ? 0 : (end - i0 >= (uint32_t)VPL ? VPL : (int)(end - i0));
         uint32_t keybits = 0;
@@ -948,9 +1107,10 @@ __device__ __forceinline__ bool svb_decode_range(const uint8_t* in, const uint8_
 template <int ELEM, bool ZZ, bool I16ZZ>
 __global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
 {
-    constexpr int STAGE = WG * Vpl<ELEM>::value * 4 + 48;
+    constexpr int STAGE = I16ZZ ? 2 * (int)I16DecPairs::BUF : WG * Vpl<ELEM>::value * 4 + 48;   // (int16 zig-zag: the two buffers of I16DecPairs; the tile loop's 8240 bytes fit)
+    static_assert(STAGE >= WG * Vpl<ELEM>::value * 4 + 48, "the tile loop's stage");
     __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
-    __shared__ uint32_t wsum[4];
+    __shared__ __attribute__((aligned(16))) uint32_t wsum[I16ZZ ? (int)I16DecPairs::WS_WORDS : 4];
 
     const uint32_t r = blockIdx.x;
     const int tid = threadIdx.x;
@@ -992,9 +1152,9 @@ __global__ __launch_bounds__(WG) void svb_seg_decode_kernel(ReadBatch b, const u
 {
     const uint32_t* seg_run = seg_run_io;
     constexpr int SEG = WG * Vpl<ELEM>::value * SEG_TILES;
-    constexpr int STAGE = MODE == 1 ? 16 : WG * Vpl<ELEM>::value * 4 + 48;
+    constexpr int STAGE = MODE == 1 ? 16 : ((I16ZZ && MODE == 0) ? 2 * (int)I16DecPairs::BUF : WG * Vpl<ELEM>::value * 4 + 48);
     __shared__ __attribute__((aligned(16))) uint8_t stage[STAGE];
-    __shared__ uint32_t wsum[4];
+    __shared__ __attribute__((aligned(16))) uint32_t wsum[(I16ZZ && MODE == 0) ? (int)I16DecPairs::WS_WORDS : 4];
     __shared__ uint64_t sums_s[8];
     uint32_t r, k;
     if (!seg_locate(seg_first, b.n_reads, blockIdx.x, r, k)) return;
