@@ -461,7 +461,7 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
             const uint32_t high = size - 1 - nlow;
             const uint32_t pos_cnt = cnt > 0 ? (uint32_t)cnt : 0u;
             const uint32_t cum_incl = wave_incl_scan_u32(pos_cnt);           // occurrences of symbols 0 .. lane
-            if ((uint32_t)__shfl((int)cum_incl, 63, 64) + nlow != size) return -1;
+            if ((uint32_t)__builtin_amdgcn_readlane((int)cum_incl, 63) + nlow != size) return -1;
             // (1) low-probability symbols: symbol s with count -1 sits in cell size-1 - (its rank among them)
             uint32_t sym_of_cell = 0xFFFFFFFFu;
             {
@@ -587,8 +587,8 @@ __device__ __noinline__ int huf_read_tree(const uint8_t* g, uint32_t n_, int lan
         ones += wt == 1 ? 1u : 0u;
     }
     if (__any(badw)) return -1;
-    const uint32_t total = (uint32_t)__shfl((int)wave_incl_scan_u32(part), 63, 64);
-    uint32_t r1 = (uint32_t)__shfl((int)wave_incl_scan_u32(ones), 63, 64);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(part), 63);
+    uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(ones), 63);
     if (total == 0) return -1;
     const uint32_t tlog = (uint32_t)hbit(total) + 1;
     if (tlog > 12) return -1;
@@ -1915,13 +1915,13 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if (go && modes == 0x10u && dtabs != nullptr) go = 2u | (used0 << 2) | (ns0 << 4);
                     }
                 }
-                go = (uint32_t)__shfl((int)go, 0, 64);
+                go = (uint32_t)__builtin_amdgcn_readlane((int)go, 0);
                 defer = go != 0;
                 fast_tabs = (go & 2u) != 0;
                 ns_fast = go >> 4;
                 used_fast = (go >> 2) & 3u;
-                ws_lit = (uint32_t)__shfl((int)ws_lit, 0, 64);
-                ws_pairs = (uint32_t)__shfl((int)ws_pairs, 0, 64);
+                ws_lit = (uint32_t)__builtin_amdgcn_readlane((int)ws_lit, 0);
+                ws_pairs = (uint32_t)__builtin_amdgcn_readlane((int)ws_pairs, 0);
             }
             // Other blocks with sequences (libzstd's frames): if the slot has room behind the frame for the literals and
             // one 16-byte record per sequence, the sequences are decoded first and executed in parallel (see below);
@@ -2054,12 +2054,12 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     // compact per-lane tables; eligibility: accuracy logs <= 6, OF = RLE of code 0, valid codes
                     uint32_t bad = 0;
                     if (lane == 0) bad = (log_ll > 6 || log_ml > 6 || log_of != 0 || (L.u.p.fse[1][0] & 0xFF) != 0) ? 1u : 0u;
-                    if (__shfl((int)bad, 0, 64)) {
+                    if (__builtin_amdgcn_readlane((int)bad, 0)) {
                         restart = true;
                         break;
                     }
-                    lgl = (uint32_t)__shfl(log_ll, 0, 64);
-                    lgm = (uint32_t)__shfl(log_ml, 0, 64);
+                    lgl = (uint32_t)__builtin_amdgcn_readlane(log_ll, 0);
+                    lgm = (uint32_t)__builtin_amdgcn_readlane(log_ml, 0);
                     uint32_t e1 = 0, e2 = 0;
                     if (lane < (1 << lgl)) {
                         const uint32_t e = L.u.p.fse[0][lane], c = e & 0xFF;
@@ -2188,7 +2188,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if (br.over) err = 1;
                     }
                 }
-                if (__shfl((int)err, 0, 64)) FAIL();
+                if (__builtin_amdgcn_readlane((int)err, 0)) FAIL();
                 uint32_t lpos = 0;
                 const uint32_t block_start = opos;
                 if (par) {
@@ -2203,11 +2203,11 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         uint4* seqbuf = reinterpret_cast<uint4*>(dst + ws_seq);
                         uint32_t reps[3] = { rep0, rep1, rep2 };
 #ifdef VBZ_SEQ_CHAIN_SCALAR
-                        const bool good = general_sequence_records(bs, bsn, seqbuf, nseq, (uint32_t)__shfl(log_ll, 0, 64), (uint32_t)__shfl(log_of, 0, 64),
-                                                                   (uint32_t)__shfl(log_ml, 0, 64), regen, opos, fcs, reps, lane);
+                        const bool good = general_sequence_records(bs, bsn, seqbuf, nseq, (uint32_t)__builtin_amdgcn_readlane(log_ll, 0), (uint32_t)__builtin_amdgcn_readlane(log_of, 0),
+                                                                   (uint32_t)__builtin_amdgcn_readlane(log_ml, 0), regen, opos, fcs, reps, lane);
 #else
-                        const bool good = general_sequence_records_lanes(bs, bsn, seqbuf, nseq, (uint32_t)__shfl(log_ll, 0, 64), (uint32_t)__shfl(log_of, 0, 64),
-                                                                         (uint32_t)__shfl(log_ml, 0, 64), regen, opos, fcs, reps, lane);
+                        const bool good = general_sequence_records_lanes(bs, bsn, seqbuf, nseq, (uint32_t)__builtin_amdgcn_readlane(log_ll, 0), (uint32_t)__builtin_amdgcn_readlane(log_of, 0),
+                                                                         (uint32_t)__builtin_amdgcn_readlane(log_ml, 0), regen, opos, fcs, reps, lane);
 #endif
                         if (!good) FAIL();
                         rep0 = reps[0];
@@ -2238,8 +2238,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                                 const uint32_t bf = (uint32_t)__shfl((int)lp, bl, 64);
                                 wave_copy((gu8*)dst + bo, (gcu8*)litp + bf, (uint32_t)__shfl((int)ll, bl, 64), lane);
                             }
-                            lposw += (uint32_t)__shfl((int)il, 63, 64);
-                            oposw += (uint32_t)__shfl((int)it, 63, 64);
+                            lposw += (uint32_t)__builtin_amdgcn_readlane((int)il, 63);
+                            oposw += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
                         }
                         // literals behind the last sequence
                         const uint32_t rest = regen - lposw;
@@ -2301,7 +2301,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                                 todo &= ~__ballot(mine);
                                 __syncthreads();  // these bytes are sources of later matches
                             }
-                            ow += (uint32_t)__shfl((int)it, 63, 64);
+                            ow += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
                         }
                         opos = ow + rest;
                     }
@@ -2343,10 +2343,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                             if (br.over) err = 1;
                         }
                     }
-                    llen = (uint32_t)__shfl((int)llen, 0, 64);
-                    mlen = (uint32_t)__shfl((int)mlen, 0, 64);
-                    offset = (uint32_t)__shfl((int)offset, 0, 64);
-                    if (__shfl((int)err, 0, 64)) FAIL();
+                    llen = (uint32_t)__builtin_amdgcn_readlane((int)llen, 0);
+                    mlen = (uint32_t)__builtin_amdgcn_readlane((int)mlen, 0);
+                    offset = (uint32_t)__builtin_amdgcn_readlane((int)offset, 0);
+                    if (__builtin_amdgcn_readlane((int)err, 0)) FAIL();
                     if (lpos + llen > regen) FAIL();
                     if ((uint64_t)opos + llen + mlen > fcs) FAIL();
                     if (ltype == 1) {
@@ -2372,7 +2372,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     if (opos - block_start > BLOCK_MAX) FAIL();
                 }
                 if (lane == 0 && !br.finished()) err = 1;
-                if (__shfl((int)err, 0, 64)) FAIL();
+                if (__builtin_amdgcn_readlane((int)err, 0)) FAIL();
                 // remaining literals
                 const uint32_t rest = regen - lpos;
                 if ((uint64_t)opos + rest > fcs) FAIL();

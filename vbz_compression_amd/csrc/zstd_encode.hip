@@ -717,7 +717,7 @@ __device__ __forceinline__ int huf_write_tree_wave(LDS& L, uint32_t maxSym, uint
                 atomicOr(&W.bitbuf[off >> 5], acc << sh);
                 if (sh + tb > 32u) atomicOr(&W.bitbuf[(off >> 5) + 1u], acc >> (32u - sh));
             }
-            const uint32_t nbytes = ((uint32_t)__shfl((int)incl, 63, 64) + 7u) >> 3;
+            const uint32_t nbytes = ((uint32_t)__builtin_amdgcn_readlane((int)incl, 63) + 7u) >> 3;
             wave_lds_sync();
             const uint32_t hSize = (uint32_t)hsz + nbytes;
             if (hSize >= 133u || !(hSize > 1u && hSize < maxSym / 2u)) fast = false;
@@ -914,7 +914,7 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
         const uint32_t c = (uint32_t)__popc(kept16);
         const uint32_t incl = wave_incl_scan_u32(c);
         const uint32_t excl = incl - c;
-        const uint32_t tot = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         // with RMIN <= 8 two qualifying runs can end inside one lane's 16 positions (never three)
         const uint32_t second = end16 & (end16 - 1);
         const uint64_t endmask1 = __ballot(end16 != 0), endmask2 = __ballot(second != 0);
@@ -937,9 +937,9 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
         SUB(2);   // (the records and the literals' stores)
         rec_total += (uint32_t)__popcll(endmask1) + (uint32_t)__popcll(endmask2);
         lit_total += tot;
-        carry60 = (uint32_t)__shfl((int)zm, 60, 64);
-        carry61 = (uint32_t)__shfl((int)zm, 61, 64);
-        carryw = (uint32_t)__shfl((int)w[3], 61, 64);
+        carry60 = (uint32_t)__builtin_amdgcn_readlane((int)zm, 60);
+        carry61 = (uint32_t)__builtin_amdgcn_readlane((int)zm, 61);
+        carryw = (uint32_t)__builtin_amdgcn_readlane((int)w[3], 61);
     }
     Lit = lit_total;
     nrec = rec_total;
@@ -1032,7 +1032,7 @@ __device__ uint32_t control_period_values(const uint8_t* keys, uint32_t K, uint3
         t = (t & 0x0F0F0F0Fu) + ((t >> 4) & 0x0F0F0F0Fu);
         const uint32_t len = at + 4u <= K ? ((t * 0x01010101u) >> 24) + 16u : 0u;
         const uint32_t incl = wave_incl_scan_u32(len);
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         if (done + total >= D) {
             // the lane whose sixteen values contain the D-th byte's end
             const uint32_t before = done + incl - len;
@@ -1134,7 +1134,7 @@ __device__ __forceinline__ uint32_t encode_zero_run_sequences(LDS& L, uint8_t* d
         *op++ = (uint8_t)of_code;
         hdr = (uint32_t)(op - dst);
     }
-    hdr = (uint32_t)__shfl((int)hdr, 0, 64);
+    hdr = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 0);
     uint8_t* out = dst + hdr;
     // LDS scratch inside the (idle) workspace of the stream packer
     uint32_t* bits = L.obuf;                 // 128 words: 64 sequences x (44 + 17) bits + carry
@@ -1266,7 +1266,7 @@ __device__ __forceinline__ uint32_t encode_zero_run_sequences(LDS& L, uint8_t* d
                 len += of_code;
             }
             const uint32_t incl = wave_incl_scan_u32(len);
-            const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t pos = base_bits + incl - len;
             if (i < rn) {
                 const uint32_t n = nseq - 1 - t;  // checkpoint: everything up to and including this sequence's bits is unread
@@ -1309,7 +1309,7 @@ __device__ __forceinline__ uint32_t encode_zero_run_sequences(LDS& L, uint8_t* d
         for (uint32_t i = 0; i < nbytes; ++i) out[flushed + i] = (uint8_t)(acc >> (8 * i));
         bits[0] = 0;
     }
-    nbytes = (uint32_t)__shfl((int)nbytes, 0, 64);
+    nbytes = (uint32_t)__builtin_amdgcn_readlane((int)nbytes, 0);
     wave_lds_sync();
     return hdr + flushed + nbytes;
 }
@@ -1949,7 +1949,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
 #pragma unroll
                     for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k].y;
                     const uint32_t incl = wave_incl_scan_u32(Tb);
-                    const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
                     const uint32_t fq = allbits >> 7;             // complete 16-byte quads
                     if ((uint64_t)spos + flushed + 16ull * fq + 24 > cap) OVERRUN();
@@ -2331,9 +2331,13 @@ __device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint
     }
     for (int i = lane; i < 2 * OBUF_WORDS; i += WAVE) (&L.obuf[0][0])[i] = 0;
     wave_lds_sync();
-    const uint32_t nb = nblk;
+    // (the stream table is the same for every lane: its entries are read into scalar registers, so that the loop's bookkeeping --
+    // stream, step, positions, the limit checks -- runs on the scalar unit beside the lanes' symbol work)
+    auto s_cnt = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)L.scnt[i]); };
+    auto s_beg = [&](uint32_t i) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)L.sbeg[i]); };
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_readfirstlane((int)nblk);
     uint32_t st = 0;
-    while (st < 4 * nb && L.scnt[st] == 0) ++st;
+    while (st < 4 * nb && s_cnt(st) == 0) ++st;
     uint32_t done = 0;
 #if VBZ_PACK_PREFETCH
     uint32_t cur[STEP_DW], nxt[STEP_DW];
@@ -2392,7 +2396,7 @@ __device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint
     uint32_t ocur = opos;        // where the current block starts
     uint32_t spos = 0;           // where the current stream starts
     uint32_t curblk = 0xFFFFFFFFu;
-    if (st < 4 * nb) load_chunk(L.sbeg[st], L.scnt[st], 0, cur);
+    if (st < 4 * nb) load_chunk(s_beg(st), s_cnt(st), 0, cur);
     PPHASE(1);
     uint32_t base_bits = 0;   // bits already in obuf (the partial word carried over)
     uint32_t flushed = 0;     // bytes of the stream already written to memory (or waiting in the other buffer for it)
@@ -2417,17 +2421,17 @@ __device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint
             for (uint32_t i = lane; i < tsz; i += WAVE) out[ocur + 3u + blk_lh(curblk) + i] = reinterpret_cast<const uint8_t*>(L.tree)[i];
             spos = ocur + hl;
         }
-        const uint32_t scnt = L.scnt[st];
+        const uint32_t scnt = s_cnt(st);
         uint8_t* sop = out + spos;
         uint32_t nst = st, ndone = done + STEP_SYMS;
         if (ndone >= scnt) {
             ndone = 0;
             ++nst;
-            while (nst < 4 * nb && L.scnt[nst] == 0) ++nst;
+            while (nst < 4 * nb && s_cnt(nst) == 0) ++nst;
         }
         flush_pending();   // (the step before: its quads, in front of the request below)
 #if VBZ_PACK_PREFETCH
-        if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, nxt);
+        if (nst < 4 * nb) load_chunk(s_beg(nst), s_cnt(nst), ndone, nxt);
 #endif
         const int32_t room = (int32_t)(scnt - done) - STEP_LANE * lane;
         const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
@@ -2438,11 +2442,12 @@ __device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint
 #pragma unroll
             for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
         }
-        uint32_t Tb = 0;  // bits of this lane's codes
+        uint32_t Tb = 0;  // bits of this lane's codes: the entries are code | length << 16 and sixteen codes of at most 11 bits add up to less than 2^16
 #pragma unroll
-        for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k] >> 16;
+        for (int k = 0; k < STEP_LANE; ++k) Tb += ent[k];
+        Tb >>= 16;
         const uint32_t incl = wave_incl_scan_u32(Tb);
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t allbits = base_bits + total;   // base_bits: bits carried over in quad 0 of the buffer (< 128)
         const uint32_t fq = allbits >> 7;             // complete 16-byte quads
         if ((uint64_t)spos + flushed + 16ull * fq + 24 > limit) REDO();
@@ -2519,7 +2524,7 @@ __device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint
 #pragma unroll
         for (int k = 0; k < STEP_DW; ++k) cur[k] = nxt[k];
 #else
-        if (nst < 4 * nb) load_chunk(L.sbeg[nst], L.scnt[nst], ndone, cur);
+        if (nst < 4 * nb) load_chunk(s_beg(nst), s_cnt(nst), ndone, cur);
 #endif
         st = nst;
         done = ndone;

@@ -50,7 +50,7 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
             pnext = i1 < nseq ? pairs[i1] : make_uint2(0u, 0u);
         }
         const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(ll + ml);
-        const uint32_t tl = (uint32_t)__shfl((int)il, 63, 64), tt = (uint32_t)__shfl((int)it, 63, 64);
+        const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)il, 63), tt = (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
         if ((uint64_t)lposw + tl > regen || (uint64_t)oposw + tt > fcs) return 0xFFFFFFFFu;
         // Common case (zero runs, a chunk's literals and output fit the LDS area): build the chunk's output in LDS --
         // zero fill, every lane drops its literals in place, runs of a non-zero byte are written out -- and copy it
@@ -95,7 +95,7 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (j + k < tl) lds_out[j + k + before + sh[k]] = (uint8_t)((k < 4 ? lb.x : lb.y) >> (8 * (k & 3)));
-                carry += (uint32_t)__shfl((int)inc, 63, 64);
+                carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             }
             wave_lds_sync();
             if (ll != 0) {  // a run of a non-zero byte (never what zstd_encode.hip writes)
@@ -316,7 +316,7 @@ __device__ __noinline__ uint32_t zero_run_chain_segments(const uint8_t* bs, uint
         sm = w >> 26;
         if (P > 8 * bsn) bad = 1;
     }
-    if (__any(bad)) return (uint32_t)__shfl((int)bad, 0, 64) ? 0u : 3u;  // a bad end mark is the frame's fault
+    if (__any(bad)) return (uint32_t)__builtin_amdgcn_readlane((int)bad, 0) ? 0u : 3u;  // a bad end mark is the frame's fault
     const uint32_t P0 = P, sl0 = sl, sm0 = sm;
     const uint32_t first = (uint32_t)lane * spacing;
     uint32_t sum_ll = 0, sum_all = 0;
@@ -361,8 +361,8 @@ __device__ __noinline__ uint32_t zero_run_chain_segments(const uint8_t* bs, uint
     }
     if (__any(bad)) return 3u;  // the serial walk decides whether the frame or only the trailer is wrong
     if (__any(impure)) return 2u;
-    const uint32_t tll = (uint32_t)__shfl((int)wave_incl_scan_u32(active ? sum_ll : 0u), 63, 64);
-    const uint32_t tall = (uint32_t)__shfl((int)wave_incl_scan_u32(active ? sum_all : 0u), 63, 64);
+    const uint32_t tll = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(active ? sum_ll : 0u), 63);
+    const uint32_t tall = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(active ? sum_all : 0u), 63);
     if (tll > regen) return 0u;
     if ((uint64_t)tall + (regen - tll) > BLOCK_MAX) return 0u;
     *total_out = tall + (regen - tll);
