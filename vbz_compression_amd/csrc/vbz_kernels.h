@@ -287,6 +287,12 @@ __device__ __forceinline__ uint32_t wave_prev_lane_u32(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, false);
 }
 
+// The value of the lane above (lane 63 gets 0): wave_shl:1.
+__device__ __forceinline__ uint32_t wave_next_lane_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);
+}
+
 // Inclusive prefix sum over the 64 lanes of a wave with DPP row shifts and row broadcasts (gfx9: no LDS crossbar
 // traffic, six additions): after the four row_shr steps every 16-lane row holds its own scan, row_bcast:15 adds the
 // last lane of rows 0 and 2 into rows 1 and 3, row_bcast:31 adds lane 31 into the upper half.

@@ -212,21 +212,24 @@ __device__ __forceinline__ void put_le(uint8_t* p, uint64_t v, int n)
     }
 }
 
+// Reductions over the wavefront (all 64 lanes active): DPP row shifts and broadcasts bring the result to lane 63, v_readlane hands it to
+// everybody in a scalar register -- six butterfly shuffles through the LDS crossbar were six round trips on a dependent chain.
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
-    return v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+#define VBZ_DPP_MAX(ctrl, rowmask) do { const uint32_t o_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rowmask, 0xF, false); v = o_ > v ? o_ : v; } while (0)
+    VBZ_DPP_MAX(0x111, 0xF);  // row_shr:1 (a lane without a source reads 0: the identity of an unsigned maximum)
+    VBZ_DPP_MAX(0x112, 0xF);
+    VBZ_DPP_MAX(0x114, 0xF);
+    VBZ_DPP_MAX(0x118, 0xF);
+    VBZ_DPP_MAX(0x142, 0xA);  // row_bcast:15
+    VBZ_DPP_MAX(0x143, 0xC);  // row_bcast:31
+#undef VBZ_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 // histogram of in[0..n) into L.hist using all 64 lanes.  LDS atomics on a shared bin serialise, so four lane
@@ -790,9 +793,8 @@ __device__ __forceinline__ void region_plan(LDS& L, uint32_t S, uint32_t Sh, uin
         }
         mybits += (uint64_t)L.hist[s] * nb;
     }
-    uint64_t bits = mybits;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) bits += __shfl_xor(bits, d, 64);
+    // (a lane's share in two limbs of 20 bits, each summed over the wavefront in 32 bits)
+    const uint64_t bits = ((uint64_t)wave_sum_u32((uint32_t)(mybits >> 20)) << 20) + wave_sum_u32((uint32_t)mybits & 0xFFFFFu);
     wave_lds_sync();
     SUB(10);
     const int ts = huf_write_tree_wave(L, maxSym, huffLog, lane);
@@ -876,13 +878,15 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
             zm = (lane >= 2 && lo < (int64_t)K) ? (uint32_t)mask16[(uint32_t)lo >> 4] & valid : 0u;
         } else {
             // bit i of the mask: byte i equals the byte in front of it (a run of r equal bytes is r - 1 ones)
-            uint32_t pw = (uint32_t)__shfl_up((int)w[3], 1, 64);
+            uint32_t pw = wave_prev_lane_u32(w[3]);   // (DPP: a shuffle through the LDS crossbar is a round trip on this loop's dependent chain)
             if (lane == 2) pw = carryw;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t x = w[q] ^ __builtin_amdgcn_alignbyte(w[q], q ? w[q - 1] : pw, 3);  // zero byte <=> equal neighbours
-#pragma unroll
-                for (int i = 0; i < 4; ++i) zm |= (((x >> (8 * i)) & 0xFF) == 0 ? 1u : 0u) << (4 * q + i);
+                // "this byte is zero" for the four bytes at once (bit 7 of each), then the four bits side by side: the multiplication
+                // moves bit 8 j to bit 21 + j (no two terms of the product meet)
+                const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+                zm |= ((((z >> 7) * 0x00204081u) >> 21) & 0xFu) << (4 * q);
             }
             zm &= valid;
             if (lane == 2 && pb == 0) zm &= ~1u;  // nothing in front of the first byte
@@ -895,12 +899,9 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
             zm = lb >= 0 ? (uint32_t)mask16[(uint32_t)lb >> 4] : 0u;
         }
         SUB(3);   // (timed build: the trip's load and the equal-neighbour mask)
-        uint32_t m1 = (uint32_t)__shfl_up((int)zm, 1, 64), m2 = (uint32_t)__shfl_up((int)zm, 2, 64);
-        uint32_t p1 = (uint32_t)__shfl_down((int)zm, 1, 64), p2 = (uint32_t)__shfl_down((int)zm, 2, 64);
-        if (lane < 1) m1 = 0;
-        if (lane < 2) m2 = 0;
-        if (lane > 62) p1 = 0;
-        if (lane > 61) p2 = 0;
+        // the masks of the two lanes below and above (DPP wave shifts: the lanes at the ends get 0)
+        const uint32_t m1 = wave_prev_lane_u32(zm), m2 = wave_prev_lane_u32(m1);
+        const uint32_t p1 = wave_next_lane_u32(zm), p2 = wave_next_lane_u32(p1);
         // window bit j <-> position lo - 24 + j
         const uint64_t W = (uint64_t)((m2 >> 8) & 0xFF) | ((uint64_t)m1 << 8) | ((uint64_t)zm << 24) | ((uint64_t)p1 << 40) |
                            ((uint64_t)(p2 & 0xFF) << 56);
@@ -1231,8 +1232,8 @@ __device__ __forceinline__ uint32_t encode_zero_run_sequences(LDS& L, uint8_t* d
                     done = true;
                 }
                 if (__ballot(!done) == 0) break;
-                const uint32_t pM = (uint32_t)__shfl_up((int)stM, 1, 64), pL = (uint32_t)__shfl_up((int)stL, 1, 64);
-                const bool pdone = __shfl_up((int)done, 1, 64) != 0;
+                const uint32_t pM = wave_prev_lane_u32(stM), pL = wave_prev_lane_u32(stL);
+                const bool pdone = wave_prev_lane_u32(done ? 1u : 0u) != 0;   // (lane 0 reads 0: it never looks, below)
                 if (!known && pdone) {
                     stM = pM;
                     stL = pL;
