@@ -98,6 +98,17 @@ VBZ_EXPORT const char* vbz_gpu_last_error(vbz_gpu_ctx* ctx);
  * that insist on consumed == source size after ONE frame); the compression itself (run sequences included) is unchanged.
  * The single-buffer API of vbz.h follows the environment variable VBZ_HIP_TRAILERS (0 / 1, default 1). */
 VBZ_EXPORT void vbz_gpu_set_trailers(vbz_gpu_ctx* ctx, int enable);
+/* Canonical encoding.  The reference's output for a buffer is a function of (input, options, libzstd version) alone
+ * (vbz/vbz.cpp:116-208).  Every frame this library writes is standard zstd that the reference decodes, but by default WHICH kernels code
+ * a read -- hence its bytes -- follows from the shape of the call it arrives in (few large reads, a handful of reads, thousands): the
+ * same read may come out differently from the HDF5 filter, the bulk re-packer and a large batch.  enable = 1: a read's bytes depend on
+ * the read, the options, the trailer setting and the library version only -- reads of 512 KiB of raw data and more are coded as spans
+ * with a table each, all others by one wavefront, whatever else is in the call.  Destination slots must have the reference's capacity
+ * (vbz_max_compressed_size), as the reference requires anyway.  Costs one stream synchronisation per compress call (the number of large
+ * reads comes back to the host), nothing at thousands of ordinary reads per call, and the small-call latency of the default (a call
+ * with one 100 k-sample read: ~0.4 ms instead of ~0.14).  Decoding is unaffected.  The single-buffer API of vbz.h, the HDF5 plugin and
+ * the re-packer follow the environment variable VBZ_HIP_CANONICAL (0 / 1, default 0). */
+VBZ_EXPORT void vbz_gpu_set_canonical(vbz_gpu_ctx* ctx, int enable);
 /* wait for everything queued on the context's stream; returns 0 or a negative HIP error */
 VBZ_EXPORT int vbz_gpu_synchronize(vbz_gpu_ctx* ctx);
 

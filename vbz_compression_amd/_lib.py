@@ -69,6 +69,7 @@ GPU_API = [
     "vbz_gpu_stream",
     "vbz_gpu_last_error",
     "vbz_gpu_set_trailers",
+    "vbz_gpu_set_canonical",
     "vbz_gpu_synchronize",
     "vbz_gpu_compress_batch",
     "vbz_gpu_decompress_batch",
@@ -126,6 +127,9 @@ def load():
     L.vbz_gpu_last_error.argtypes = [vp]
     L.vbz_gpu_set_trailers.restype = None
     L.vbz_gpu_set_trailers.argtypes = [vp, ctypes.c_int]
+    if hasattr(L, "vbz_gpu_set_canonical"):   # (builds of earlier rounds, loaded through VBZ_HIP_LIB, do not have it)
+        L.vbz_gpu_set_canonical.restype = None
+        L.vbz_gpu_set_canonical.argtypes = [vp, ctypes.c_int]
     L.vbz_gpu_synchronize.restype = ctypes.c_int
     L.vbz_gpu_synchronize.argtypes = [vp]
     for name in ("vbz_gpu_compress_batch", "vbz_gpu_decompress_batch"):

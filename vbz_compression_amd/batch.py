@@ -48,6 +48,11 @@ class GpuCodec:
         """Decoder hints (checkpoints, span index) in skippable frames behind the zstd frame: on by default (include/vbz_gpu.h)."""
         self.L.vbz_gpu_set_trailers(self.ctx, int(bool(enable)))
 
+    def set_canonical(self, enable):
+        """A read's compressed bytes depend on the read, the options and the library version only -- not on the batch it arrives in
+        (include/vbz_gpu.h: vbz_gpu_set_canonical)."""
+        self.L.vbz_gpu_set_canonical(self.ctx, int(bool(enable)))
+
     def close(self):
         if getattr(self, "ctx", None):
             self.L.vbz_gpu_destroy(self.ctx)

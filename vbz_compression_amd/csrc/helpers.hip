@@ -229,6 +229,24 @@ __global__ __launch_bounds__(1024) void route_pick_kernel(ReadBatch b, const uin
     }
 }
 
+// ---- canonical mode (vbz_api.hip): which reads take the large-read path is decided by each read's OWN size, whatever the batch around it.
+// gate_small[i] = GATE_SKIP for reads of min_bytes raw bytes and more (the input gate, or 0, for the others); gate_large[i] the reverse
+// (a read that carries an error is reported by the first group); counts[0] = the reads of min_bytes and more.
+__global__ __launch_bounds__(256) void canon_classify_kernel(uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint32_t min_bytes, uint32_t* gate_small,
+                                                             uint32_t* gate_large, uint32_t* counts)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t g = (i < n && gate) ? gate[i] : 0u;
+    const uint32_t sz = i < n ? raw_size[i] : 0u;
+    const bool big = i < n && g < GATE_SKIP && sz >= min_bytes && sz < E_FIRST;
+    if (i < n) {
+        gate_small[i] = big ? GATE_SKIP : g;
+        gate_large[i] = big ? g : GATE_SKIP;
+    }
+    const uint64_t m = __ballot(big);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[0], (uint32_t)__popcll(m));
+}
+
 // results of the second launch group back to the reads they belong to
 __global__ void route_results_kernel(const uint32_t* l_result, const uint32_t* l_map, const uint32_t* l_count, uint32_t max_reads, uint32_t* result)
 {
@@ -417,6 +435,15 @@ hipError_t launch_route_reads(const ReadBatch& b, const uint32_t* raw_size, uint
 }
 
 size_t route_cand_words() { return ROUTE_CAND_MAX + 4; }
+
+hipError_t launch_canon_classify(uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint32_t min_bytes, uint32_t* gate_small, uint32_t* gate_large,
+                                 uint32_t* counts, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(counts, 0, 8, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(canon_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, raw_size, gate, min_bytes, gate_small, gate_large, counts);
+    return hipGetLastError();
+}
 
 hipError_t launch_route_results(const uint32_t* l_result, const uint32_t* l_map, const uint32_t* l_count, uint32_t max_reads, uint32_t* result, hipStream_t s)
 {

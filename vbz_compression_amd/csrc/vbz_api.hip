@@ -65,6 +65,10 @@ struct vbz_gpu_ctx
     int split_stagger = 0;        // VBZ_HIP_SPLIT_STAGGER=1: the upper half starts behind the lower half's first large launch (measured: 548 GB/s
                                   // against 565 when both halves start together -- the device interleaves the two queues by itself)
     bool last_split = false;      // vbz_gpu_decode_paths: the last decompress call ran as halves
+    // Canonical encoding (vbz_gpu_set_canonical / VBZ_HIP_CANONICAL=1): a read's compressed bytes are a function of the read, the options
+    // and the library version -- not of the batch it arrives in (see compress_canonical)
+    bool canonical = false;
+    uint32_t* canon_host = nullptr;   // pinned: the classification's count comes back here
     // single-buffer API staging
     DevBuf one_in, one_out, one_meta;
     DevBuf dbg;       // per-read phase timers (VBZ_HIP_PHASE_TIMING=1)
@@ -505,7 +509,8 @@ int compress_group(vbz_gpu_ctx* c, const ReadBatch& rb_in, uint64_t src_bytes, c
         // elements, whose control bytes are mostly zero and cheap to code: 0.176 -> 0.140 ms per call for a 100 k-sample read.  The
         // control-byte spans of 32-bit elements take as long as the table construction itself (a 40 MB buffer: 100 us in the first launch,
         // + 15 us counting + 34 us packing against 125 us for everything in one launch) -- they keep a table per span.
-        const uint32_t shspan = (c->shared_tables && (o->integer_size == 1 || o->integer_size == 2)) ? zstd_span_shared_bytes(scratch_need) : 0u;
+        // (canonical mode: whether the data bytes share a table must not follow from the call's size -- every span its own table)
+        const uint32_t shspan = (c->shared_tables && !c->canonical && (o->integer_size == 1 || o->integer_size == 2)) ? zstd_span_shared_bytes(scratch_need) : 0u;
         const bool shared = shspan != 0;
         if (!ensure(c, c->spanmeta, (size_t)max_spans * (zstd_span_desc_bytes() + 12) + ((size_t)n + 2) * 4 + 256 + (shared ? zstd_span_region_bytes(n) + 64 : 0))) return -1;
         MetaCarver sm(c->spanmeta.p);
@@ -746,10 +751,10 @@ bool routing_applies(const vbz_gpu_ctx* c, const CompressionOptions* o, uint64_t
     return c->routing && c->segmented < 0 && n > 1 && o->integer_size != 0 && !half_codec(o) && raw_arena_bytes >= ROUTE_MIN_BYTES;
 }
 
-int route(vbz_gpu_ctx* c, const ReadBatch& rb, const uint32_t* raw_size, Routed* r)
+// the second launch group's context (the large-read path beside the first group, on a stream of its own)
+int ensure_large(vbz_gpu_ctx* c)
 {
-    const uint32_t n = rb.n_reads;
-    if (!c->large) {   // the second group's context: its launches are small and run beside the first group's on a stream of their own
+    if (!c->large) {
         c->large = vbz_gpu_create(c->device, nullptr);
         if (!c->large || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -757,10 +762,21 @@ int route(vbz_gpu_ctx* c, const ReadBatch& rb, const uint32_t* raw_size, Routed*
             return -1;
         }
         c->large->routing = 0;
+        c->large->split_min = 0;
     }
     c->large->trailers = c->trailers;
     c->large->zero_run_sequences = c->zero_run_sequences;
+    c->large->long_repeats = c->long_repeats;
+    c->large->shared_tables = c->shared_tables;
+    c->large->canonical = c->canonical;
     c->large->segmented = 1;
+    return 0;
+}
+
+int route(vbz_gpu_ctx* c, const ReadBatch& rb, const uint32_t* raw_size, Routed* r)
+{
+    const uint32_t n = rb.n_reads;
+    if (ensure_large(c) != 0) return -1;
     if (!ensure(c, c->route, (size_t)n * 4 + (size_t)ROUTE_MAX_READS * 48 + route_cand_words() * 4 + 512)) return -1;
     MetaCarver mc(c->route.p);
     r->gate_small = mc.take<uint32_t>(n);
@@ -924,6 +940,55 @@ int decompress_split(vbz_gpu_ctx* c, const ReadBatch& rb, uint64_t dst_bytes, co
     return rc;
 }
 
+
+// ---- canonical encoding ----------------------------------------------------------------------------------------------------------------
+// The reference is a pure function of (input, options, libzstd version) per buffer (vbz/vbz.cpp:116-208).  This library's frames are
+// standard zstd whatever path wrote them, but WHICH path a read takes follows, by default, from the shape of the call it arrives in
+// (a batch of few large reads, a handful of reads, per-read routing with its limits, shared tables while the call is small): the same
+// read can come out as different -- equally valid -- bytes from the HDF5 filter, the bulk re-packer and a batch of thousands.  In
+// canonical mode the rule looks at the READ alone: a read of CANON_LARGE_BYTES raw bytes and more is coded as spans (every span its own
+// table), every other read by one wavefront -- one kernel classifies the reads by their sizes on the device, the count of large ones
+// comes back to the host (the one synchronisation of the call), and the two kinds run as two launch groups beside each other like
+// per-read routing's.  Destination slots are taken to have the reference's capacity contract (vbz_max_compressed_size): the long-repeat
+// coder's workspace is what a slot has above the worst-case frame.  Decoding needs no such mode.  tests/test_gpu_canonical.py holds
+// vbz_compress, batches of 1 and of 4096, the HDF5 filter and the bulk re-packer to one sha256 per read.
+constexpr uint32_t CANON_LARGE_BYTES = (uint32_t)SEGMENTED_MIN_AVG;
+
+int compress_canonical(vbz_gpu_ctx* c, const ReadBatch& rb, uint64_t src_bytes, const CompressionOptions* o, int sized)
+{
+    const uint32_t n = rb.n_reads;
+    hipStream_t s = c->stream;
+    if (!c->canon_host && hipHostMalloc((void**)&c->canon_host, 16, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error(c, "pinned word for the canonical classification");
+        return -1;
+    }
+    if (!ensure(c, c->route, (size_t)n * 8 + 64)) return -1;
+    MetaCarver mc(c->route.p);
+    uint32_t* counts = mc.take<uint32_t>(4);
+    uint32_t* gate_small = mc.take<uint32_t>(n);
+    uint32_t* gate_large = mc.take<uint32_t>(n);
+    HIPCHK(c, launch_canon_classify(n, rb.src_size, rb.gate, CANON_LARGE_BYTES, gate_small, gate_large, counts, s), "classify launch");
+    HIPCHK(c, hipMemcpyAsync(c->canon_host, counts, 8, hipMemcpyDeviceToHost, s), "count copy");
+    HIPCHK(c, hipStreamSynchronize(s), "stream synchronize");
+    const uint32_t nbig = c->canon_host[0];
+    const bool split = split_applies(c, o, n);
+    if (nbig == 0) return split ? compress_split(c, rb, src_bytes, o, sized) : compress_group(c, rb, src_bytes, o, sized, false);
+    if (nbig == n) return compress_group(c, rb, src_bytes, o, sized, true);
+    if (ensure_large(c) != 0) return -1;
+    HIPCHK(c, hipEventRecord(c->ev_fork, s), "event record");
+    HIPCHK(c, hipStreamWaitEvent(c->large->stream, c->ev_fork, 0), "stream wait");
+    ReadBatch small = rb, large = rb;
+    small.gate = gate_small;
+    large.gate = gate_large;
+    int rc = 0;   // (as in compress_batch_impl: the second stream is joined whatever happens)
+    if (compress_group(c->large, large, src_bytes, o, sized, true) != 0) rc = -1;
+    if (rc == 0 && (split ? compress_split(c, small, src_bytes, o, sized) : compress_group(c, small, src_bytes, o, sized, false)) != 0) rc = -1;
+    if (rc != 0 && c->error.empty() && !c->large->error.empty()) c->error = c->large->error;
+    if (hipEventRecord(c->ev_join, c->large->stream) != hipSuccess || hipStreamWaitEvent(s, c->ev_join, 0) != hipSuccess) rc = -1;
+    return rc;
+}
+
 // The caller's descriptor table is untrusted (vbz_gpu.h): one thread per read checks its slots against the declared arenas before any
 // other kernel forms an address from them; the verdicts are the gate every launch group of the call starts from.
 int validate_descriptors(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, ReadBatch* rb)
@@ -957,6 +1022,8 @@ int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compressi
     if (n == 0) return 0;
     ReadBatch rb = to_rb(bt);
     if (!own_descriptors && validate_descriptors(c, bt, &rb) != 0) return -1;
+    if (c->canonical && c->segmented < 0 && o->integer_size != 0 && o->zstd_compression_level != 0 && !half_codec(o))
+        return compress_canonical(c, rb, bt->src_bytes, o, sized);
     const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->src_bytes, n, false);
     const bool split = !by_shape && split_applies(c, o, n);
     if (by_shape || !routing_applies(c, o, bt->src_bytes, n))
@@ -1070,6 +1137,7 @@ vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)
     if (const char* e = getenv("VBZ_HIP_ROUTING")) c->routing = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SEGMENTED")) c->segmented = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_TRAILERS")) c->trailers = atoi(e) != 0;
+    if (const char* e = getenv("VBZ_HIP_CANONICAL")) c->canonical = atoi(e) != 0;
     if (const char* e = getenv("VBZ_HIP_SPLIT_MIN")) c->split_min = (uint32_t)strtoul(e, nullptr, 10);   // 0: a batch is never coded as two halves
     if (const char* e = getenv("VBZ_HIP_SPLIT_STAGGER")) c->split_stagger = atoi(e);
 #ifdef VBZ_EXPERIMENTS
@@ -1132,6 +1200,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->pinned) (void)hipHostFree(c->pinned);
+    if (c->canon_host) (void)hipHostFree(c->canon_host);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1141,6 +1210,10 @@ void* vbz_gpu_stream(vbz_gpu_ctx* c) { return c ? (void*)c->stream : nullptr; }
 void vbz_gpu_set_trailers(vbz_gpu_ctx* c, int enable)
 {
     if (c) c->trailers = enable != 0;
+}
+void vbz_gpu_set_canonical(vbz_gpu_ctx* c, int enable)
+{
+    if (c) c->canonical = enable != 0;
 }
 const char* vbz_gpu_last_error(vbz_gpu_ctx* c) { return c ? c->error.c_str() : "no context"; }
 

@@ -235,6 +235,9 @@ struct ScratchPlan
 };
 hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t max_segs, uint32_t* seg_first,
                            uint32_t* gate_out, const ScratchPlan* scratch, hipStream_t s);
+// canonical mode: see canon_classify_kernel (helpers.hip).  counts: two words of device memory.
+hipError_t launch_canon_classify(uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint32_t min_bytes, uint32_t* gate_small, uint32_t* gate_large,
+                                 uint32_t* counts, hipStream_t s);
 // per-read routing: see route_reads_kernel (helpers.hip).  raw_size[i] = the read's raw (decoded) byte count.
 hipError_t launch_route_reads(const ReadBatch& b, const uint32_t* raw_size, uint32_t min_bytes, uint32_t max_reads, uint64_t max_bytes, uint32_t* gate_small,
                               uint64_t* l_src_off, uint32_t* l_src_size, uint64_t* l_dst_off, uint32_t* l_dst_cap, uint32_t* l_gate, uint32_t* l_map,
