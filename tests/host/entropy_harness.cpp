@@ -3,6 +3,7 @@
 // what libzstd emits for the same histogram.  Built by tests/test_entropy_host.py with g++.
 #include <cstring>
 #include "zstd_entropy.h"
+#include "zstd_reference_huffman.h"   // libzstd's construction: the yardstick (BSD notice inside)
 
 using namespace vbzhip;
 

@@ -1,0 +1,22 @@
+"""The reference hands the caller's zstd level to libzstd (vbz/vbz.cpp:194-207); this library writes level-1-shaped frames at every level
+above 0.  On the reference's OWN inputs -- its perf generator (iota and the cycled template: vbz/perf/test_data_generator.h:12-74), its
+plugin test (iota at level 5, random data: vbz_plugin/test/vbz_hdf_plugin_test.cpp:15-136), its Python benchmark (randint(-50, 50):
+python/benchmark/benchmark.py:86-89) and the pyvbz unit tests -- every case must come out at 0.9 x the reference path's ratio or better at
+the level the caller asked for (a few bytes of slack for buffers of a dozen values, where a frame header is most of the output), and decode
+both ways (tools/ratio_sweep.py checks that on the way).  The full-size table is profiles/r06_ratio_sweep.md."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+
+def test_ratio_on_the_references_own_inputs():
+    import ratio_sweep
+
+    rows = ratio_sweep.run(quick=True)
+    assert len(rows) >= 40
+    bad = [r for r in rows if r["this"] > r["reference"] / 0.9 + 6 * r["buffers"]]
+    assert not bad, bad

@@ -60,7 +60,8 @@ gcc $SAN -Iinclude -o "$TMP/filter_call" "$TMP/filter_call.c" -L"$TMP" -lvbz_hdf
 "$TMP/filter_call" 2> "$TMP/filter.err" || { cat "$TMP/filter.err"; echo "filter_call failed"; exit 1; }
 grep -q "ERROR: AddressSanitizer\|runtime error" "$TMP/filter.err" && { cat "$TMP/filter.err"; exit 1; }
 set +e
-"$TMP/vbz_fast5_repack" tests/golden/multi_fast5_zip.fast5 "$TMP/out.fast5" > "$TMP/repack.out" 2> "$TMP/repack.err"
+cp tests/golden/multi_fast5_zip.fast5 "$TMP/in.fast5"   # (the tool writes its <name>.tmp beside the input: not into the fixture directory)
+"$TMP/vbz_fast5_repack" "$TMP/in.fast5" "$TMP/out.fast5" > "$TMP/repack.out" 2> "$TMP/repack.err"
 rc=$?
 set -e
 if grep -q "ERROR: AddressSanitizer\|runtime error" "$TMP/repack.err"; then cat "$TMP/repack.err"; exit 1; fi

@@ -15,10 +15,11 @@
 //   vbz_fast5_repack --list FILE [--export-signal OUT] [--export-chunks OUT]
 //   vbz_fast5_repack --samples FILE...          (one line per file: name, reads, samples -- what a work queue deals files by)
 //
-// Several files are a PIPELINE (the reference's users run many files side by side: README.md:36-40 `xargs -P 10`): while the GPU
-// codes file k, a loader thread copies, reads and inflates file k + 1 and a writer thread stores file k - 1 -- the codec is a few
-// milliseconds of a file's 100+, the rest is libhdf5 and zlib on the host.  libhdf5 is not thread-safe in its usual builds: every
-// call into it is made under one mutex, whichever thread makes it.  Several GPUs: one process per device over a share of the file
+// Several files are a PIPELINE (the reference's users run many files side by side: README.md:36-40 `xargs -P 10`): a loader thread, the
+// GPU and a writer thread work on files k + 1, k and k - 1 -- the codec is a few milliseconds of a file's 100+, the rest is libhdf5 and
+// zlib on the host.  libhdf5 is not thread-safe in its usual builds: every call into it is made under one mutex, and the loader holds
+// it for a file's whole load, the writer for its whole store -- so the two libhdf5 stages take turns; what overlaps them is the GPU's
+// work and the inflate / deflate pools (which run outside the mutex).  Several GPUs: one process per device over a share of the file
 // list (python -m vbz_compression_amd.fast5 --gpus N deals the files by their sample counts).
 //
 // libhdf5 (>= 1.10.3, for the direct chunk calls) is loaded at run time: --hdf5-lib PATH, $VBZ_HDF5_LIB, or the

@@ -353,6 +353,7 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
     uint64_t F = 0;  // bytes of the aligned space already flushed (multiple of 16)
     uint64_t P = A;  // next byte position in the aligned space; stage[] holds [F, P)
     uint32_t probe_p0 = 0;   // != 0: the probe table stands, with its probes at data bytes probe_p0 ...
+    bool probe_runs = false; // the probes could not be placed: the distance 1 ("a run") is proposed (zstd_encode.hip: RUN_D)
     if (PROBE) {
         for (uint32_t i = tid; i < PROBE_TABLE; i += WG) pp->val[i] = i == 0 ? 1u : 0u;   // hash(0) = 0, hash(1) != 0
         if (tid == 0) {
@@ -539,6 +540,7 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
                 if (tid == 0) pp->lost = 0;
                 wg_lds_barrier();
             }
+            if (!probe_p0) probe_runs = true;   // (no sixteen distinct dwords at any of the places tried: bytes that are all alike -- a run is proposed)
             if (probe_p0 && tid < 12) {
                 const uint8_t* q = stage + A + probe_p0 + 4 * tid;
                 pp->ctx[tid] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
@@ -585,7 +587,7 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
     }
     if (COUNT_ONLY) return P - A;
     wg_lds_barrier();
-    if (PROBE && tid == 0) *hint_out = pp->best == 0xFFFFFFFFu ? 0u : pp->best;
+    if (PROBE && tid == 0) *hint_out = pp->best == 0xFFFFFFFFu ? (probe_runs ? 1u : 0u) : pp->best;
     {   // tail: bytes [F, P) still in LDS
         const uint32_t rem = (uint32_t)(P - F);
         const uint32_t lo = (F == 0) ? A : 0u;

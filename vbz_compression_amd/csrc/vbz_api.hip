@@ -1019,6 +1019,7 @@ bool plausible_extents(vbz_gpu_ctx* c, const vbz_gpu_batch* bt)
 int compress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const CompressionOptions* o, int sized, bool own_descriptors = false)
 {
     const uint32_t n = bt->n_reads;
+    c->last_span_frames = 0;   // (vbz_gpu_decode_span_paths: its redo[] lives in spanmeta, which a span-mode compress call carves anew)
     if (n == 0) return 0;
     ReadBatch rb = to_rb(bt);
     if (!own_descriptors && validate_descriptors(c, bt, &rb) != 0) return -1;
@@ -1046,6 +1047,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
 {
     const uint32_t n = bt->n_reads;
     c->last_frames = 0;
+    c->last_span_frames = 0;
     if (n == 0) return 0;
     hipStream_t s = c->stream;
     ReadBatch rb = to_rb(bt);
@@ -1579,7 +1581,8 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
         c->pinned = nullptr;
         c->pinned_cap = 0;
         const size_t want = std::max<size_t>(pin_need, 1u << 20);
-        if (hipHostMalloc(&c->pinned, want, hipHostMallocDefault) != hipSuccess) {
+        // (host-coherent: the hand-back flag is polled while the kernel that raises it may still be running)
+        if (hipHostMalloc(&c->pinned, want, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
             (void)hipGetLastError();
             c->pinned = nullptr;
             return VBZ_OUT_OF_MEMORY_ERROR;
@@ -1622,7 +1625,10 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
     bt.dst_bytes = dev_cap;
     bt.result = &dm->result;
     int rc = compress ? compress_batch_impl(c, &bt, o, sized, true) : decompress_batch_impl(c, &bt, o, sized, true);
-    if (rc != 0) return device_failure();
+    if (rc != 0) {
+        (void)hipStreamSynchronize(s);   // (the copy out of the pinned area may still be in flight: the next call rewrites it)
+        return device_failure();
+    }
     uint32_t result = VBZ_DEVICE_ERROR;
     uint32_t have = 0;   // bytes of the result that have arrived in pinned memory
     volatile uint32_t* hb = (volatile uint32_t*)(pin + out_off);
@@ -1631,6 +1637,7 @@ vbz_size_t run_one(bool compress, const void* src, vbz_size_t src_size, void* ds
         hb[2] = 0;
         if (launch_hand_back(&dm->result, (const uint8_t*)c->one_out.p, (uint32_t*)(pin + out_off), out_cap, seq, &dm->pad, s) != hipSuccess) {
             set_error(c, "hand-back launch failed: %s", hipGetErrorString(hipGetLastError()));
+            (void)hipStreamSynchronize(s);
             return device_failure();
         }
         // poll the flag; now and then ask the stream whether it is still alive (a faulting kernel never raises the flag)

@@ -956,12 +956,20 @@ __device__ void tokenise_runs(uint8_t* k, uint32_t K, uint2* rec, uint32_t& Lit,
 // before" (period_mask) and runs of RPER or more marked positions become sequences with the explicit offset D (OF table in
 // RLE mode with code floor(log2(D + 3))).
 constexpr uint32_t PERIOD_MIN_D = 64;   // (short distances: the d = 1 tokeniser and the Huffman code do better)
+// ... with ONE exception (round 6): distance 1, "a run".  Data bytes that are one long run -- iota of any integer type is one, the
+// reference's own perf and plugin-test input (vbz/perf/test_data_generator.h:12-23, vbz_hdf_plugin_test.cpp:15-48): every delta is 1 --
+// cost a Huffman code one bit per byte, and libzstd a few bytes per block: 1 MB of int16 iota came out as 64 696 bytes against 47
+// (profiles/r06_ratio_sweep.md).  A read whose probes cannot be placed because the bytes under them are all alike is proposed the
+// distance 1 (svb_kernels.hip, period_probe_kernel); it goes the way of every other distance: period_holds asks eight places spread
+// over the data bytes, the matcher marks "equals the byte in front of it" and runs of RPER and more become matches with the explicit
+// offset 1.
+constexpr uint32_t RUN_D = 1;
 
 // all lanes: eight places spread over the region are asked (one lane each); most of them must repeat what stands D bytes
 // before -- a template repeated with a few changed samples still qualifies, a chance hit of the probe does not.
 __device__ bool period_holds(const uint8_t* in, uint32_t S, uint32_t D, int lane)
 {
-    if (D < PERIOD_MIN_D || S < 8192 || (uint64_t)D + 32u > S) return false;
+    if ((D < PERIOD_MIN_D && D != RUN_D) || S < 8192 || (uint64_t)D + 32u > S) return false;
     bool agree = false;
     if (lane < 8) {
         const uint32_t t = D + 8u + (uint32_t)(((uint64_t)(S - D - 16u) * (uint32_t)lane) / 8u);  // spread over what has a predecessor
@@ -996,7 +1004,7 @@ __device__ __forceinline__ bool deep_layout(uint32_t N, uint32_t K, const uint8_
     if (frame_worst + 64 > dst_cap) return false;
     uint64_t room = dst_cap - frame_worst - 48;                           // of the destination slot, above the frame
     const uintptr_t top = (uintptr_t)(out + dst_cap) & ~(uintptr_t)15;
-    const uint64_t keyrecs = 8ull * (K / RMIN + 4u) + 8;                  // the control-byte region's records, at the top of the scratch slot
+    const uint64_t keyrecs = 8ull * (K / RMIN + 4u + 2u * d.nchK) + 8;    // the control-byte region's records (of every chunk of it), at the top of the scratch slot
     uintptr_t mask;
     if ((uint64_t)N + 32 + mask_bytes + 16 + keyrecs <= slot) {
         mask = ((uintptr_t)(in + slot) - keyrecs - mask_bytes) & ~(uintptr_t)15;
@@ -1601,6 +1609,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     // chunks of at most a block like the data bytes', each one block of literals and matches; without it (no period, too few
     // periods, no room) the region is coded as ever -- zero runs in one block, or plain Huffman blocks beyond a block's length.
     uint32_t deepDk = 0, kunits = 1, chunkK = 0;
+    bool kzero_chunks = false;   // the control bytes in chunks of at most a block, each with zero-run sequences of its own
     uint16_t* mask16K = nullptr;
     uint16_t* mask16 = nullptr;
     uint8_t* deep_recs = nullptr;
@@ -1608,7 +1617,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
     if (DEEP && !span_mode && deep_d && K != 0 && src_cap && seqtab && N - K >= 8192) {
         const uint32_t SD = N - K, D = deep_d[r];   // the first launch has checked the distance
         DeepLayout dl;
-        if (D >= PERIOD_MIN_D && (uint64_t)D + 32u <= SD && deep_layout(N, K, in, src_cap[r], out, cap, hdr, dl)) {
+        if ((D >= PERIOD_MIN_D || D == RUN_D) && (uint64_t)D + 32u <= SD && deep_layout(N, K, in, src_cap[r], out, cap, hdr, dl)) {
             period_mask(in + K, SD, D, dl.mask, lane);
             __syncthreads();
             // the matches are counted before anything is moved: they must fit the room their records have
@@ -1652,6 +1661,15 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                         }
                     }
                 }
+                // Control bytes without a distance of their own that are longer than a block (a long read: only the matcher's wavefront
+                // sees one whole): chunks of at most a block, each ONE block whose zero runs become sequences -- as plain Huffman blocks a
+                // region of zeros cost a bit per byte (iota of 1 M int8 values: 31 KB of its 44 KB; profiles/r06_ratio_sweep.md)
+                if (deepDk == 0 && K > BLOCK_MAX) {
+                    kzero_chunks = true;
+                    chunkK = ((K + dl.nchK - 1u) / dl.nchK + 15u) & ~15u;
+                    kunits = dl.nchK;
+                    nunit = kunits + dl.nch;
+                }
             }
         }
     }
@@ -1667,7 +1685,7 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         const bool isK = (uint32_t)region < kunits;
         const uint32_t cidx = isK ? (uint32_t)region : (uint32_t)region - kunits;
         const uint32_t r0 = span_mode ? sp.r0 : (isK ? cidx * chunkK : K + cidx * chunk);
-        const uint32_t r1 = span_mode ? sp.r1 : (isK ? ((deepDk && K - r0 > chunkK) ? r0 + chunkK : (K ? K : N)) : ((deepD && N - r0 > chunk) ? r0 + chunk : N));
+        const uint32_t r1 = span_mode ? sp.r1 : (isK ? (((deepDk || kzero_chunks) && K - r0 > chunkK) ? r0 + chunkK : (K ? K : N)) : ((deepD && N - r0 > chunk) ? r0 + chunk : N));
         if (!isK && K == 0) break;
         uint32_t S = r1 - r0;
         const bool lastRegion = span_mode ? (sp.flags & SPAN_LAST) != 0 : (r1 == N);
@@ -1692,6 +1710,9 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
                 bool shared_;
                 span_cut(N, K, TABLES ? shared.shspan : 0u, keyN, dataN, shared_);   // (only keyN is wanted)
                 ord = sp.ord;
+            } else if (kzero_chunks) {
+                keyN = kunits;
+                ord = cidx;
             }
             const uint32_t recs_all = (K ? K : N) / RMIN + 2u * keyN + 2u;  // (a frame without a control-byte region is tokenised as a whole)
             const uint64_t need = (uint64_t)N + 16 + 8ull * recs_all;
@@ -3028,7 +3049,8 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
     __syncthreads();
     // the check zstd_encode_kernel<.., false> makes at its top, by the first wavefront: does the distance hold, is there room
     if (tid < WAVE) {
-        const uint32_t hint = best == 0xFFFFFFFFu ? 0u : best;
+        // (probes that could not be placed at any of the places tried: the bytes there are all alike -- a run is proposed)
+        const uint32_t hint = best == 0xFFFFFFFFu ? ((!placed && SD >= PP_P0 + PP_TRIES * PP_SHIFT + 48u) ? RUN_D : 0u) : best;
         uint32_t D = 0;
         if (hint) {
             const uint8_t* in = b.src + b.src_off[r];

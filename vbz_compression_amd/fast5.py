@@ -80,12 +80,26 @@ def compress_many(filenames, output_suffix, vbz_version=0, decompress=False, gpu
     if not filenames:
         return []
     gpus = max(1, min(int(gpus), len(filenames)))
+    if gpus > 1:   # (the devices the kernel driver knows; a parent that never loads the HIP runtime cannot hand children an initialised one)
+        import glob
+
+        have = 0
+        for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            try:
+                with open(path) as f:
+                    have += any(ln.split()[0] == "simd_count" and int(ln.split()[1]) > 0 for ln in f if ln.strip())
+            except (OSError, ValueError, IndexError):
+                pass
+        if have and gpus > have:
+            raise ValueError("--gpus %d but %d GPU(s) in /sys/class/kfd" % (gpus, have))
     shares = [(0, len(filenames))] if gpus == 1 else deal_files([s for _, s in file_samples(filenames, hdf5_lib)], gpus)
     base = [_tool(), "-s", output_suffix, "--vbz-version", str(int(vbz_version))] + (["-d"] if decompress else []) + (["--hdf5-lib", hdf5_lib] if hdf5_lib else [])
     procs = []
     for device, (a, b) in enumerate(shares):
         if b > a:
-            procs.append((a, b, subprocess.Popen(base + ["--device", str(device)] + filenames[a:b], stdout=subprocess.PIPE, universal_newlines=True)))
+            # (one process: the tool's own default -- $VBZ_HIP_DEVICE, else device 0 -- stands)
+            dev = ["--device", str(device)] if gpus > 1 else []
+            procs.append((a, b, subprocess.Popen(base + dev + filenames[a:b], stdout=subprocess.PIPE, universal_newlines=True)))
     names = [None] * len(filenames)
     failed = None
     for a, b, p in procs:
