@@ -45,7 +45,7 @@ def cases(quick):
     for dt in (np.int8, np.int16, np.int32):
         n = 1000 * 1000 // np.dtype(dt).itemsize
         out.append(("perf/sequence %s" % np.dtype(dt).name, [np.arange(n, dtype=np.int64).astype(dt)], (True, np.dtype(dt).itemsize, 1, 0)))
-        lens = rng.integers(30000, 200001, 4 if quick else 24)
+        lens = rng.integers(30000, 200001, 12 if quick else 24)   # (the generator's own spread of lengths: what it reports is the aggregate)
         out.append(("perf/signal %s" % np.dtype(dt).name, [np.resize(t, int(k)).astype(dt) for k in lens], (True, np.dtype(dt).itemsize, 1, 0)))
     for dt in (np.int8, np.int16, np.int32, np.uint8, np.uint16, np.uint32):
         isz = np.dtype(dt).itemsize

@@ -983,6 +983,43 @@ __device__ bool period_holds(const uint8_t* in, uint32_t S, uint32_t D, int lane
     return __popcll(__ballot(agree)) >= 5;
 }
 
+// all lanes.  A read that was proposed the distance 1 (its probes could not be placed: runs) may be runs that REPEAT -- iota of int8 is 255
+// equal data bytes and a two-byte value, over and over (libzstd matches it at distance 257 and writes 2.9 KB where runs alone cost 20) --:
+// the places where a byte differs from the one in front of it are looked up in the 2 KB behind data byte 64, and the distance from the
+// first such place to the next one that does not belong to the same cluster is proposed instead, if it holds (period_holds); else the run.
+__device__ uint32_t run_period(const uint8_t* d, uint32_t S, int lane)
+{
+    constexpr uint32_t FROM = 64, SPAN = 32u * WAVE;
+    if (S < FROM + SPAN + 16u) return RUN_D;
+    const uint8_t* p = d + FROM + 32u * (uint32_t)lane;
+    uint32_t m = 0;
+    {
+        uint32_t w[9];
+        __builtin_memcpy(&w[1], p, 32);
+        w[0] = (uint32_t)p[-1] << 24;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t x = w[q + 1] ^ __builtin_amdgcn_alignbyte(w[q + 1], w[q], 3);   // zero byte <=> equals the byte in front of it
+            const uint32_t z = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+            m |= (((((z >> 7) * 0x00204081u) >> 21) & 0xFu) ^ 0xFu) << (4 * q);
+        }
+    }
+    uint64_t who = __ballot(m != 0);
+    uint32_t first = 0xFFFFFFFFu, cand = 0;
+    while (who != 0 && cand == 0) {
+        const int l = __ffsll((long long)who) - 1;
+        uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, l);
+        while (mm != 0 && cand == 0) {
+            const uint32_t at = 32u * (uint32_t)l + (uint32_t)__ffs((int)mm) - 1u;
+            if (first == 0xFFFFFFFFu) first = at;
+            else if (at >= first + PERIOD_MIN_D) cand = at - first;
+            mm &= mm - 1u;
+        }
+        who &= who - 1ull;
+    }
+    return (cand != 0 && period_holds(d, S, cand, lane)) ? cand : RUN_D;
+}
+
 // Where the long-repeat coder keeps its workspace -- one mask bit per data byte and one 8-byte record per match.  The mask
 // goes to the spare room of the library's scratch slot behind the stream (below the control-byte region's run records) if
 // it fits there, the records to the top of the read's DESTINATION slot, which the caller sizes for the worst case
@@ -1556,15 +1593,16 @@ __global__ __launch_bounds__(WAVE, VBZ_ENC_WAVES) void zstd_encode_kernel(ReadBa
         if (DEEP) {
             if (deep_d[r] == 0) return;
         } else {
-            const uint32_t hint = deep_d[r];
+            uint32_t hint = deep_d[r];
             if (hint) {
                 bool ok = false;
                 if (K != 0 && src_cap && seqtab && N - K >= 8192) {
                     DeepLayout dl;
+                    if (hint == RUN_D) hint = run_period(in + K, N - K, lane);   // (runs that repeat: their distance)
                     ok = deep_layout(N, K, in, src_cap[r], out, cap, hdr, dl) && period_holds(in + K, N - K, hint, lane);
                 }
+                if (lane == 0) deep_d[r] = ok ? hint : 0u;
                 if (ok) return;
-                if (lane == 0) deep_d[r] = 0;
             }
         }
     }
@@ -2231,15 +2269,18 @@ __global__ __launch_bounds__(WAVE, VBZ_TABLE_WAVES) void zstd_plan_kernel(ReadBa
     uint8_t* out = b.dst + b.dst_off[r];
     // a read whose repeat distance holds is the matcher's (the check the one-launch kernel makes at its top; deep_d[r] keeps the verdict)
     if (deep_d) {
-        const uint32_t hint = deep_d[r];
+        uint32_t hint = deep_d[r];
         if (hint) {
+            // (both roles of a read come here and reach the same verdict: whichever value of deep_d[r] the other has left -- the
+            // proposal, or the distance it has settled on --, the distance this one settles on is the same)
             bool ok = false;
             if (K != 0 && src_cap && seqtab && N - K >= 8192) {
                 DeepLayout dl;
+                if (hint == RUN_D) hint = run_period(in + K, N - K, lane);
                 ok = deep_layout(N, K, in, src_cap[r], out, cap, hdr, dl) && period_holds(in + K, N - K, hint, lane);
             }
+            if (lane == 0) deep_d[r] = ok ? hint : 0u;
             if (ok) return;
-            if (lane == 0) deep_d[r] = 0;
         }
     }
     if ((uint64_t)hdr + 9 > cap) return;
@@ -3055,7 +3096,8 @@ __global__ __launch_bounds__(256) void period_probe_kernel(ReadBatch b, const ui
         if (hint) {
             const uint8_t* in = b.src + b.src_off[r];
             DeepLayout dl;
-            if (deep_layout(N, K, in, src_cap[r], b.dst + b.dst_off[r], b.dst_cap[r], hdr, dl) && period_holds(in + K, SD, hint, tid)) D = hint;
+            const uint32_t h2 = hint == RUN_D ? run_period(in + K, SD, tid) : hint;
+            if (deep_layout(N, K, in, src_cap[r], b.dst + b.dst_off[r], b.dst_cap[r], hdr, dl) && period_holds(in + K, SD, h2, tid)) D = h2;
         }
         if (tid == 0) {
             deep_d[r] = D;
