@@ -59,29 +59,60 @@ def kfd_gpu_count():
 
 
 def launch_ranks(args, argv):
+    """Start one rank process per GPU, wait for all of them, relay rank 0's JSON line.  Every rank's stderr goes to a file of its own
+    (gpurun_out/ranks/rank<k>.err when that directory can be made, else a temporary one): a rank that fails takes its peers down
+    with timeouts, and it is the FIRST failing rank's last lines that say why -- they are relayed on the launcher's stderr."""
+    import tempfile
+
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    logdir = os.path.join(ROOT, "gpurun_out", "ranks")
+    try:
+        os.makedirs(logdir, exist_ok=True)
+    except OSError:
+        logdir = tempfile.mkdtemp(prefix="vbz_bench_ranks_")
+    procs, logs = [], []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0")
+        log = open(os.path.join(logdir, "rank%d.err" % r), "w+")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=log))
     out0 = procs[0].communicate()[0].decode()
-    rcs = [p.wait() for p in procs]
+    # the order the ranks end in: the first one to fail is the cause, the others follow it down
+    first_bad, rcs = None, [None] * len(procs)
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rc = p.poll()
+                if rc is not None:
+                    rcs[r] = rc
+                    if rc != 0 and first_bad is None:
+                        first_bad = r
+        time.sleep(0.05)
     line = ""
     for ln in out0.splitlines():
         if ln.startswith("{"):
             line = ln
     if line:
         print(line, flush=True)
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad or not line:
-        sys.stderr.write("bench.py launcher: rank exit codes %s%s\n" % (rcs, "" if line else "; rank 0 printed no JSON line"))
+    tails = []
+    for r, log in enumerate(logs):
+        log.flush()
+        log.seek(0)
+        tails.append(log.read()[-2000:])
+        log.close()
+    if first_bad is not None or not line:
+        sys.stderr.write("bench.py launcher: rank exit codes %s%s; per-rank stderr in %s\n" % (rcs, "" if line else "; rank 0 printed no JSON line", logdir))
+        who = first_bad if first_bad is not None else 0
+        sys.stderr.write("---- rank %d (the first to fail) ----\n%s\n" % (who, tails[who]))
         return 1
+    if tails[0].strip():   # (warnings of a run that went through: rank 0's, as before)
+        sys.stderr.write(tails[0])
     return 0
 
 

@@ -2,6 +2,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -137,6 +139,54 @@ def test_fixed_job_is_sharded_over_the_ranks():
     assert 1.0 <= two["rank_imbalance"] < 1.01
     assert one["collective"] == dict(one["collective"], backend=None, world_size=1, devices=[0], reads_per_rank=[3001])
     assert two["collective"]["world_size"] == 2 and sum(two["collective"]["reads_per_rank"]) == 3001
+
+
+def test_fixed_job_of_half_a_million_reads_over_eight_ranks():
+    """BASELINE configs[4] at its stated size -- 500 000 reads of ~100 k samples, 100 GB -- over EIGHT ranks: launcher, process group
+    (gloo here, RCCL on the node), read-table broadcast, partition by cumulative samples, tallies.  No codec (dry run): what the day
+    an 8-GPU node is there must already be right is the plumbing -- shares that add up to the job, ranks within 1 % of each other,
+    contiguous ranges, one device per rank.  No 1 -> 8 curve has been measured on hardware (README)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--workload", "config5", "--dry-run", "--total-reads", "500000"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong"
+    ranges = out["ranges"]
+    assert len(ranges) == 8 and ranges[0][0] == 0 and ranges[-1][1] == 500000
+    assert all(ranges[k][1] == ranges[k + 1][0] for k in range(7))
+    c = out["collective"]
+    assert c["world_size"] == 8 and sorted(c["devices"]) == list(range(8))
+    assert sum(c["reads_per_rank"]) == 500000 and c["reads_per_rank"] == [b - a for a, b in ranges]
+    assert 1.0 <= out["rank_imbalance"] <= 1.01
+    t = out["tallies"]
+    assert sum(row[0] for row in t) == 500000
+    assert 0.95e11 < sum(row[1] for row in t) < 1.05e11          # ~100 GB of raw signal
+
+
+def test_launcher_relays_the_first_failing_rank():
+    """A rank that fails takes the others down with it: the launcher must fail too and show THAT rank's last words (every rank's stderr
+    is kept in a file of its own)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # without --dry-run every rank needs a GPU: there is none here, so each says so and exits
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--reads", "64", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, HIP_VISIBLE_DEVICES="-1"))
+    if r.returncode == 0:
+        pytest.skip("this box has GPUs: the ranks ran")
+    if "GPU(s) in /sys/class/kfd" in r.stderr:
+        pytest.skip("fewer GPUs than ranks: the launcher refused before it started any")
+    assert "first to fail" in r.stderr and "rank exit codes" in r.stderr
 
 
 def test_launcher_counts_gpus_without_the_hip_runtime():
