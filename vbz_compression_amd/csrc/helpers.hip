@@ -247,6 +247,18 @@ __global__ __launch_bounds__(256) void canon_classify_kernel(uint32_t n, const u
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[0], (uint32_t)__popcll(m));
 }
 
+// how many words of a[0..n) are not zero (the frames the batched decoder left to the one-wavefront decoder: vbz_api.hip, foreign_note)
+__global__ __launch_bounds__(256) void count_nonzero_kernel(const uint32_t* a, uint32_t n, uint32_t* out)
+{
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += a[i] != 0;
+    const uint64_t m = __ballot(c != 0);
+    (void)m;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
 // results of the second launch group back to the reads they belong to
 __global__ void route_results_kernel(const uint32_t* l_result, const uint32_t* l_map, const uint32_t* l_count, uint32_t max_reads, uint32_t* result)
 {
@@ -435,6 +447,15 @@ hipError_t launch_route_reads(const ReadBatch& b, const uint32_t* raw_size, uint
 }
 
 size_t route_cand_words() { return ROUTE_CAND_MAX + 4; }
+
+hipError_t launch_count_nonzero(const uint32_t* a, uint32_t n, uint32_t* out, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(out, 0, 4, s);
+    if (e != hipSuccess) return e;
+    const uint32_t blocks = n < 256u * 64u ? (n + 255u) / 256u : 64u;
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(blocks ? blocks : 1u), dim3(256), 0, s, a, n, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_canon_classify(uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint32_t min_bytes, uint32_t* gate_small, uint32_t* gate_large,
                                  uint32_t* counts, hipStream_t s)

@@ -65,6 +65,15 @@ struct vbz_gpu_ctx
     int split_stagger = 0;        // VBZ_HIP_SPLIT_STAGGER=1: the upper half starts behind the lower half's first large launch (measured: 548 GB/s
                                   // against 565 when both halves start together -- the device interleaves the two queues by itself)
     bool last_split = false;      // vbz_gpu_decode_paths: the last decompress call ran as halves
+    // Frames of OTHER writers (every vbz file in existence: the reference's libzstd frames) decode on one wavefront each behind a chain walk
+    // of fixed latency, and two halves of such a call do not run beside each other (482 GB/s as one group, 420 as halves); the host
+    // does not know whose frames a call holds.  Every decompress call leaves the number of frames the batched decoder did not take in
+    // pinned memory (a counting launch and a 4-byte copy behind the call, no wait); the NEXT call looks at it if it has arrived and runs
+    // as one group when most frames were foreign.  A matter of speed only: the decoded bytes do not depend on it.
+    uint32_t* foreign_host = nullptr;   // pinned: [frames left to the one-wavefront decoder, frames looked at]
+    DevBuf foreign_dev;
+    hipEvent_t ev_foreign = nullptr;
+    bool foreign_pending = false, mostly_foreign = false;
     // Canonical encoding (vbz_gpu_set_canonical / VBZ_HIP_CANONICAL=1): a read's compressed bytes are a function of the read, the options
     // and the library version -- not of the batch it arrives in (see compress_canonical)
     bool canonical = false;
@@ -590,6 +599,24 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
            "zstd_decode (batched) launch");
     c->last_walked = walk;
     c->last_frames = dbg ? 0 : n;
+    if (c->split_min != 0 && n >= c->split_min / 2 && !dbg) {   // (the context of a call that may be split: see foreign_host)
+        if (!c->foreign_host && (hipHostMalloc((void**)&c->foreign_host, 16, hipHostMallocDefault) != hipSuccess ||
+                                 hipEventCreateWithFlags(&c->ev_foreign, hipEventDisableTiming) != hipSuccess)) {
+            (void)hipGetLastError();
+            if (c->foreign_host) (void)hipHostFree(c->foreign_host);
+            c->foreign_host = nullptr;
+        }
+        if (c->foreign_host && !c->foreign_pending && ensure(c, c->foreign_dev, 16)) {
+            uint32_t* d = (uint32_t*)c->foreign_dev.p;
+            if (launch_count_nonzero(zstd_fast_redo(c->fastmeta.p, n), n, d, s) == hipSuccess &&
+                hipMemcpyAsync(c->foreign_host, d, 4, hipMemcpyDeviceToHost, s) == hipSuccess && hipEventRecord(c->ev_foreign, s) == hipSuccess) {
+                c->foreign_host[1] = n;
+                c->foreign_pending = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     return 0;
 }
 
@@ -1068,7 +1095,13 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
         rb.gate = gate;
     }
     const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n, true);
-    const bool split = !by_shape && split_applies(c, o, n);
+    if (c->foreign_pending && hipEventQuery(c->ev_foreign) == hipSuccess) {   // what the call before this one found (see foreign_host)
+        c->mostly_foreign = 2ull * c->foreign_host[0] > c->foreign_host[1];
+        c->foreign_pending = false;
+    } else if (c->foreign_pending) {
+        (void)hipGetLastError();   // (hipErrorNotReady is not an error to leave behind)
+    }
+    const bool split = !by_shape && split_applies(c, o, n) && !c->mostly_foreign;
     c->last_split = false;
     if (by_shape || !routing_applies(c, o, bt->dst_bytes, n))
         return split ? decompress_split(c, rb, bt->dst_bytes, o) : decompress_group(c, rb, bt->dst_bytes, o, by_shape);
@@ -1190,7 +1223,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs, &c->splitmeta })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs, &c->splitmeta, &c->foreign_dev })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
     if (c->half) vbz_gpu_destroy(c->half);
@@ -1203,6 +1236,8 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->canon_host) (void)hipHostFree(c->canon_host);
+    if (c->foreign_host) (void)hipHostFree(c->foreign_host);
+    if (c->ev_foreign) (void)hipEventDestroy(c->ev_foreign);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -235,6 +235,7 @@ struct ScratchPlan
 };
 hipError_t launch_seg_plan(uint32_t n, const uint32_t* size, uint32_t unit_bytes, const uint32_t* gate, uint32_t max_segs, uint32_t* seg_first,
                            uint32_t* gate_out, const ScratchPlan* scratch, hipStream_t s);
+hipError_t launch_count_nonzero(const uint32_t* a, uint32_t n, uint32_t* out, hipStream_t s);   // *out = the words of a[0..n) that are not zero
 // canonical mode: see canon_classify_kernel (helpers.hip).  counts: two words of device memory.
 hipError_t launch_canon_classify(uint32_t n, const uint32_t* raw_size, const uint32_t* gate, uint32_t min_bytes, uint32_t* gate_small, uint32_t* gate_large,
                                  uint32_t* counts, hipStream_t s);
