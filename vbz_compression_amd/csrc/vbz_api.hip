@@ -74,6 +74,7 @@ struct vbz_gpu_ctx
     DevBuf foreign_dev;
     hipEvent_t ev_foreign = nullptr;
     bool foreign_pending = false, mostly_foreign = false;
+    int foreign_state = -1;   // what the last call that was looked at held: -1 not known, 0 no foreign frame at all, 1 some
     // Canonical encoding (vbz_gpu_set_canonical / VBZ_HIP_CANONICAL=1): a read's compressed bytes are a function of the read, the options
     // and the library version -- not of the batch it arrives in (see compress_canonical)
     bool canonical = false;
@@ -589,7 +590,10 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
     // that finds no room is decoded as before).  libzstd on nanopore signal writes ~1 100 sequences per 126 KB of content -- records of
     // 14 % of the content's size --: the workspace is a quarter of the declared content + 1 MiB, at most 1 GiB (the declared size
     // is the caller's word, and the buffer stays with the context: ADVICE round 4; 16 384 reads of 100 k samples need 290 MB).
-    const bool walk = c->ref_chains >= 2 || (c->ref_chains == 1 && n >= REF_MIN_READS);
+    // (a workload that has shown no foreign frame does not launch the walk at all: the -- empty -- launch sits on a side stream, gets its
+    // few wavefronts late when the device is full, and the launches behind the join wait for it; should foreign frames appear after all,
+    // the one-wavefront decoder walks their chains itself for one call and the next call knows)
+    const bool walk = (c->ref_chains >= 2 || (c->ref_chains == 1 && n >= REF_MIN_READS)) && (c->foreign_state != 0 || c->ref_chains >= 2);
     const uint64_t recs_bytes = walk ? std::min<uint64_t>(((content_bytes >> 2) + (1ull << 20)) & ~15ull, 1ull << 30) : 0;
     if (walk && (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
         return -1;
@@ -888,6 +892,7 @@ int split_plan(vbz_gpu_ctx* c, const ReadBatch& rb, const uint32_t* raw_size, ui
     k->ref_chains = c->ref_chains;
     k->fuse_svb = c->fuse_svb;
     k->profiling = c->profiling;
+    k->foreign_state = c->foreign_state;
     const size_t scratch_need = (size_t)(((unsigned __int128)raw_bytes * num + den - 1) / den) + (size_t)n * 96 + 256;
     if (!ensure(c, c->scratch, scratch_need) || !ensure(c, c->splitmeta, (size_t)n * 16 + 256)) return -1;
     MetaCarver mc(c->splitmeta.p);
@@ -1097,6 +1102,7 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
     const bool by_shape = o->integer_size != 0 && !half_codec(o) && use_segments(c, bt->dst_bytes, n, true);
     if (c->foreign_pending && hipEventQuery(c->ev_foreign) == hipSuccess) {   // what the call before this one found (see foreign_host)
         c->mostly_foreign = 2ull * c->foreign_host[0] > c->foreign_host[1];
+        c->foreign_state = c->foreign_host[0] != 0 ? 1 : 0;
         c->foreign_pending = false;
     } else if (c->foreign_pending) {
         (void)hipGetLastError();   // (hipErrorNotReady is not an error to leave behind)
