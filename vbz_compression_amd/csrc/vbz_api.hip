@@ -1131,9 +1131,9 @@ int decompress_batch_impl(vbz_gpu_ctx* c, const vbz_gpu_batch* bt, const Compres
 extern "C" {
 
 #ifdef VBZ_EXPERIMENTS
-const char* vbz_gpu_version(void) { return "vbz_hip 0.5.0 gfx950 +experiments"; }
+const char* vbz_gpu_version(void) { return "vbz_hip 0.6.0 gfx950 +experiments"; }
 #else
-const char* vbz_gpu_version(void) { return "vbz_hip 0.5.0 gfx950"; }
+const char* vbz_gpu_version(void) { return "vbz_hip 0.6.0 gfx950"; }
 #endif
 
 vbz_gpu_ctx* vbz_gpu_create(int device, void* stream)

@@ -503,10 +503,26 @@ __device__ __forceinline__ void fast_fill_table(uint16_t* T, const uint8_t* W, u
     }
 }
 
-constexpr int RING = 64;          // dwords per lane in the LDS ring
-constexpr int BATCH = 32;         // one request: a whole aligned 128-byte line
-constexpr int PERIOD = 32;        // symbols between two requests (at most 11 dwords: the ring cannot run dry, profiles/r04_stream_scaling.md)
+// Round 6: a 32-dword ring, 64-byte requests, a look at the ring's room every 16 symbols -- 13.5 KB of LDS per wavefront instead of 21.8:
+// eleven wavefronts per CU instead of seven.  The kernel is a chain of dependent LDS look-ups (two per symbol pair, ~220 cycles per symbol
+// and lane at seven wavefronts, VALU 25 - 44 % busy, LDS pipe 35 %): wavefronts in flight are what its throughput follows.  Looking at the
+// room twice as often costs 0.85 ms per 65 536 frames by itself (VBZ_FS_RING=64 VBZ_FS_BATCH=32 VBZ_FS_PERIOD=16: 7.6 against 6.75 ms for the
+// whole stage), the four wavefronts more return it and a little more: 6.76 ms alone, and 608 against 597 GB/s for the step with the two
+// halves of a call in flight (round 5's 48-dword ring paid the first and got two wavefronts: it lost).
+#ifndef VBZ_FS_RING
+#define VBZ_FS_RING 32
+#define VBZ_FS_BATCH 16
+#define VBZ_FS_PERIOD 16
+#endif
+constexpr int RING = VBZ_FS_RING;      // dwords per lane in the LDS ring
+constexpr int BATCH = VBZ_FS_BATCH;    // one request: a whole aligned line of 4 * BATCH bytes (128)
+constexpr int PERIOD = VBZ_FS_PERIOD;  // symbols between two requests (at most 11 bits each: PERIOD * 11 / 32 dwords)
 constexpr int BURST = 128;        // bytes a lane stores together
+constexpr unsigned long long LINE = 4ull * BATCH;
+// The ring cannot run dry between a request and its commit (one period later): a request is refused while more than RING - BATCH dwords
+// are unread, so a period starts with at least RING - BATCH + 1 - (a period's worst case) unread dwords, which must cover a period
+static_assert((RING & (RING - 1)) == 0 && RING - BATCH + 1 - (PERIOD * 11 + 31) / 32 >= (PERIOD * 11 + 31) / 32, "the ring would run dry");
+static_assert(BURST % PERIOD == 0 && PERIOD % 16 == 0 && BATCH % 4 == 0, "burst = whole periods, period = whole groups of 16 symbols");
 constexpr uint32_t TBL_BIG = 2048, TBL_SMALL = 512;  // entries: one table of up to 11-bit codes, one of up to 9-bit codes
 
 // The decoder of zstd_decode.hip's flush_tasks_ring (no bit buffer: the next 32 unread bits are one v_alignbit of two ring dwords held
@@ -569,8 +585,8 @@ __global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const F
             cnt = 0;
         } else {
             const uint64_t e = (uint64_t)(p + nbytes);
-            nextline = (e + 127ull) & ~127ull;
-            lowline = (uint64_t)p & ~127ull;
+            nextline = (e + (LINE - 1ull)) & ~(LINE - 1ull);
+            lowline = (uint64_t)p & ~(LINE - 1ull);
             const uint32_t pad = (uint32_t)(nextline - e);
             n = -(int32_t)(8u * pad + 8u - (uint32_t)(31 - __clz((int)last)));  // bytes above the stream, padding bits, end mark
             end_bits = 8u * (nbytes + pad);
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const F
     typedef __attribute__((address_space(1))) const u32x4 gq4;
 #define FETCH(pend)                                                         \
     do {                                                                    \
-        gcu8* q__ = (gcu8*)(nextline - 128ull);                             \
+        gcu8* q__ = (gcu8*)(nextline - LINE);                               \
         _Pragma("unroll") for (int v = 0; v < BATCH / 4; ++v) {             \
             const u32x4 x__ = *(gq4*)(q__ + 16 * (BATCH / 4 - 1 - v));      \
             pend[4 * v + 0] = x__.w;                                        \
@@ -587,7 +603,7 @@ __global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const F
             pend[4 * v + 2] = x__.y;                                        \
             pend[4 * v + 3] = x__.x;                                        \
         }                                                                   \
-        nextline -= 128ull;                                                 \
+        nextline -= LINE;                                                   \
     } while (0)
 #define RING_PUT(pend)                                                                                 \
     do {                                                                                               \
