@@ -1106,8 +1106,11 @@ __device__ __forceinline__ bool svb_decode_range(const uint8_t* in, const uint8_
     return good;
 }
 
+#ifndef VBZ_SVBDEC_WAVES
+#define VBZ_SVBDEC_WAVES 1
+#endif
 template <int ELEM, bool ZZ, bool I16ZZ>
-__global__ __launch_bounds__(WG) void svb_decode_kernel(ReadBatch b)
+__global__ __launch_bounds__(WG, VBZ_SVBDEC_WAVES) void svb_decode_kernel(ReadBatch b)
 {
     constexpr int STAGE = I16ZZ ? 2 * (int)I16DecPairs::BUF : WG * Vpl<ELEM>::value * 4 + 48;   // (int16 zig-zag: the two buffers of I16DecPairs; the tile loop's 8240 bytes fit)
     static_assert(STAGE >= WG * Vpl<ELEM>::value * 4 + 48, "the tile loop's stage");
