@@ -252,10 +252,7 @@ __global__ __launch_bounds__(256) void count_nonzero_kernel(const uint32_t* a, u
 {
     uint32_t c = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += a[i] != 0;
-    const uint64_t m = __ballot(c != 0);
-    (void)m;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+    c = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(c), 63);   // (all 64 lanes are here: the wavefront's total)
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
 

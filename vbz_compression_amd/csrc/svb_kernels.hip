@@ -149,6 +149,7 @@ struct I16Pairs
     uint8_t* gal;
     uint8_t* stage;      // two buffers of BUF bytes; [0] is the one the caller's own loop uses
     uint32_t* wsum;      // 8 words
+    uint16_t* kb16;      // 2 x 512 halfwords: the control bytes of a pair on their way out (two sets used in turn)
     PeriodProbe* pp;
     CntLds* CL;
     uint32_t A, hmode;
@@ -251,7 +252,7 @@ struct I16Pairs
         const uint32_t m0 = wv > 0 ? 0xFFFFFFFFu : 0u, m1 = wv > 1 ? 0xFFFFFFFFu : 0u, m2 = wv > 2 ? 0xFFFFFFFFu : 0u;
         uint32_t cur = 0;   // the stage buffer this trip writes
         const uint8_t* ip = in + ((size_t)t0 + (size_t)tid * 8) * 2;
-        uint8_t* kp = keys + ((t0 + (uint32_t)tid * 8) >> 2);
+        uint8_t* kp0 = keys + (t0 >> 2);   // the pair's control bytes: 1 KB from here
         // lane 0 of a wavefront: the aligned dword in front of its samples -- its top half is the sample in front (samples start 16-byte
         // aligned here, and the read's very first value has nothing in front of it)
         auto prev_of = [&](const uint8_t* p, bool first_value) -> uint32_t {
@@ -283,17 +284,21 @@ struct I16Pairs
             const uint32_t ka = ((fa0 * 0x01041040u) >> 24) | (((fa1 * 0x01041040u) >> 24) << 8);
             const uint32_t kb = ((fb0 * 0x01041040u) >> 24) | (((fb1 * 0x01041040u) >> 24) << 8);
             const uint32_t pa0 = fa0 * 0x01010101u, pa1 = fa1 * 0x01010101u, pb0 = fb0 * 0x01010101u, pb1 = fb1 * 0x01010101u;
-            {
-                const uint16_t k0 = (uint16_t)ka, k1 = (uint16_t)kb;
-                __builtin_memcpy(kp, &k0, 2);
-                __builtin_memcpy(kp + TILE / 4, &k1, 2);
-            }
+            // control bytes: a lane's two bytes per tile go to LDS, and behind the barrier ONE wavefront stores the pair's kilobyte of them
+            // as 16 bytes per lane (two 2-byte stores per lane of every wavefront measured 0.36 ms of the kernel's 4.2: 1.6 GB in 128-byte
+            // requests)
+            kb16[par * 128 + (uint32_t)tid] = (uint16_t)ka;
+            kb16[par * 128 + 256u + (uint32_t)tid] = (uint16_t)kb;
             // one scan for both tiles: tile A's byte count in the low half, tile B's in the high half
             const uint32_t L = (8u + (pa0 >> 24) + (pa1 >> 24)) | ((8u + (pb0 >> 24) + (pb1 >> 24)) << 16);
             const uint32_t inc = wave_incl_scan_u32(L);
             uint32_t* ws = wsum + par;
             if (lane == 63) ws[wv] = inc;
             wg_lds_barrier();   // (also: the previous trip's kept bytes stand in this trip's buffer, its flush has read the other one)
+            if (tid < 64) {
+                const uint4 kv = *reinterpret_cast<const uint4*>(kb16 + par * 128 + 8u * (uint32_t)tid);
+                __builtin_memcpy(kp0 + 16u * (uint32_t)tid, &kv, 16);
+            }
             const uint4 s4 = *reinterpret_cast<const uint4*>(ws);
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(s4.x + s4.y + s4.z + s4.w));
             const uint32_t ex = (s4.x & m0) + (s4.y & m1) + (s4.z & m2) + inc - L;
@@ -314,7 +319,7 @@ struct I16Pairs
             par ^= 4u;
             t0 += 2u * TILE;
             ip += TILE * 4;
-            kp += TILE / 2;
+            kp0 += TILE / 2;
         }
         wg_lds_barrier();   // the last flush has read its buffer, the kept bytes stand in stage[cur]
         if (cur != 0) {
@@ -376,7 +381,7 @@ __device__ __forceinline__ uint64_t svb_encode_range(const uint8_t* in, uint32_t
             // (with PROBE the read's first tile goes through the loop below, which builds the probe table from it)
             fast_done = true;
             if (end - t0 >= 2u * (uint32_t)TILE) {
-                I16Pairs<PROBE, CNT> fp = { in, keys, gal, stage, wsum, pp, CL, A, hmode, cnt_on, probe_p0 };
+                I16Pairs<PROBE, CNT> fp = { in, keys, gal, stage, wsum, reinterpret_cast<uint16_t*>(stage + 2 * I16Pairs<PROBE, CNT>::BUF), pp, CL, A, hmode, cnt_on, probe_p0 };
                 t0 = fp.run(t0, end, F, P);
                 if (t0 >= end) break;
                 const uint32_t i0 = t0 + (uint32_t)tid * VPL;
@@ -603,7 +608,7 @@ template <int ELEM, bool I16ZZ>
 struct EncStage
 {
     // (int16 zig-zag: the two buffers of I16Pairs; the tile loop of svb_encode_range uses the head of the first, one tile's worst case)
-    static constexpr int value = I16ZZ ? 2 * (int)I16Pairs<false, false>::BUF : WG * Vpl<ELEM>::value * 4 + 32;
+    static constexpr int value = I16ZZ ? 2 * (int)I16Pairs<false, false>::BUF + 2048 : WG * Vpl<ELEM>::value * 4 + 32;   // (+ the control bytes' 2 x 1 KB)
 };
 
 template <bool CNT> struct CntLdsOf { typedef CntLds type; };
