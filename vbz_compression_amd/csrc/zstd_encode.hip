@@ -2343,9 +2343,15 @@ __global__ __launch_bounds__(WAVE, VBZ_TABLE_WAVES) void zstd_plan_kernel(ReadBa
 // and step, a wave prefix sum of the bit counts, bits OR-ed into an LDS buffer, 16-byte quads out), the block headers; the sequences
 // section of the first block moved into place; the checkpoint trailer.  Byte for byte the fused kernel's frame.  80 registers and
 // 5 KB of LDS instead of 128 (+ spills) and 10 KB: 24 waves per CU instead of 16 (profiles/r04_experiments.md).
+#ifndef VBZ_PACK_TABLE_COPIES
+#define VBZ_PACK_TABLE_COPIES 1
+#endif
+constexpr int PACK_COPIES = VBZ_PACK_TABLE_COPIES;   // copies of the code table, one per group of 64 / PACK_COPIES lanes (fewer lanes per bank).
+// Measured (round 6; the kernel's LDS pipe is 75 % busy, a fifth of it bank conflicts): two copies +- 0 (6.75 - 6.85 against 6.77 - 6.82 ms for
+// the encoder), four copies + 0.75 ms (7.9 KB of LDS: four wavefronts per CU fewer).  One copy stays.
 struct PackLds
 {
-    uint32_t ctable[256];   // code | length << 16
+    uint32_t ctable[PACK_COPIES * 256];   // code | length << 16
     uint32_t tree[34];
     uint32_t ssize[WAVE], sbeg[WAVE], scnt[WAVE];
     // Two bit buffers, used in turn: a step's complete quads stay in its buffer and are stored at the top of the NEXT step, in front
@@ -2369,7 +2375,12 @@ __device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint
 #define REDO() return false
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) L.ctable[lane + 64 * j] = ctable_g[lane + 64 * j];
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t e = ctable_g[lane + 64 * j];
+#pragma unroll
+        for (int cpy = 0; cpy < PACK_COPIES; ++cpy) L.ctable[256 * cpy + lane + 64 * j] = e;
+    }
+    const uint32_t* const mytable = L.ctable + 256 * (lane / (WAVE / PACK_COPIES));
     if (lane < 34) L.tree[lane] = tree_g[lane];
     const uint32_t base = S / nblk, extra = S % nblk;
     {
@@ -2500,7 +2511,7 @@ __device__ __forceinline__ bool pack_region(PackLds& L, const uint8_t* rin, uint
         const int skip = room >= STEP_LANE ? 0 : (room <= 0 ? STEP_LANE : (int)(STEP_LANE - room));
         uint32_t ent[STEP_LANE];   // code | length << 16 of the lane's symbols
 #pragma unroll
-        for (int k = 0; k < STEP_LANE; ++k) ent[k] = L.ctable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
+        for (int k = 0; k < STEP_LANE; ++k) ent[k] = mytable[(cur[k >> 2] >> (8 * (k & 3))) & 0xFF];
         if (skip != 0) {  // only the last step of a stream has lanes in front of its start
 #pragma unroll
             for (int k = 0; k < STEP_LANE; ++k) ent[k] = k >= skip ? ent[k] : 0u;
