@@ -2250,9 +2250,9 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                             }
                             for (uint64_t bigs = ltype == 1 ? 0ull : __ballot(big); bigs; bigs &= bigs - 1) {
                                 const int bl = __ffsll((long long)bigs) - 1;
-                                const uint32_t bo = (uint32_t)__shfl((int)(oposw + it - tot), bl, 64);
-                                const uint32_t bf = (uint32_t)__shfl((int)lp, bl, 64);
-                                wave_copy((gu8*)dst + bo, (gcu8*)litp + bf, (uint32_t)__shfl((int)ll, bl, 64), lane);
+                                const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)(oposw + it - tot), bl);
+                                const uint32_t bf = (uint32_t)__builtin_amdgcn_readlane((int)lp, bl);
+                                wave_copy((gu8*)dst + bo, (gcu8*)litp + bf, (uint32_t)__builtin_amdgcn_readlane((int)ll, bl), lane);
                             }
                             lposw += (uint32_t)__builtin_amdgcn_readlane((int)il, 63);
                             oposw += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
@@ -2282,7 +2282,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                             uint64_t todo = __ballot(i < nseq && sv.y != 0);
                             while (todo) {
                                 const int f = __ffsll((long long)todo) - 1;
-                                const uint32_t frontier = (uint32_t)__shfl((int)mdst, f, 64);
+                                const uint32_t frontier = (uint32_t)__builtin_amdgcn_readlane((int)mdst, f);
                                 const bool mine = ((todo >> lane) & 1ull) && (lane == f || msrc + sv.y <= frontier || sv.z <= sv.x);  // ... or its source lies in its own literals
                                 // a match longer than its offset repeats the bytes in front of it: offsets 1, 2, 4, 8, 16
                                 // (runs of a byte, of a key pattern) become pattern stores, other short offsets go byte by byte
@@ -2303,18 +2303,18 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                                 }
                                 for (uint64_t bigs = __ballot(big); bigs; bigs &= bigs - 1) {
                                     const int bl = __ffsll((long long)bigs) - 1;
-                                    const uint32_t bo = (uint32_t)__shfl((int)mdst, bl, 64), bn = (uint32_t)__shfl((int)sv.y, bl, 64);
-                                    if (__shfl((int)pat, bl, 64)) {
+                                    const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)mdst, bl), bn = (uint32_t)__builtin_amdgcn_readlane((int)sv.y, bl);
+                                    if (__builtin_amdgcn_readlane((int)pat, bl)) {
                                         u32x4 bv;
-                                        bv.x = (uint32_t)__shfl((int)pv.x, bl, 64);
-                                        bv.y = (uint32_t)__shfl((int)pv.y, bl, 64);
-                                        bv.z = (uint32_t)__shfl((int)pv.z, bl, 64);
-                                        bv.w = (uint32_t)__shfl((int)pv.w, bl, 64);
+                                        bv.x = (uint32_t)__builtin_amdgcn_readlane((int)pv.x, bl);
+                                        bv.y = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, bl);
+                                        bv.z = (uint32_t)__builtin_amdgcn_readlane((int)pv.z, bl);
+                                        bv.w = (uint32_t)__builtin_amdgcn_readlane((int)pv.w, bl);
                                         wave_fill((gu8*)dst + bo, bv, bn, lane);
-                                    } else if (__shfl((int)rep, bl, 64)) {
-                                        wave_copy_repeat((gu8*)dst + bo, (uint32_t)__shfl((int)sv.z, bl, 64), bn, lane);
+                                    } else if (__builtin_amdgcn_readlane((int)rep, bl)) {
+                                        wave_copy_repeat((gu8*)dst + bo, (uint32_t)__builtin_amdgcn_readlane((int)sv.z, bl), bn, lane);
                                     } else {
-                                        wave_copy((gu8*)dst + bo, (gcu8*)dst + (uint32_t)__shfl((int)msrc, bl, 64), bn, lane);
+                                        wave_copy((gu8*)dst + bo, (gcu8*)dst + (uint32_t)__builtin_amdgcn_readlane((int)msrc, bl), bn, lane);
                                     }
                                 }
                                 todo &= ~__ballot(mine);

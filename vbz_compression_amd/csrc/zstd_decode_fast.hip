@@ -495,9 +495,9 @@ __device__ __forceinline__ void fast_fill_table(uint16_t* T, const uint8_t* W, u
         while (big) {
             const int src_lane = __ffsll((long long)big) - 1;
             big &= big - 1;
-            const uint32_t bst = (uint32_t)__shfl((int)st[j], src_lane, 64);
-            const uint32_t blen = (uint32_t)__shfl((int)len[j], src_lane, 64);
-            const uint32_t bent = (uint32_t)__shfl((int)ent, src_lane, 64);
+            const uint32_t bst = (uint32_t)__builtin_amdgcn_readlane((int)st[j], src_lane);
+            const uint32_t blen = (uint32_t)__builtin_amdgcn_readlane((int)len[j], src_lane);
+            const uint32_t bent = (uint32_t)__builtin_amdgcn_readlane((int)ent, src_lane);
             for (uint32_t i = lane; i < blen; i += WAVE) T[bst + i] = (uint16_t)bent;
         }
     }

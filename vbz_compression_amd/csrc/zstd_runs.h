@@ -151,9 +151,10 @@ __device__ __noinline__ uint32_t place_zero_runs(uint8_t* dst, const uint2* pair
         while (big) {
             const int sl_ = __ffsll((long long)big) - 1;
             big &= big - 1;
-            const uint32_t bo = (uint32_t)__shfl((int)my_out, sl_, 64);
-            const uint32_t bl = (uint32_t)__shfl((int)ml, sl_, 64);
-            const uint32_t bv = (uint32_t)__shfl((int)lastb, sl_, 64);
+            // (the lane comes out of a ballot: a scalar -- v_readlane, not a round trip through the LDS crossbar per value)
+            const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)my_out, sl_);
+            const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)ml, sl_);
+            const uint32_t bv = (uint32_t)__builtin_amdgcn_readlane((int)lastb, sl_);
             for (uint32_t k = lane; k < bl; k += WAVE) dst[bo + k] = (uint8_t)bv;
         }
         lposw += tl;
