@@ -178,11 +178,21 @@ struct RefPre
     uint32_t ok, nblk, pad[6];
     RefBlock blk[REF_MAXBLK];
 };
+// The literals of a reference-written frame's first block, decoded ahead of the one-wavefront decoder BESIDE the chain walk (the walk is a
+// few hundred wavefronts bound by latency; the literals are seven tenths of such a frame's cycles and need nothing of the chains):
+// blk = where the block header sits in the frame (0: not done), regen / csize as its literals header says, at = where in the
+// destination slot the literals stand.  The decoder takes them when its own reading of the block says the same four numbers.
+struct RefLits
+{
+    uint32_t blk, regen, csize, at;
+};
 struct RefChains  // what launch_zstd_decode_only needs of them (pre == nullptr: none)
 {
     const RefPre* pre = nullptr;
     const void* recs = nullptr;
+    const RefLits* lits = nullptr;   // (nullable; only looked at for frames whose chains are walked)
 };
+
 size_t zstd_ref_pre_bytes(uint32_t n_reads);
 const RefPre* zstd_ref_pre(const void* pre_meta);  // the per-frame hand-overs inside pre_meta
 size_t zstd_ref_table_bytes(uint32_t n_reads);     // 0: a batch of this size keeps its tables in LDS

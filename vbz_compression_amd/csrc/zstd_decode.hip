@@ -1075,6 +1075,10 @@ __device__ __noinline__ bool huf_split_plan(const uint8_t* src, uint32_t& ntask,
 // Returns true if any stream is corrupt.
 __device__ __noinline__ bool flush_tasks(const uint8_t* src, uint8_t* dst, uint32_t& ntask, bool keep_fse, int lane)
 {
+    if (ntask == 0) {   // (a block whose literals stood already)
+        __syncthreads();
+        return false;
+    }
     constexpr int KEEP = 3 * FSE_SLOT / WAVE;
     uint32_t keep[KEEP];
     uint32_t* f = &L.u.p.fse[0][0];
@@ -1954,7 +1958,13 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             }
             const uint32_t lit_dst = !has_seq ? opos : (defer ? ws_lit : (par ? ws_plit : fcs - regen));
             const uint8_t* lit_src = blk + lh;  // raw literals are read in place
-            if (ltype >= 2) {
+            // a walked frame's literals may stand already (ref_pieces_kernel, beside the walk): the same block, sizes and place
+            bool lits_ahead = false;
+            if (use_pre && chains.lits != nullptr && ltype == 2 && streams == 4) {
+                const RefLits rl = chains.lits[r];
+                lits_ahead = uni((rl.blk != 0 && rl.blk == pos - 3 && rl.regen == regen && rl.csize == csize && rl.at == lit_dst) ? 1u : 0u) != 0;
+            }
+            if (ltype >= 2 && !lits_ahead) {
                 const uint8_t* q = blk + lh + tree_used;
                 uint32_t qn = csize - tree_used;
                 if (ntask + streams > WAVE) {

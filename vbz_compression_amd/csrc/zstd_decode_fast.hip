@@ -21,6 +21,8 @@
 // array -- which is also what decides every error verdict.  A frame decoded here gets exactly the bytes the one-wavefront decoder
 // writes: same tables, same streams, same placement code.
 // Replaces, like zstd_decode.hip, the reference's ZSTD_decompress call (vbz/vbz.cpp:236-273).
+#include <cstdlib>
+
 #include "vbz_kernels.h"
 #include "zstd_runs.h"
 
@@ -69,6 +71,38 @@ __device__ __forceinline__ uint64_t ld64(const uint8_t* p)
     return v;
 }
 
+// one lane: the frame header (RFC 8878 3.1.1.1) of a frame of at least 16 bytes, in the terms of zstd_decode_kernel; false: not for the
+// batched kernels (F->fcs, F->block_max, *pos = where the first block begins)
+__device__ __forceinline__ bool scan_frame_header(const uint8_t* src, uint32_t cap, FastFrame* F, uint32_t* pos_out, uint32_t* has_checksum)
+{
+    const uint64_t h0 = ld64(src), h1 = ld64(src + 8);
+    auto hb = [&](uint32_t i) -> uint32_t { return (uint32_t)((i < 8 ? h0 >> (8 * i) : h1 >> (8 * (i - 8))) & 0xFF); };
+    const uint32_t fhd = hb(4);
+    if ((uint32_t)h0 != 0xFD2FB528u || (fhd & 0x08) || (fhd & 3)) return false;  // (a Dictionary_ID field: the careful decoder)
+    const uint32_t single = (fhd >> 5) & 1, fcs_flag = fhd >> 6;
+    uint32_t pos = 5;
+    uint64_t window = 0;
+    if (!single) {
+        const uint32_t wd = hb(pos++);
+        const uint32_t wlog = 10 + (wd >> 3);
+        if (wlog > 31) return false;
+        window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
+    }
+    const uint32_t fsz = fcs_flag == 0 ? (single ? 1u : 0u) : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
+    if (fsz == 0) return false;
+    uint64_t fcs = 0;
+    for (uint32_t i = 0; i < fsz; ++i) fcs |= (uint64_t)hb(pos + i) << (8 * i);
+    if (fsz == 2) fcs += 256;
+    pos += fsz;
+    if (fcs > cap || fcs >= (1u << 30)) return false;
+    if (single) window = fcs;
+    F->fcs = (uint32_t)fcs;
+    F->block_max = (uint32_t)(window < BLOCK_MAX ? window : BLOCK_MAX);
+    *has_checksum = (fhd >> 2) & 1;
+    *pos_out = pos;
+    return true;
+}
+
 // ---- one lane per frame ------------------------------------------------------------------------------------------------------------
 // Everything zstd_decode_kernel checks on its way through a frame of this shape is checked here (or in the kernels behind), in the
 // same terms; whatever is not of this shape returns early and leaves redo[r] = 1.  (Reads of up to 16 bytes past the read are inside
@@ -86,32 +120,7 @@ __global__ __launch_bounds__(256) void fast_scan_kernel(ReadBatch b, FastFrame* 
     FastFrame F = {};
     uint32_t pos;
     uint32_t has_checksum;
-    {
-        const uint64_t h0 = ld64(src), h1 = ld64(src + 8);
-        auto hb = [&](uint32_t i) -> uint32_t { return (uint32_t)((i < 8 ? h0 >> (8 * i) : h1 >> (8 * (i - 8))) & 0xFF); };
-        const uint32_t fhd = hb(4);
-        if ((uint32_t)h0 != 0xFD2FB528u || (fhd & 0x08) || (fhd & 3)) return;  // (a Dictionary_ID field: the careful decoder)
-        const uint32_t single = (fhd >> 5) & 1, fcs_flag = fhd >> 6;
-        pos = 5;
-        uint64_t window = 0;
-        if (!single) {
-            const uint32_t wd = hb(pos++);
-            const uint32_t wlog = 10 + (wd >> 3);
-            if (wlog > 31) return;
-            window = (1ull << wlog) + ((1ull << wlog) >> 3) * (wd & 7);
-        }
-        const uint32_t fsz = fcs_flag == 0 ? (single ? 1u : 0u) : (fcs_flag == 1 ? 2u : (fcs_flag == 2 ? 4u : 8u));
-        if (fsz == 0) return;
-        uint64_t fcs = 0;
-        for (uint32_t i = 0; i < fsz; ++i) fcs |= (uint64_t)hb(pos + i) << (8 * i);
-        if (fsz == 2) fcs += 256;
-        pos += fsz;
-        if (fcs > cap || fcs >= (1u << 30)) return;
-        if (single) window = fcs;
-        F.fcs = (uint32_t)fcs;
-        F.block_max = (uint32_t)(window < BLOCK_MAX ? window : BLOCK_MAX);
-        has_checksum = (fhd >> 2) & 1;
-    }
+    if (!scan_frame_header(src, cap, &F, &pos, &has_checksum)) return;
     // the encoder's checkpoint trailer (see zero_run_chain_segments); an index trailer may follow it
     if (n >= 64) {
         uint32_t tb = ld32(src + n - 4), ne = n;
@@ -740,6 +749,358 @@ __global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const F
     }
 }
 
+// ---- frames the reference wrote: the literals of the first block, beside the chain walk (RefLits, vbz_kernels.h) ---------------------
+// libzstd gives a read one or two 128 KB blocks whose literals are FOUR Huffman streams of up to 32 KB: a chain of ~ 28 000 dependent
+// symbols per stream, seven tenths of what such a frame costs the one-wavefront decoder -- and nothing of it needs the sequence chains
+// that ref_chain_kernel walks meanwhile on a few hundred wavefronts.  Huffman codes resynchronise, so (as zstd_decode.hip's
+// huf_split_plan) every stream is cut into 16 pieces of equal bit length, one lane each; but a piece is walked ONCE here:
+//   run-up  a lane starts REF_RUNUP bits before its piece (dry) and walks to the first code boundary inside it: its presumed start;
+//   walk    from there to the first boundary inside the next piece, and what it decodes is KEPT -- in a stripe of its own in the free
+//           part of the destination slot, behind where the block's literals belong;
+//   check   a piece's end must be the next one's presumed start, the last one's the first bit of the stream, and the counts must add
+//           up to the stream's regenerated size;
+//   move    then the counts place every piece, and the bytes are moved (a copy through the caches, a thirtieth of a walk).
+// Nothing is repaired and no verdict is given here: a frame for which anything fails is left as it was -- the one-wavefront decoder
+// decodes its streams itself and is the one to say what is wrong with it.
+constexpr uint32_t REF_TASKS = 4;
+constexpr uint32_t REF_PIECES_LOG = 4, REF_PIECES = 1u << REF_PIECES_LOG;
+constexpr uint32_t REF_RUNUP = 768;                          // bits
+constexpr uint32_t REF_MIN_STREAM = 64u * REF_PIECES;        // bytes: shorter streams are not worth it
+#ifndef VBZ_REF_MOVE_G
+#define VBZ_REF_MOVE_G 8
+#endif
+constexpr int MOVE_G = VBZ_REF_MOVE_G;                       // pieces moved together
+static_assert(REF_TASKS * REF_PIECES == (uint32_t)WAVE, "one lane per piece");
+
+// one lane per frame with only[r] != 0: is it of the shape, where are the tree and the four streams (skip[r] = 0 if so)
+__global__ __launch_bounds__(256) void ref_lit_scan_kernel(ReadBatch b, const uint32_t* only, FastFrame* frames, FastTask* tasks, uint32_t* skip)
+{
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    if (r >= b.n_reads) return;
+    skip[r] = 1;
+    if (!only[r]) return;
+    if (b.gate && b.gate[r] >= GATE_SKIP) return;
+    const uint32_t n = b.src_size[r];
+    if (n >= E_FIRST || n < 32) return;
+    const uint8_t* src = b.src + b.src_off[r];
+    const uint32_t cap = b.dst_cap[r];
+    FastFrame F = {};
+    uint32_t pos, has_checksum;
+    if (!scan_frame_header(src, cap, &F, &pos, &has_checksum)) return;
+    if (pos + 3 + 16 > n) return;
+    const uint64_t a0 = ld64(src + pos), a1 = ld64(src + pos + 8);
+    const uint32_t bh = (uint32_t)a0 & 0xFFFFFFu;
+    const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
+    if (btype != 2 || bsize < 5 || bsize >= BLOCK_MAX || (uint64_t)pos + 3 + bsize > n) return;
+    const uint32_t blk = pos + 3;
+    uint32_t lh, regen, csize;
+    {
+        const uint64_t v = (a0 >> 24) | (a1 << 40);
+        const uint32_t h0 = (uint32_t)v & 0xFF, fmt = (h0 >> 2) & 3;
+        if ((h0 & 3) != 2 || fmt == 0) return;   // compressed literals under a tree of their own, four streams
+        if (fmt == 1) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; }
+        else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; }
+        else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; }
+    }
+    if (regen == 0 || csize == 0 || regen > BLOCK_MAX || lh + csize >= bsize || regen > F.fcs) return;
+    if (src[blk + lh + csize] == 0) return;      // no sequences: such literals go straight to the output
+    // where the decoder stages the literals of a block whose chains are walked ahead (zstd_decode_kernel: ws_plit, par)
+    const uint64_t at = ((uint64_t)F.fcs + 15u) & ~15ull;
+    if (at + ((regen + 15u) & ~15u) + 16 > cap) return;
+    const uint32_t hb = src[blk + lh];
+    uint32_t tree_used;
+    if (hb >= 128) tree_used = 1 + ((hb - 127) + 1) / 2;
+    else if (hb == 0) return;
+    else tree_used = 1 + hb;
+    if (tree_used + 10 > csize) return;
+    uint32_t q = blk + lh + tree_used, qn = csize - tree_used - 6;
+    const uint64_t j = ld64(src + q);
+    const uint32_t s1 = (uint32_t)j & 0xFFFFu, s2 = (uint32_t)(j >> 16) & 0xFFFFu, s3 = (uint32_t)(j >> 32) & 0xFFFFu;
+    q += 6;
+    if (s1 + s2 + s3 > qn) return;
+    const uint32_t seg = (regen + 3) >> 2;
+    if (seg * 3 > regen) return;
+    const uint32_t so[4] = { 0u, s1, s1 + s2, s1 + s2 + s3 };
+    const uint32_t sz[4] = { s1, s2, s3, qn - s1 - s2 - s3 };
+    if (sz[0] < REF_MIN_STREAM || sz[1] < REF_MIN_STREAM || sz[2] < REF_MIN_STREAM || sz[3] < REF_MIN_STREAM) return;
+    F.ntask = REF_TASKS;
+    F.ntree = 1;
+    F.tree_off[0] = blk + lh;
+    F.tree_len[0] = tree_used;
+    F.b0_regen = regen;
+    F.ws_lit = (uint32_t)at;
+    F.pad[0] = pos;      // the block header
+    F.pad[1] = csize;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        FastTask t;
+        t.src = q + so[k];
+        t.size = sz[k];
+        t.out = (uint32_t)at + (uint32_t)k * seg;
+        t.cnt = k < 3 ? seg : regen - 3 * seg;
+        tasks[(size_t)r * REF_TASKS + k] = t;
+    }
+    frames[r] = F;
+    skip[r] = 0;
+}
+
+// one wavefront per frame that the scan and the weights kernel have passed: the table, the 64 pieces, the check, the move
+__global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const FastFrame* frames, const FastTask* tasks, const uint8_t* weights,
+                                                            const uint32_t* skip, RefLits* lits)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t T[TBL_BIG];
+    __shared__ uint32_t ringbuf[RING + 1][WAVE];
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x;
+    RefLits res = { 0u, 0u, 0u, 0u };
+#define LEAVE()                           \
+    do {                                  \
+        if (lane == 0) lits[r] = res;     \
+        return;                           \
+    } while (0)
+    if (skip[r]) LEAVE();
+    const FastFrame* F = frames + r;
+    const uint32_t tlog = F->tlog[0];
+    if (tlog > 11 || tlog == 0) LEAVE();
+    fast_fill_table(T, weights + ((size_t)r * 2) * 256, F->nw[0], tlog, lane);
+    const uint8_t* src = b.src + b.src_off[r];
+    uint8_t* dst = b.dst + b.dst_off[r];
+    const uint32_t cap = b.dst_cap[r];
+    const uint32_t st = (uint32_t)lane >> REF_PIECES_LOG, j = (uint32_t)lane & (REF_PIECES - 1u);
+    const FastTask tk = tasks[(size_t)r * REF_TASKS + st];
+    const uint32_t nbytes = tk.size, cnt = tk.cnt;
+    const uint8_t* p = src + tk.src;
+    const uint32_t last = p[nbytes - 1];
+    if (__any(last == 0)) LEAVE();
+    const uint32_t pad = 8u - (uint32_t)hbit(last), B = 8u * nbytes;
+    const uint32_t seg = (B - pad + REF_PIECES - 1u) >> REF_PIECES_LOG;
+    const uint32_t c_lo = pad + j * seg, c_hi = j == REF_PIECES - 1u ? B : pad + (j + 1u) * seg;
+    // the stripes: what the slot has behind the literals' place, 128-byte aligned, a 64th each; a piece holds its share of the
+    // stream's symbols give or take a few per cent -- a stripe must have room for a quarter more, else the frame is not done here
+    const uint32_t regen = F->b0_regen;
+    const uint64_t tb = ((uint64_t)(dst + F->ws_lit + ((regen + 15u) & ~15u) + 16u) + 127ull) & ~127ull, te = (uint64_t)(dst + cap);
+    const uint32_t pcap = te > tb ? (uint32_t)(((te - tb) >> 6) < 0x10000ull ? ((te - tb) >> 6) : 0x10000ull) & ~127u : 0u;
+    if (__any((cnt >> REF_PIECES_LOG) + (cnt >> (REF_PIECES_LOG + 2u)) + 256u > pcap)) LEAVE();
+    gu8* o = (gu8*)(tb + (uint64_t)lane * pcap);
+
+    // ---- the walker: fast_streams_kernel's (aligned lines into a ring per lane, two symbols per 32 fresh bits), started in mid-stream:
+    // bit positions count from the top of the first line a lane requests (rel = abs + off; abs: bits consumed from the stream's end)
+    const uint32_t sL = 32u - tlog;
+    const uint16_t* Tl = T;
+    uint32_t* ring = &ringbuf[0][0] + lane;
+    const uint32_t from = (j == 0 || c_lo - pad <= REF_RUNUP) ? pad : c_lo - REF_RUNUP;
+    const uint64_t e = (uint64_t)(p + nbytes);
+    uint64_t nextline = (e - (uint64_t)(from >> 3) + (LINE - 1ull)) & ~(LINE - 1ull);
+    const uint64_t lowline = (uint64_t)p & ~(LINE - 1ull);
+    const int32_t off = (int32_t)(8ll * (int64_t)(nextline - e));
+    int32_t n = -((int32_t)from + off);
+    uint32_t widx = 0;
+    wave_lds_sync();
+    typedef __attribute__((address_space(1))) const u32x4 gq4;
+#define FETCH(pend)                                                         \
+    do {                                                                    \
+        gcu8* q__ = (gcu8*)(nextline - LINE);                               \
+        _Pragma("unroll") for (int v = 0; v < BATCH / 4; ++v) {             \
+            const u32x4 x__ = *(gq4*)(q__ + 16 * (BATCH / 4 - 1 - v));      \
+            pend[4 * v + 0] = x__.w;                                        \
+            pend[4 * v + 1] = x__.z;                                        \
+            pend[4 * v + 2] = x__.y;                                        \
+            pend[4 * v + 3] = x__.x;                                        \
+        }                                                                   \
+        nextline -= LINE;                                                   \
+    } while (0)
+#define RING_PUT(pend)                                                                                 \
+    do {                                                                                               \
+        const uint32_t wb__ = (uint32_t)RING - (widx & (uint32_t)(RING - 1));                          \
+        _Pragma("unroll") for (int k = 0; k < BATCH; ++k) ring[(wb__ - (uint32_t)k) * WAVE] = pend[k]; \
+        if (wb__ == (uint32_t)RING) ring[0] = pend[0];                                                 \
+        widx += BATCH;                                                                                 \
+    } while (0)
+#define MORE() (nextline > lowline)
+    for (int f = 0; f < 2; ++f) {
+        uint32_t pend0[BATCH];
+        if (MORE()) {
+            FETCH(pend0);
+            RING_PUT(pend0);
+        }
+    }
+    int32_t tprev = n >> 5;
+    uint32_t w0 = ring[((((uint32_t)tprev) & (uint32_t)(RING - 1)) + 1u) * WAVE];
+    uint32_t w1 = ring[(((uint32_t)tprev) & (uint32_t)(RING - 1)) * WAVE];
+    uint32_t w2 = ring[(((uint32_t)tprev - 1u) & (uint32_t)(RING - 1)) * WAVE];
+#define HUF_PAIR(e1, e2)                                                     \
+    do {                                                                     \
+        const int32_t t__ = n >> 5;                                          \
+        const bool adv__ = t__ != tprev;                                     \
+        const uint32_t a__ = adv__ ? w1 : w0, b__ = adv__ ? w2 : w1;         \
+        w0 = a__;                                                            \
+        w1 = b__;                                                            \
+        tprev = t__;                                                         \
+        w2 = ring[(((uint32_t)t__ - 1u) & (uint32_t)(RING - 1)) * WAVE];     \
+        uint32_t x__ = __builtin_amdgcn_alignbit(a__, b__, (uint32_t)n);     \
+        e1 = Tl[x__ >> sL];                                                  \
+        x__ <<= (e1 >> 8);                                                   \
+        e2 = Tl[x__ >> sL];                                                  \
+    } while (0)
+#define QUAD(dstword)                                                                             \
+    do {                                                                                          \
+        uint32_t e1, e2, e3, e4;                                                                  \
+        HUF_PAIR(e1, e2);                                                                         \
+        n -= (int32_t)((e1 >> 8) + (e2 >> 8));                                                    \
+        HUF_PAIR(e3, e4);                                                                         \
+        n -= (int32_t)((e3 >> 8) + (e4 >> 8));                                                    \
+        dstword = (e1 & 0xFFu) | ((e2 & 0xFFu) << 8) | ((e3 & 0xFFu) << 16) | (e4 << 24);         \
+    } while (0)
+#define ROOM() (widx - (((uint32_t)~n) >> 5) <= (uint32_t)(RING - BATCH))
+    typedef __attribute__((address_space(1), aligned(16))) u32x4 gs4;
+    uint32_t m = 0;
+    bool spill = false;
+    // to the first code boundary at or beyond `stop` (rel).  A symbol is at most 11 bits: 128 / 16 symbols are decoded unlooked-at while
+    // they cannot cross it, the last few one by one.  keep: the symbols are stored (a lane that runs out of room stops, and says so).
+    auto walk_to = [&](int32_t stop, bool keep) {
+        if (keep) {
+            while (__any(!spill && stop + n >= (int32_t)(BURST * 11))) {
+                if (!spill && stop + n >= (int32_t)(BURST * 11)) {
+                    if (m + (uint32_t)BURST > pcap) {
+                        spill = true;
+                    } else {
+                        uint32_t ow[BURST / 4];
+#pragma unroll
+                        for (int h = 0; h < BURST / PERIOD; ++h) {
+                            uint32_t pend[BATCH];
+                            const bool issue = ROOM() && MORE();
+                            if (issue) FETCH(pend);
+#pragma unroll
+                            for (int q = h * PERIOD / 4; q < (h + 1) * PERIOD / 4; ++q) QUAD(ow[q]);
+                            if (h == BURST / PERIOD - 1) {
+#pragma unroll
+                                for (int q = 0; q < BURST / 16; ++q) {
+                                    const u32x4 ov = { ow[4 * q], ow[4 * q + 1], ow[4 * q + 2], ow[4 * q + 3] };
+                                    *(gs4*)(o + 16 * q) = ov;
+                                }
+                            }
+                            if (issue) RING_PUT(pend);
+                        }
+                        o += BURST;
+                        m += BURST;
+                    }
+                }
+            }
+        }
+        while (__any(!spill && stop + n >= 16 * 11)) {
+            uint32_t pend[BATCH];
+            const bool go = !spill && stop + n >= 16 * 11;
+            const bool issue = go && ROOM() && MORE();
+            if (issue) FETCH(pend);
+            if (go) {
+                uint32_t ow[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) QUAD(ow[q]);
+                if (keep) {
+                    if (m + 16u > pcap) {
+                        spill = true;
+                    } else {
+                        const u32x4 ov = { ow[0], ow[1], ow[2], ow[3] };
+                        *(gs4*)o = ov;
+                        o += 16;
+                        m += 16;
+                    }
+                }
+            }
+            if (issue) RING_PUT(pend);
+        }
+        while (__any(!spill && stop + n > 0)) {
+            uint32_t pend[BATCH];
+            const bool issue = !spill && stop + n > 0 && ROOM() && MORE();
+            if (issue) FETCH(pend);
+#pragma unroll 1
+            for (int i = 0; i < 16; ++i) {
+                if (!spill && stop + n > 0) {
+                    uint32_t e1, e2;
+                    HUF_PAIR(e1, e2);
+                    (void)e2;  // only the first symbol of the pair is taken
+                    n -= (int32_t)(e1 >> 8);
+                    if (keep) {
+                        if (m + 1u > pcap) {
+                            spill = true;
+                        } else {
+                            *o = (uint8_t)e1;
+                            ++o;
+                            ++m;
+                        }
+                    }
+                }
+            }
+            if (issue) RING_PUT(pend);
+        }
+    };
+    walk_to((int32_t)c_lo + off, false);           // run-up (lanes that start at a known boundary are there already)
+    const uint32_t s_bit = (uint32_t)(-n - off);   // where this piece presumably starts
+    walk_to((int32_t)c_hi + off, true);
+    const uint32_t e_bit = (uint32_t)(-n - off);
+#undef HUF_PAIR
+#undef QUAD
+#undef ROOM
+#undef MORE
+#undef RING_PUT
+#undef FETCH
+    if (__any(spill)) LEAVE();
+    // ---- the pieces must chain from the end mark to the first bit of the stream, symbol for symbol
+    const uint32_t e_prev = (uint32_t)__shfl_up((int)e_bit, 1, 64);
+    const bool holds = (j == 0 ? s_bit == pad : s_bit == e_prev) && (j != REF_PIECES - 1u || e_bit == B);
+    const uint32_t incl = wave_incl_scan_u32(m);
+    const uint32_t before_ = (uint32_t)__shfl((int)incl, st ? (int)(st * REF_PIECES) - 1 : 0, 64);   // (every lane takes part: the source must be active)
+    const uint32_t before = st ? before_ : 0u;
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(st * REF_PIECES + REF_PIECES - 1u), 64) - before;
+#ifdef VBZ_REF_DEBUG
+    if (r == 0) printf("lane %2d st %u j %2u pad %u B %u seg %u c_lo %u c_hi %u from %u off %d s_bit %u e_bit %u e_prev %u m %u cnt %u total %u holds %d spill %d pcap %u\n", lane, st, j, pad, B, seg, c_lo, c_hi, from, off, s_bit, e_bit, e_prev, m, cnt, total, (int)holds, (int)spill, pcap);
+#endif
+    if (__any(!holds || total != cnt)) LEAVE();
+    __syncthreads();   // (the stripes are in memory)
+    // ---- the move: piece after piece by the whole wavefront (a lane moving its own piece is 64 requests an instruction; this way an
+    // instruction is a kilobyte of whole lines), eight pieces' loads in flight before their stores
+    {
+        typedef __attribute__((address_space(1), aligned(16))) const u32x4 gl4;
+        typedef __attribute__((address_space(1), aligned(1))) u32x4 gst4;
+        const uint32_t dpos = tk.out + (incl - m - before);
+        const uint32_t k0 = 16u * (uint32_t)lane;
+        for (int g = 0; g < WAVE; g += MOVE_G) {
+            u32x4 v[MOVE_G][3];
+            uint32_t tailb[MOVE_G];
+#pragma unroll
+            for (int u = 0; u < MOVE_G; ++u) {
+                const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)m, g + u);
+                gcu8* f = (gcu8*)(tb + (uint64_t)(g + u) * pcap);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (k0 + 1024u * c + 16u <= mq) v[u][c] = *(gl4*)(f + k0 + 1024u * c);
+                const uint32_t rb = mq & 15u;
+                tailb[u] = (uint32_t)lane < rb ? f[mq - rb + (uint32_t)lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < MOVE_G; ++u) {
+                const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)m, g + u);
+                gu8* d = (gu8*)dst + (uint32_t)__builtin_amdgcn_readlane((int)dpos, g + u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (k0 + 1024u * c + 16u <= mq) *(gst4*)(d + k0 + 1024u * c) = v[u][c];
+                const uint32_t rb = mq & 15u;
+                if ((uint32_t)lane < rb) d[mq - rb + (uint32_t)lane] = (uint8_t)tailb[u];
+                if (mq > 3072u + 16u) {   // (a stripe of more than 3 KB: only where the slot is far larger than the frame)
+                    gcu8* f = (gcu8*)(tb + (uint64_t)(g + u) * pcap);
+                    for (uint32_t k = k0 + 3072u; k + 16u <= mq; k += 1024u) *(gst4*)(d + k) = *(gl4*)(f + k);
+                }
+            }
+        }
+    }
+    res.blk = F->pad[0];
+    res.regen = regen;
+    res.csize = F->pad[1];
+    res.at = F->ws_lit;
+    LEAVE();
+#undef LEAVE
+}
+
 // ---- one wavefront per frame: the zero-run block ----------------------------------------------------------------------------------------
 constexpr uint32_t RUNS_LDS = 8704;
 __global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const FastFrame* frames, const SeqDTables* dtabs, uint32_t* redo)
@@ -775,9 +1136,20 @@ __global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const Fast
 
 }  // namespace
 
+// VBZ_HIP_REF_LITERALS=0: no literals ahead of the decoder (measurements, tests of the other path)
+static int ref_lits_ahead()
+{
+    static const int on = [] {
+        const char* e = getenv("VBZ_HIP_REF_LITERALS");
+        return e ? atoi(e) : 1;   // (3: behind the walk instead of beside it -- measurements)
+    }();
+    return on;
+}
+
 size_t zstd_fast_meta_bytes(uint32_t n_reads)
 {
-    return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4 + 4) + 1024;
+    return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4 + 4) + 1024 +
+           (size_t)n_reads * (sizeof(FastFrame) + REF_TASKS * sizeof(FastTask) + 512 + 4 + sizeof(RefLits)) + 1024;   // (... of the reference's frames)
 }
 
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads)
@@ -800,6 +1172,17 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
     uint32_t* redo = reinterpret_cast<uint32_t*>(m);
     m += (size_t)n * 4;
     uint32_t* scanned = reinterpret_cast<uint32_t*>(m);  // redo[] as the scan left it: what the chain walk goes by
+    m += (size_t)n * 4;
+    m += (256 - (reinterpret_cast<uintptr_t>(m) & 255)) & 255;
+    FastFrame* rframes = reinterpret_cast<FastFrame*>(m);   // the literals of the reference's frames (ref_pieces_kernel)
+    m += (size_t)n * sizeof(FastFrame);
+    FastTask* rtasks = reinterpret_cast<FastTask*>(m);
+    m += (size_t)n * REF_TASKS * sizeof(FastTask);
+    uint8_t* rweights = m;
+    m += (size_t)n * 512;
+    RefLits* rlits = reinterpret_cast<RefLits*>(m);
+    m += (size_t)n * sizeof(RefLits);
+    uint32_t* rskip = reinterpret_cast<uint32_t*>(m);
     hipError_t e = hipSuccess;
     if (dbg) {  // phase timing: every frame to the one-wavefront decoder
         e = hipMemsetAsync(redo, 1, 4ull * n, s);
@@ -833,6 +1216,18 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
         hipLaunchKernelGGL(fast_streams_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, tasks, weights, redo);
         hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
         e = hipGetLastError();
+    }
+    if (beside && ref_lits_ahead() == 3) {
+        const hipError_t e1 = hipStreamWaitEvent(s, side.join, 0);
+        if (e == hipSuccess) e = e1;
+    }
+    // the literals of the frames being walked, meanwhile
+    if (ref_pre && ref_lits_ahead() && e == hipSuccess) {
+        hipLaunchKernelGGL(ref_lit_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, scanned, rframes, rtasks, rskip);
+        hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, rframes, rweights, rskip);
+        hipLaunchKernelGGL(ref_pieces_kernel, dim3(n), dim3(WAVE), 0, s, b, rframes, rtasks, rweights, rskip, rlits);
+        e = hipGetLastError();
+        chains.lits = rlits;
     }
     if (beside) {
         const hipError_t e1 = hipStreamWaitEvent(s, side.join, 0);

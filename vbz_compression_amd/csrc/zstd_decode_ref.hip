@@ -629,6 +629,11 @@ __global__ __launch_bounds__(WAVE) void ref_chain_kernel(ReadBatch b, const uint
 {
     __shared__ RefLds<FPW, INLDS> S;
     const int l = threadIdx.x;
+    // a few hundred wavefronts whose latency the whole call waits for, beside thousands that only need throughput (the literals of the
+    // same frames, ref_pieces_kernel): theirs is the issue slot when both want it
+#ifndef VBZ_REF_NOPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     if (l < 36) S.llb[l] = LL_BASE[l];
     if (l < 53) S.mlb[l] = ML_BASE[l];
     __syncthreads();
