@@ -157,6 +157,9 @@ VBZ_EXPORT void vbz_gpu_profile_reset(vbz_gpu_ctx* ctx);
  * general decoder (frames the reference wrote with libzstd).  Returns the number of frames of that group, 0 when it did not run on these
  * paths (the large-read path, VBZ_HIP_FAST_DECODE=0), < 0 on a device error.  The bytes and verdicts never depend on the path. */
 VBZ_EXPORT int vbz_gpu_decode_paths(vbz_gpu_ctx* ctx, uint32_t* batched, uint32_t* walked);
+/* ... and for how many of the walked frames the literals of the first block were decoded beside the walk (64 pieces of the four Huffman
+ * streams, one lane each, ahead of the general decoder; VBZ_HIP_REF_LITERALS=0: never).  A diagnostic like the above; < 0 on a device error. */
+VBZ_EXPORT int vbz_gpu_decode_literals_ahead(vbz_gpu_ctx* ctx);
 /* The same for the large-read path (few, large reads; synchronizes): *by_spans = frames of the last decompress launch group that were
  * decoded span by span as their index says (or, without an index, by one wavefront at once) -- the others needed the second, gated
  * launch of the one-wavefront decoder.  Returns the frames of that group, 0 when it did not run on the large-read path. */

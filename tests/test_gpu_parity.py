@@ -1856,6 +1856,7 @@ out = {}
 caps16 = [a.nbytes for a in reads] * (len(frames16) // len(reads))
 out['i16'] = G.decompress(frames16, caps16, _lib.CompressionOptions(True, 2, 1, 1))
 out['i16_paths'] = G.codec().decode_paths()
+out['i16_ahead'] = G.codec().decode_literals_ahead()
 # both kinds of frame in one call: the walk runs beside the batched decoder's launches for this library's frames
 own = G.compress(reads, _lib.CompressionOptions(True, 2, 1, 1))
 mix, mixcaps = [], []
@@ -1909,16 +1910,21 @@ pickle.dump(out, open(sys.argv[2], 'wb'))
         outs = {}
         # walked with the tables in LDS (what a batch of this size gets), walked with the tables in memory (what a batch of more
         # than 9216 frames gets), not walked
-        for walk, tables in (("2", "lds"), ("2", "mem"), ("0", "lds")):
-            env = dict(os.environ, VBZ_HIP_REF_CHAINS=walk, VBZ_HIP_REF_TABLES=tables, VBZ_HIP_SEGMENTED="0", VBZ_HIP_ROUTING="0")
+        # ... and walked without the literals of the first block decoded beside the walk (round 6: ref_pieces_kernel; on by default)
+        for walk, tables, lits in (("2", "lds", "1"), ("2", "mem", "1"), ("0", "lds", "1"), ("2", "mem", "0")):
+            env = dict(os.environ, VBZ_HIP_REF_CHAINS=walk, VBZ_HIP_REF_TABLES=tables, VBZ_HIP_SEGMENTED="0", VBZ_HIP_ROUTING="0", VBZ_HIP_REF_LITERALS=lits)
             subprocess.run([sys.executable, "-c", code, os.path.join(td, "in.pkl"), os.path.join(td, "out.pkl")], check=True, env=env)
-            outs[walk + tables] = pickle.load(open(os.path.join(td, "out.pkl"), "rb"))
-    on, mem, off = outs["2lds"], outs["2mem"], outs["0lds"]
+            outs[walk + tables + lits] = pickle.load(open(os.path.join(td, "out.pkl"), "rb"))
+    on, mem, off, nolits = outs["2lds1"], outs["2mem1"], outs["0lds1"], outs["2mem0"]
     for k in ("i16", "mix", "i32", "zoo", "bad"):
-        assert len(on[k]) == len(off[k]) == len(mem[k])
-        for i, (a, b, c) in enumerate(zip(on[k], off[k], mem[k])):
-            assert a == b and a == c, (k, i)
-        assert off[k + "_paths"][2] == 0 and mem[k + "_paths"] == on[k + "_paths"]
+        assert len(on[k]) == len(off[k]) == len(mem[k]) == len(nolits[k])
+        for i, (a, b, c, d) in enumerate(zip(on[k], off[k], mem[k], nolits[k])):
+            assert a == b and a == c and a == d, (k, i)
+        assert off[k + "_paths"][2] == 0 and mem[k + "_paths"] == on[k + "_paths"] == nolits[k + "_paths"]
+    # the literals were decoded ahead for the reads that have four streams of a kilobyte and more in their first block (not: the short
+    # reads, zeros, noise); never without the walk or when switched off
+    assert on["i16_ahead"] == mem["i16_ahead"] and on["i16_ahead"] >= 3 * 5 and off["i16_ahead"] == 0 and nolits["i16_ahead"] == 0, \
+        (on["i16_ahead"], mem["i16_ahead"], off["i16_ahead"], nolits["i16_ahead"])
     for i, f in enumerate(frames16):
         assert on["i16"][i] == reads[i % len(reads)].tobytes(), i
     for i in range(2 * len(reads)):
@@ -1977,3 +1983,45 @@ def test_walked_chains_in_calls_large_enough_to_walk_by_default():
     for i, b in enumerate(back):
         assert not isinstance(b, int) and b.tobytes() == reads[i // 2].tobytes(), i
 
+
+
+def test_reference_frames_literals_decoded_beside_the_walk():
+    """Round 6: for frames the reference wrote, the four Huffman streams of the first block are cut into 64 pieces that are walked once
+    (ref_pieces_kernel, beside the chain walk) and left in stripes the general decoder reads in place (zstd_decode_fast.hip / RefLits).
+    A call large enough to walk by default, reads chosen for what the decoder does with stripes: first blocks below and above the 24 KB of
+    literals from which the streams are cut (about 30 000 samples), up to full 128 KB ones, second blocks, long runs of literals (moved by the whole wavefront across
+    stripes), long zero runs (patterns taken from the literals), matches that copy their own literals, flat and noisy stretches."""
+    import gpu_util as G
+    from multiprocessing.pool import ThreadPool
+
+    if O.lib().vbo_zstd_version() is None:
+        pytest.skip("no libzstd on this box")
+    rng = np.random.default_rng(606)
+    opts, oo = G.codec().options(True, 2, 1, 1), O.options(True, 2, 1, 1)
+    reads = []
+    for i in range(2700):
+        n = int(rng.integers(18000, 60000)) if i % 50 else int(rng.integers(120000, 300000))
+        a = O.synth_signal(5, 7000 + i, n).copy()
+        k = i % 7
+        if k == 1:      # flat stretches: zero runs of hundreds of control bytes between the literals
+            for _ in range(3):
+                s0 = int(rng.integers(0, n - 6000))
+                a[s0 : s0 + int(rng.integers(1500, 6000))] = a[s0]
+        elif k == 2:    # a noisy stretch: two-byte codes, no matches -- a long run of literals
+            s0 = int(rng.integers(0, n - 9000))
+            a[s0 : s0 + 8000] = rng.integers(-20000, 20000, 8000).astype(np.int16)
+        elif k == 3:    # a stretch that repeats itself
+            s0 = int(rng.integers(4000, n - 9000))
+            a[s0 : s0 + 4000] = a[s0 - 4000 : s0]
+        elif k == 4:    # steps: runs of equal control bytes that are not zero
+            a[: n // 3] = (np.arange(n // 3) * 300 % 30000).astype(np.int16)
+        reads.append(a)
+    with ThreadPool(min(16, os.cpu_count() or 1)) as pool:
+        ref = pool.map(lambda a: O.compress(a, oo), reads)
+    back = G.decompress(ref, [a.nbytes for a in reads], opts)
+    n, batched, walked = G.codec().decode_paths()
+    ahead = G.codec().decode_literals_ahead()
+    for i, (a, b) in enumerate(zip(reads, back)):
+        assert not isinstance(b, int) and b.tobytes() == a.tobytes(), i
+    forced = n == 0   # (the suite is also run with every call forced onto the large-read path: no report from there)
+    assert forced or (n == len(reads) and walked >= 2600 and 1000 <= ahead <= 2400), (n, batched, walked, ahead)

@@ -84,6 +84,7 @@ GPU_API = [
     "vbz_gpu_profile_read",
     "vbz_gpu_profile_reset",
     "vbz_gpu_decode_paths",
+    "vbz_gpu_decode_literals_ahead",
     "vbz_gpu_decode_span_paths",
     "vbz_gpu_version",
 ]
@@ -158,6 +159,8 @@ def load():
     L.vbz_gpu_profile_read.argtypes = [vp, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_double), ctypes.c_int]
     L.vbz_gpu_decode_paths.restype = ctypes.c_int
     L.vbz_gpu_decode_paths.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.vbz_gpu_decode_literals_ahead.restype = ctypes.c_int
+    L.vbz_gpu_decode_literals_ahead.argtypes = [vp]
     if hasattr(L, "vbz_gpu_decode_span_paths"):   # (tools/ab_libs.py, tools/compare_libs.py load builds of earlier rounds through VBZ_HIP_LIB)
         L.vbz_gpu_decode_span_paths.restype = ctypes.c_int
         L.vbz_gpu_decode_span_paths.argtypes = [vp, ctypes.POINTER(u32)]

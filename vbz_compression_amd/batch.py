@@ -189,6 +189,13 @@ class GpuCodec:
             raise RuntimeError("vbz_gpu_decode_paths failed")
         return n, int(b.value), int(w.value)
 
+    def decode_literals_ahead(self):
+        """walked frames of the last decompress launch group whose first block's literals were decoded beside the walk: vbz_gpu_decode_literals_ahead."""
+        n = self.L.vbz_gpu_decode_literals_ahead(self.ctx)
+        if n < 0:
+            raise RuntimeError("vbz_gpu_decode_literals_ahead failed")
+        return n
+
     def decode_span_paths(self):
         """(frames, by_spans) of the last decompress launch group on the large-read path: include/vbz_gpu.h, vbz_gpu_decode_span_paths."""
         b = ctypes.c_uint32(0)

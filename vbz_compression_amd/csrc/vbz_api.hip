@@ -1432,6 +1432,24 @@ int vbz_gpu_decode_paths(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)
     return (n0 < 0 || n1 < 0) ? -1 : n0 + n1;
 }
 
+int vbz_gpu_decode_literals_ahead(vbz_gpu_ctx* c)
+{
+    if (!c) return -1;
+    int total = 0;
+    for (vbz_gpu_ctx* k : { c, (c->last_split && c->half) ? c->half : (vbz_gpu_ctx*)nullptr }) {
+        if (!k || !k->last_frames || !k->last_walked || !zstd_ref_literals_enabled()) continue;
+        DeviceGuard guard(k->device);
+        std::vector<RefLits> lits(k->last_frames);
+        if (hipMemcpyAsync(lits.data(), zstd_ref_lits(k->fastmeta.p, k->last_frames), sizeof(RefLits) * lits.size(), hipMemcpyDeviceToHost, k->stream) != hipSuccess ||
+            hipStreamSynchronize(k->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            return -1;
+        }
+        for (const RefLits& l : lits) total += l.blk != 0;
+    }
+    return total;
+}
+
 static int decode_paths_one(vbz_gpu_ctx* c, uint32_t* batched, uint32_t* walked)
 {
     DeviceGuard guard(c->device);

@@ -185,12 +185,14 @@ struct RefPre
 struct RefLits
 {
     uint32_t blk, regen, csize, at;
+    uint32_t tb, pcap, pad[2];   // the literals stand in 64 stripes of pcap bytes from offset tb of the slot; lits_pos[64 r + q]: the first literal of stripe q
 };
 struct RefChains  // what launch_zstd_decode_only needs of them (pre == nullptr: none)
 {
     const RefPre* pre = nullptr;
     const void* recs = nullptr;
     const RefLits* lits = nullptr;   // (nullable; only looked at for frames whose chains are walked)
+    const uint32_t* lits_pos = nullptr;
 };
 
 size_t zstd_ref_pre_bytes(uint32_t n_reads);
@@ -209,6 +211,8 @@ hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, c
 // ref_*: scratch of launch_zstd_ref_chain (ref_pre == nullptr: frames of other writers go to the one-wavefront decoder as they are).
 // dbg (nullable): phase cycle counters of the one-wavefront decoder, which then decodes EVERY frame (walked chains included).
 size_t zstd_fast_meta_bytes(uint32_t n_reads);
+const RefLits* zstd_ref_lits(const void* meta, uint32_t n_reads);   // (diagnostics: blk != 0 = the frame's literals were decoded ahead)
+bool zstd_ref_literals_enabled();                                   // VBZ_HIP_REF_LITERALS
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads);  // after the call: redo[i] == 0 <=> frame i was decoded by the batched decoder
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
                                    void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, FastSide side, hipStream_t s);

@@ -1187,9 +1187,14 @@ __device__ __forceinline__ void wave_copy_repeat(gu8* o, uint32_t off, uint32_t 
 }
 
 // 16 bytes of the period-`off` pattern that starts at f (off = 1, 2, 4, 8 or 16; f[0 .. 15] must be readable)
+__device__ __forceinline__ u32x4 period_expand(u32x4 v, uint32_t off);
 __device__ __forceinline__ u32x4 period_pattern(gcu8* f, uint32_t off)
 {
-    u32x4 v = *(gld16*)f;
+    return period_expand(*(gld16*)f, off);
+}
+// ... from its first `off` bytes in v
+__device__ __forceinline__ u32x4 period_expand(u32x4 v, uint32_t off)
+{
     if (off == 1) v.x = (v.x & 0xFFu) * 0x01010101u;
     if (off == 2) v.x = (v.x & 0xFFFFu) * 0x00010001u;
     if (off <= 4) v.y = v.x;
@@ -1852,7 +1857,15 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
 #define SQB(i) ((uint32_t)(sq8 >> (8 * (i))) & 0xFFu)
             wave_lds_sync();
             PHASE(6);
-            if (ltype == 2) {
+            // a walked frame's literals may stand already (ref_pieces_kernel, beside the walk): the same block and sizes here, the same
+            // place further down.  Then nobody needs this block's table unless a later block is coded under it: the last block's is not built.
+            bool lits_cand = false;
+            RefLits rl = { 0u, 0u, 0u, 0u };
+            if (use_pre && chains.lits != nullptr && ltype == 2 && streams == 4) {
+                rl = chains.lits[r];
+                lits_cand = uni((rl.blk != 0 && rl.blk == pos - 3 && rl.regen == regen && rl.csize == csize) ? 1u : 0u) != 0;
+            }
+            if (ltype == 2 && !(lits_cand && last)) {
                 PHASE(0);
                 // tree description: at most 129 bytes; the weights are decoded by wave-uniform code, the wave fills the table
                 const uint32_t tn = csize < 160 ? csize : 160;
@@ -1958,11 +1971,10 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             }
             const uint32_t lit_dst = !has_seq ? opos : (defer ? ws_lit : (par ? ws_plit : fcs - regen));
             const uint8_t* lit_src = blk + lh;  // raw literals are read in place
-            // a walked frame's literals may stand already (ref_pieces_kernel, beside the walk): the same block, sizes and place
-            bool lits_ahead = false;
-            if (use_pre && chains.lits != nullptr && ltype == 2 && streams == 4) {
-                const RefLits rl = chains.lits[r];
-                lits_ahead = uni((rl.blk != 0 && rl.blk == pos - 3 && rl.regen == regen && rl.csize == csize && rl.at == lit_dst) ? 1u : 0u) != 0;
+            const bool lits_ahead = lits_cand && uni(rl.at == lit_dst ? 1u : 0u) != 0;
+            if (lits_cand && !lits_ahead) {   // (not where this decoder wants them: the frame again, without hand-overs)
+                restart = true;
+                break;
             }
             if (ltype >= 2 && !lits_ahead) {
                 const uint8_t* q = blk + lh + tree_used;
@@ -2198,6 +2210,71 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 }
                 PHASE(9);
                 const uint8_t* litp = ltype == 0 ? lit_src : dst + lit_dst;
+                // Literals that were decoded ahead stand in 64 stripes (ref_pieces_kernel; RefLits): stripe q holds the literals
+                // [P[q], P[q + 1]) at sbase + q * pcap and, behind them, the next stripe's first 256 (= LANE_COPY_MAX): whatever a LANE
+                // reads -- a run of up to 256 literals, the source of a match inside it -- it reads in one piece from where the run
+                // begins (lit_at); only what the whole wavefront moves (longer runs) goes stripe by stripe (lits_wave).
+                const bool striped = lits_ahead;
+                const uint8_t* const sbase = dst + rl.tb;
+                const uint32_t spcap = rl.pcap;
+                // P: lane q holds P[q].  Where a literal stands is a ballot (how many stripes begin at or before it), no table in LDS:
+                const uint32_t Pv = striped ? chains.lits_pos[(size_t)r * WAVE + lane] : 0u;
+                auto lit_seg = [&](uint32_t idx, uint32_t& room) -> const uint8_t* {   // idx UNIFORM; room: literals of its stripe from it on
+                    if (!striped) {
+                        room = 0xFFFFFFFFu;
+                        return litp + idx;
+                    }
+                    const uint32_t q = (uint32_t)__popcll(__ballot(Pv <= idx)) - 1u;   // (P[0] = 0)
+                    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)Pv, (int)q);
+                    const uint32_t p1 = q < 63u ? (uint32_t)__builtin_amdgcn_readlane((int)Pv, (int)(q + 1u)) : regen;
+                    room = p1 - idx;
+                    return sbase + q * spcap + (idx - p0);
+                };
+                // all lanes (uniform arguments): n literals from idx on to o.  Out of stripes: four stripes' loads are in flight before their
+                // stores -- the literals behind a block's last sequence are most of what a read's data bytes are, tens of kilobytes that
+                // cross dozens of stripes; a stripe at a time (load, wait, store) this copy alone took longer than all the sequences.
+                auto lits_wave = [&](gu8* o, uint32_t idx, uint32_t n) {
+                    if (!striped) {
+                        wave_copy(o, (gcu8*)(litp + idx), n, lane);
+                        return;
+                    }
+                    constexpr int GW = 4;
+                    const uint32_t k0 = 16u * (uint32_t)lane;
+                    while (n) {
+                        gcu8* f[GW];
+                        gu8* d[GW];
+                        uint32_t c[GW];
+#pragma unroll
+                        for (int u = 0; u < GW; ++u) {
+                            uint32_t room = 0;
+                            f[u] = (gcu8*)lit_seg(idx < regen ? idx : 0u, room);
+                            c[u] = n < room ? n : room;
+                            d[u] = o;
+                            o += c[u];
+                            idx += c[u];
+                            n -= c[u];
+                        }
+                        u32x4 v[GW][2];
+                        uint32_t tb_[GW];
+#pragma unroll
+                        for (int u = 0; u < GW; ++u) {
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch)
+                                if (k0 + 1024u * ch + 16u <= c[u]) v[u][ch] = *(gld16*)(f[u] + k0 + 1024u * ch);
+                            const uint32_t rb = c[u] & 15u;
+                            tb_[u] = (uint32_t)lane < rb ? f[u][c[u] - rb + (uint32_t)lane] : 0u;
+                        }
+#pragma unroll
+                        for (int u = 0; u < GW; ++u) {
+#pragma unroll
+                            for (int ch = 0; ch < 2; ++ch)
+                                if (k0 + 1024u * ch + 16u <= c[u]) *(gst16*)(d[u] + k0 + 1024u * ch) = v[u][ch];
+                            const uint32_t rb = c[u] & 15u;
+                            if ((uint32_t)lane < rb) d[u][c[u] - rb + (uint32_t)lane] = (uint8_t)tb_[u];
+                            for (uint32_t k = k0 + 2048u; k + 16u <= c[u]; k += 1024u) *(gst16*)(d[u] + k) = *(gld16*)(f[u] + k);   // (a stripe of more than 2 KB)
+                        }
+                    }
+                };
                 const uint8_t rle_byte = ltype == 1 ? lit_src[0] : 0;
                 const uint8_t* bs = sq + sq_used;
                 const uint32_t bsn = sqn - sq_used;
@@ -2244,25 +2321,79 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     PHASE(10);
                     // ---- (B) all literals at once: positions from prefix sums, 64 sequences per trip
                     {
+                        // With them go the matches that repeat the sequence's OWN literals (offset <= literal length) without
+                        // overlapping themselves, or as a pattern of 1, 2, 4, 8 or 16 bytes -- the zero runs of the control bytes
+                        // are all of that kind: their source is read from the literal buffer, so they depend on nothing that is
+                        // written here and need no round of (C) (SEQ_OWN: the same predicate takes them out of (C)'s lists).
+#define SEQ_OWN(sv) (ltype != 1 && (sv).y != 0 && (sv).z <= (sv).x && ((sv).z >= (sv).y || (sv).z == 1 || (sv).z == 2 || (sv).z == 4 || (sv).z == 8 || (sv).z == 16))
                         uint32_t lposw = 0, oposw = opos;
+                        uint4 svn = (uint32_t)lane < nseq ? seqbuf[lane] : make_uint4(0u, 0u, 0u, 0u);
                         for (uint32_t base = 0; base < nseq; base += WAVE) {
                             const uint32_t i = base + (uint32_t)lane;
-                            const uint4 sv = i < nseq ? seqbuf[i] : make_uint4(0u, 0u, 0u, 0u);
+                            const uint4 sv = svn;
+                            svn = i + WAVE < nseq ? seqbuf[i + WAVE] : make_uint4(0u, 0u, 0u, 0u);   // (the next trip's, under this trip's copies)
                             const uint32_t ll = sv.x, tot = sv.x + sv.y;
                             const uint32_t il = wave_incl_scan_u32(ll), it = wave_incl_scan_u32(tot);
                             const uint32_t lp = lposw + il - ll;
                             uint8_t* o = dst + oposw + it - tot;
                             const bool big = ll > LANE_COPY_MAX;  // long runs are moved by the whole wave
+                            const bool own = i < nseq && SEQ_OWN(sv);
+                            const bool ownpat = own && sv.z < sv.y;
+                            const bool ownbig = own && sv.y > LANE_COPY_MAX;
+                            u32x4 pv = {};
+                            // (where this lane's run stands; the source of an own match of a run of up to 256 literals lies inside the run)
+                            // where this lane's run stands: the trip's runs are consecutive literals, so they begin in the stripe of the
+                            // trip's first literal or in one of the next few -- one pass over those stripes' first indices
+                            const uint8_t* lf = litp + lp;
+                            if (striped) {
+                                const uint32_t lpend = lposw + (uint32_t)__builtin_amdgcn_readlane((int)il, 63);
+                                uint32_t q0 = (uint32_t)__popcll(__ballot(Pv <= lposw)) - 1u;
+                                uint32_t q = q0, p0 = (uint32_t)__builtin_amdgcn_readlane((int)Pv, (int)q0);
+                                for (uint32_t bq = q0 + 1u; bq < (uint32_t)WAVE; ++bq) {
+                                    const uint32_t pb = (uint32_t)__builtin_amdgcn_readlane((int)Pv, (int)bq);
+                                    if (pb >= lpend) break;
+                                    const bool in = lp >= pb;
+                                    q = in ? bq : q;
+                                    p0 = in ? pb : p0;
+                                }
+                                lf = sbase + q * spcap + (lp - p0);
+                                // (a long run is moved by the wavefront, stripe by stripe; the source of its own match is looked up by itself)
+                                for (uint64_t bo = __ballot(big && own); bo; bo &= bo - 1) {
+                                    const int bl = __ffsll((long long)bo) - 1;
+                                    uint32_t room;
+                                    const uint8_t* f = lit_seg((uint32_t)__builtin_amdgcn_readlane((int)(lp + ll - sv.z), bl), room);
+                                    if (lane == bl) lf = f - (ll - sv.z);
+                                }
+                            }
+                            if (ownpat) pv = period_pattern((gcu8*)(lf + ll - sv.z), sv.z);
                             if (ltype == 1) {
                                 for (uint32_t k = 0; k < ll; ++k) o[k] = rle_byte;
                             } else if (!big) {
-                                lane_copy((gu8*)o, (gcu8*)(litp + lp), ll);
+                                lane_copy((gu8*)o, (gcu8*)lf, ll);
+                            }
+                            if (own && !ownbig) {
+                                if (ownpat) lane_fill((gu8*)o + ll, pv, sv.y);
+                                else lane_copy((gu8*)o + ll, (gcu8*)(lf + ll - sv.z), sv.y);
                             }
                             for (uint64_t bigs = ltype == 1 ? 0ull : __ballot(big); bigs; bigs &= bigs - 1) {
                                 const int bl = __ffsll((long long)bigs) - 1;
                                 const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)(oposw + it - tot), bl);
                                 const uint32_t bf = (uint32_t)__builtin_amdgcn_readlane((int)lp, bl);
-                                wave_copy((gu8*)dst + bo, (gcu8*)litp + bf, (uint32_t)__builtin_amdgcn_readlane((int)ll, bl), lane);
+                                lits_wave((gu8*)dst + bo, bf, (uint32_t)__builtin_amdgcn_readlane((int)ll, bl));
+                            }
+                            for (uint64_t bigs = __ballot(ownbig); bigs; bigs &= bigs - 1) {
+                                const int bl = __ffsll((long long)bigs) - 1;
+                                const uint32_t bo = (uint32_t)__builtin_amdgcn_readlane((int)(oposw + it - sv.y), bl), bn = (uint32_t)__builtin_amdgcn_readlane((int)sv.y, bl);
+                                if (__builtin_amdgcn_readlane((int)ownpat, bl)) {
+                                    u32x4 bv;
+                                    bv.x = (uint32_t)__builtin_amdgcn_readlane((int)pv.x, bl);
+                                    bv.y = (uint32_t)__builtin_amdgcn_readlane((int)pv.y, bl);
+                                    bv.z = (uint32_t)__builtin_amdgcn_readlane((int)pv.z, bl);
+                                    bv.w = (uint32_t)__builtin_amdgcn_readlane((int)pv.w, bl);
+                                    wave_fill((gu8*)dst + bo, bv, bn, lane);
+                                } else {
+                                    lits_wave((gu8*)dst + bo, (uint32_t)__builtin_amdgcn_readlane((int)(lp + ll - sv.z), bl), bn);
+                                }
                             }
                             lposw += (uint32_t)__builtin_amdgcn_readlane((int)il, 63);
                             oposw += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
@@ -2273,7 +2404,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if (ltype == 1) {
                             for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
                         } else {
-                            wave_copy((gu8*)dst + oposw, (gcu8*)litp + lposw, rest, lane);
+                            lits_wave((gu8*)dst + oposw, lposw, rest);
                         }
                         lpos = regen;
                         __syncthreads();
@@ -2282,14 +2413,16 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         // below the first not yet copied match of the trip is final and its source ends below that
                         // point; the first one is always ready (a lane copies byte by byte, so it may overlap itself)
                         uint32_t ow = opos;
+                        uint4 svm = (uint32_t)lane < nseq ? seqbuf[lane] : make_uint4(0u, 0u, 0u, 0u);
                         for (uint32_t base = 0; base < nseq; base += WAVE) {
                             const uint32_t i = base + (uint32_t)lane;
-                            const uint4 sv = i < nseq ? seqbuf[i] : make_uint4(0u, 0u, 0u, 0u);
+                            const uint4 sv = svm;
+                            svm = i + WAVE < nseq ? seqbuf[i + WAVE] : make_uint4(0u, 0u, 0u, 0u);
                             const uint32_t tot = sv.x + sv.y;
                             const uint32_t it = wave_incl_scan_u32(tot);
                             const uint32_t mdst = ow + it - sv.y;  // where this lane's match goes
                             const uint32_t msrc = mdst - sv.z;
-                            uint64_t todo = __ballot(i < nseq && sv.y != 0);
+                            uint64_t todo = __ballot(i < nseq && sv.y != 0 && !SEQ_OWN(sv));
                             while (todo) {
                                 const int f = __ffsll((long long)todo) - 1;
                                 const uint32_t frontier = (uint32_t)__builtin_amdgcn_readlane((int)mdst, f);
@@ -2333,6 +2466,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                             ow += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
                         }
                         opos = ow + rest;
+#undef SEQ_OWN
                     }
                     if (opos - block_start > BLOCK_MAX || opos - block_start > block_max) FAIL();
                     __syncthreads();

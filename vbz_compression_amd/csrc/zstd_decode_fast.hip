@@ -759,17 +759,18 @@ __global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const F
 //           part of the destination slot, behind where the block's literals belong;
 //   check   a piece's end must be the next one's presumed start, the last one's the first bit of the stream, and the counts must add
 //           up to the stream's regenerated size;
-//   move    then the counts place every piece, and the bytes are moved (a copy through the caches, a thirtieth of a walk).
+//   hand-over  the counts say which literals a stripe holds; zstd_decode_kernel reads them where they stand.
 // Nothing is repaired and no verdict is given here: a frame for which anything fails is left as it was -- the one-wavefront decoder
 // decodes its streams itself and is the one to say what is wrong with it.
 constexpr uint32_t REF_TASKS = 4;
 constexpr uint32_t REF_PIECES_LOG = 4, REF_PIECES = 1u << REF_PIECES_LOG;
 constexpr uint32_t REF_RUNUP = 768;                          // bits
-constexpr uint32_t REF_MIN_STREAM = 64u * REF_PIECES;        // bytes: shorter streams are not worth it
-#ifndef VBZ_REF_MOVE_G
-#define VBZ_REF_MOVE_G 8
+constexpr uint32_t REF_HALO = 256;                           // literals of the next stripe repeated behind a stripe (= zstd_decode.hip's LANE_COPY_MAX)
+constexpr uint32_t REF_MIN_STREAM = 384u * REF_PIECES;       // bytes: a piece of 384 bytes holds at least 256 symbols of up to 11 bits + the run-up's share
+#ifndef VBZ_REF_RING
+#define VBZ_REF_RING 32
+#define VBZ_REF_BATCH 16
 #endif
-constexpr int MOVE_G = VBZ_REF_MOVE_G;                       // pieces moved together
 static_assert(REF_TASKS * REF_PIECES == (uint32_t)WAVE, "one lane per piece");
 
 // one lane per frame with only[r] != 0: is it of the shape, where are the tree and the four streams (skip[r] = 0 if so)
@@ -846,13 +847,21 @@ __global__ __launch_bounds__(256) void ref_lit_scan_kernel(ReadBatch b, const ui
 
 // one wavefront per frame that the scan and the weights kernel have passed: the table, the 64 pieces, the check, the move
 __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const FastFrame* frames, const FastTask* tasks, const uint8_t* weights,
-                                                            const uint32_t* skip, RefLits* lits)
+                                                            const uint32_t* skip, RefLits* lits, uint32_t* pos)
 {
+    // (The ring's size is this kernel's own.  It runs beside ref_chain_kernel, whose wavefront holds 60 KB of a CU's LDS: eight of these fit
+    // beside it, twelve would with 16 dwords a lane -- but a 16-dword ring in requests of 16 bytes has no slack for the dword that is
+    // requested a pair ahead (w2): measured, 5 % of the frames came out with wrong symbols of the RIGHT lengths, which no check of positions
+    // and counts can see.  Hence the two dwords of margin in the assertion, and 32 / 16, fast_streams_kernel's proven pair.)
+    constexpr int RING = VBZ_REF_RING, BATCH = VBZ_REF_BATCH, PERIOD = 16;
+    constexpr unsigned long long LINE = 4ull * BATCH;
+    static_assert((RING & (RING - 1)) == 0 && RING - BATCH + 1 - (PERIOD * 11 + 31) / 32 >= (PERIOD * 11 + 31) / 32 + 2, "the ring would run dry");
+    static_assert(BURST % PERIOD == 0 && BATCH % 4 == 0, "burst = whole periods");
     __shared__ __attribute__((aligned(16))) uint16_t T[TBL_BIG];
     __shared__ uint32_t ringbuf[RING + 1][WAVE];
     const int lane = threadIdx.x;
     const uint32_t r = blockIdx.x;
-    RefLits res = { 0u, 0u, 0u, 0u };
+    RefLits res = {};
 #define LEAVE()                           \
     do {                                  \
         if (lane == 0) lits[r] = res;     \
@@ -1056,47 +1065,31 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     if (r == 0) printf("lane %2d st %u j %2u pad %u B %u seg %u c_lo %u c_hi %u from %u off %d s_bit %u e_bit %u e_prev %u m %u cnt %u total %u holds %d spill %d pcap %u\n", lane, st, j, pad, B, seg, c_lo, c_hi, from, off, s_bit, e_bit, e_prev, m, cnt, total, (int)holds, (int)spill, pcap);
 #endif
     if (__any(!holds || total != cnt)) LEAVE();
+    // The stripes stay where they are: the decoder reads the literals out of them (RefLits: tb, pcap; pos[]: the index of every piece's first
+    // literal) -- moving them to one place first cost 0.54 of this kernel's 2.1 ms per 16 384 frames and 3 GB of traffic under the walks.
+    // What is moved is a HALO: behind its last literal a stripe gets the next stripe's first REF_HALO, so that a run of up to REF_HALO
+    // literals that begins in a stripe is read in one piece from it (the decoder's lanes place runs of up to 256 bytes each; a run that
+    // had to be fetched in two parts cost every lane of the wavefront a second memory round trip, trip after trip).
+    if (__any(m < REF_HALO || m + REF_HALO > pcap)) LEAVE();
     __syncthreads();   // (the stripes are in memory)
-    // ---- the move: piece after piece by the whole wavefront (a lane moving its own piece is 64 requests an instruction; this way an
-    // instruction is a kilobyte of whole lines), eight pieces' loads in flight before their stores
-    {
+    if (lane != WAVE - 1) {
         typedef __attribute__((address_space(1), aligned(16))) const u32x4 gl4;
-        typedef __attribute__((address_space(1), aligned(1))) u32x4 gst4;
-        const uint32_t dpos = tk.out + (incl - m - before);
-        const uint32_t k0 = 16u * (uint32_t)lane;
-        for (int g = 0; g < WAVE; g += MOVE_G) {
-            u32x4 v[MOVE_G][3];
-            uint32_t tailb[MOVE_G];
+        typedef __attribute__((address_space(1), aligned(1))) u32x4 gh4;
+        gcu8* f = (gcu8*)(tb + (uint64_t)(lane + 1) * pcap);
+        gu8* h = (gu8*)(tb + (uint64_t)lane * pcap) + m;
+        u32x4 v[REF_HALO / 16];
 #pragma unroll
-            for (int u = 0; u < MOVE_G; ++u) {
-                const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)m, g + u);
-                gcu8* f = (gcu8*)(tb + (uint64_t)(g + u) * pcap);
+        for (int k = 0; k < (int)(REF_HALO / 16); ++k) v[k] = *(gl4*)(f + 16 * k);
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (k0 + 1024u * c + 16u <= mq) v[u][c] = *(gl4*)(f + k0 + 1024u * c);
-                const uint32_t rb = mq & 15u;
-                tailb[u] = (uint32_t)lane < rb ? f[mq - rb + (uint32_t)lane] : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < MOVE_G; ++u) {
-                const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)m, g + u);
-                gu8* d = (gu8*)dst + (uint32_t)__builtin_amdgcn_readlane((int)dpos, g + u);
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (k0 + 1024u * c + 16u <= mq) *(gst4*)(d + k0 + 1024u * c) = v[u][c];
-                const uint32_t rb = mq & 15u;
-                if ((uint32_t)lane < rb) d[mq - rb + (uint32_t)lane] = (uint8_t)tailb[u];
-                if (mq > 3072u + 16u) {   // (a stripe of more than 3 KB: only where the slot is far larger than the frame)
-                    gcu8* f = (gcu8*)(tb + (uint64_t)(g + u) * pcap);
-                    for (uint32_t k = k0 + 3072u; k + 16u <= mq; k += 1024u) *(gst4*)(d + k) = *(gl4*)(f + k);
-                }
-            }
-        }
+        for (int k = 0; k < (int)(REF_HALO / 16); ++k) *(gh4*)(h + 16 * k) = v[k];
     }
+    pos[(size_t)r * WAVE + lane] = tk.out - F->ws_lit + (incl - m - before);
     res.blk = F->pad[0];
     res.regen = regen;
     res.csize = F->pad[1];
     res.at = F->ws_lit;
+    res.tb = (uint32_t)(tb - (uint64_t)dst);
+    res.pcap = pcap;
     LEAVE();
 #undef LEAVE
 }
@@ -1141,7 +1134,7 @@ static int ref_lits_ahead()
 {
     static const int on = [] {
         const char* e = getenv("VBZ_HIP_REF_LITERALS");
-        return e ? atoi(e) : 1;   // (3: behind the walk instead of beside it -- measurements)
+        return e ? atoi(e) : 1;
     }();
     return on;
 }
@@ -1149,40 +1142,76 @@ static int ref_lits_ahead()
 size_t zstd_fast_meta_bytes(uint32_t n_reads)
 {
     return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4 + 4) + 1024 +
-           (size_t)n_reads * (sizeof(FastFrame) + REF_TASKS * sizeof(FastTask) + 512 + 4 + sizeof(RefLits)) + 1024;   // (... of the reference's frames)
+           (size_t)n_reads * (sizeof(FastFrame) + REF_TASKS * sizeof(FastTask) + 512 + 4 + sizeof(RefLits) + 4 * WAVE) + 2048;   // (... of the reference's frames)
 }
 
-const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads)
+// what the batched decoder keeps per read in the call's scratch (zstd_fast_meta_bytes)
+struct FastMeta
 {
-    return reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(meta) + (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512));
+    FastFrame* frames;
+    FastTask* tasks;
+    uint8_t* weights;
+    uint32_t* redo;
+    uint32_t* scanned;   // redo[] as the scan left it: what the chain walk goes by
+    FastFrame* rframes;  // the literals of the reference's frames (ref_pieces_kernel): frames, streams, weights, hand-overs, stripes' first literals
+    FastTask* rtasks;
+    uint8_t* rweights;
+    RefLits* rlits;
+    uint32_t* rskip;
+    uint32_t* rpos;
+};
+static FastMeta fast_meta(void* meta, uint32_t n)
+{
+    FastMeta M;
+    uint8_t* m = reinterpret_cast<uint8_t*>(meta);
+    M.frames = reinterpret_cast<FastFrame*>(m);
+    m += (size_t)n * sizeof(FastFrame);
+    M.tasks = reinterpret_cast<FastTask*>(m);
+    m += (size_t)n * FAST_TASKS * sizeof(FastTask);
+    M.weights = m;
+    m += (size_t)n * 512;
+    M.redo = reinterpret_cast<uint32_t*>(m);
+    m += (size_t)n * 4;
+    M.scanned = reinterpret_cast<uint32_t*>(m);
+    m += (size_t)n * 4;
+    m += (256 - (reinterpret_cast<uintptr_t>(m) & 255)) & 255;
+    M.rframes = reinterpret_cast<FastFrame*>(m);
+    m += (size_t)n * sizeof(FastFrame);
+    M.rtasks = reinterpret_cast<FastTask*>(m);
+    m += (size_t)n * REF_TASKS * sizeof(FastTask);
+    M.rweights = m;
+    m += (size_t)n * 512;
+    M.rlits = reinterpret_cast<RefLits*>(m);
+    m += (size_t)n * sizeof(RefLits);
+    M.rskip = reinterpret_cast<uint32_t*>(m);
+    m += (size_t)n * 4;
+    m += (256 - (reinterpret_cast<uintptr_t>(m) & 255)) & 255;
+    M.rpos = reinterpret_cast<uint32_t*>(m);
+    return M;
 }
+
+const RefLits* zstd_ref_lits(const void* meta, uint32_t n_reads) { return fast_meta(const_cast<void*>(meta), n_reads).rlits; }
+bool zstd_ref_literals_enabled() { return ref_lits_ahead() != 0; }
+
+const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads) { return fast_meta(const_cast<void*>(meta), n_reads).redo; }
 
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
                                    void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, FastSide side, hipStream_t s)
 {
     const uint32_t n = b.n_reads;
     if (n == 0) return hipSuccess;
-    uint8_t* m = reinterpret_cast<uint8_t*>(meta);
-    FastFrame* frames = reinterpret_cast<FastFrame*>(m);
-    m += (size_t)n * sizeof(FastFrame);
-    FastTask* tasks = reinterpret_cast<FastTask*>(m);
-    m += (size_t)n * FAST_TASKS * sizeof(FastTask);
-    uint8_t* weights = m;
-    m += (size_t)n * 512;
-    uint32_t* redo = reinterpret_cast<uint32_t*>(m);
-    m += (size_t)n * 4;
-    uint32_t* scanned = reinterpret_cast<uint32_t*>(m);  // redo[] as the scan left it: what the chain walk goes by
-    m += (size_t)n * 4;
-    m += (256 - (reinterpret_cast<uintptr_t>(m) & 255)) & 255;
-    FastFrame* rframes = reinterpret_cast<FastFrame*>(m);   // the literals of the reference's frames (ref_pieces_kernel)
-    m += (size_t)n * sizeof(FastFrame);
-    FastTask* rtasks = reinterpret_cast<FastTask*>(m);
-    m += (size_t)n * REF_TASKS * sizeof(FastTask);
-    uint8_t* rweights = m;
-    m += (size_t)n * 512;
-    RefLits* rlits = reinterpret_cast<RefLits*>(m);
-    m += (size_t)n * sizeof(RefLits);
-    uint32_t* rskip = reinterpret_cast<uint32_t*>(m);
+    const FastMeta M = fast_meta(meta, n);
+    FastFrame* const frames = M.frames;
+    FastTask* const tasks = M.tasks;
+    uint8_t* const weights = M.weights;
+    uint32_t* const redo = M.redo;
+    uint32_t* const scanned = M.scanned;
+    FastFrame* const rframes = M.rframes;
+    FastTask* const rtasks = M.rtasks;
+    uint8_t* const rweights = M.rweights;
+    RefLits* const rlits = M.rlits;
+    uint32_t* const rskip = M.rskip;
+    uint32_t* const rpos = M.rpos;
     hipError_t e = hipSuccess;
     if (dbg) {  // phase timing: every frame to the one-wavefront decoder
         e = hipMemsetAsync(redo, 1, 4ull * n, s);
@@ -1204,12 +1233,10 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
             if (e != hipSuccess) return e;
             e = hipStreamWaitEvent(side.stream, side.fork, 0);
             if (e != hipSuccess) return e;
+            e = hipEventRecord(side.join, side.stream);   // "the second stream has come as far as the walk's launch": see below
         }
-        e = launch_zstd_ref_chain(b, scanned, ref_pre, ref_tables, ref_recs, ref_recs_cap, &chains, beside ? side.stream : s);
-        if (beside) {
-            const hipError_t e1 = hipEventRecord(side.join, side.stream);
-            if (e == hipSuccess) e = e1;
-        }
+        const hipError_t e1 = launch_zstd_ref_chain(b, scanned, ref_pre, ref_tables, ref_recs, ref_recs_cap, &chains, beside ? side.stream : s);
+        if (e == hipSuccess) e = e1;
     }
     if (!dbg && e == hipSuccess) {
         hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo);
@@ -1217,21 +1244,26 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
         hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
         e = hipGetLastError();
     }
-    if (beside && ref_lits_ahead() == 3) {
-        const hipError_t e1 = hipStreamWaitEvent(s, side.join, 0);
-        if (e == hipSuccess) e = e1;
-    }
     // the literals of the frames being walked, meanwhile
     if (ref_pre && ref_lits_ahead() && e == hipSuccess) {
         hipLaunchKernelGGL(ref_lit_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, scanned, rframes, rtasks, rskip);
         hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, rframes, rweights, rskip);
-        hipLaunchKernelGGL(ref_pieces_kernel, dim3(n), dim3(WAVE), 0, s, b, rframes, rtasks, rweights, rskip, rlits);
+        // The pieces' 16 384 wavefronts must not be on the device before the walk's 256: a walk wavefront holds 60 KB of LDS and finds no CU
+        // with that much free once twelve of these sit on each -- it then starts a round of pieces late, and the call ends 0.8 ms later
+        // (measured: calls of 4.6 and of 5.4 ms, by which queue was served first).  So this stream waits until the other has reached the walk.
+        if (beside) {
+            const hipError_t e1 = hipStreamWaitEvent(s, side.join, 0);
+            if (e == hipSuccess) e = e1;
+        }
+        hipLaunchKernelGGL(ref_pieces_kernel, dim3(n), dim3(WAVE), 0, s, b, rframes, rtasks, rweights, rskip, rlits, rpos);
+        chains.lits_pos = rpos;
         e = hipGetLastError();
         chains.lits = rlits;
     }
-    if (beside) {
-        const hipError_t e1 = hipStreamWaitEvent(s, side.join, 0);
-        if (e == hipSuccess) e = e1;
+    if (beside) {   // (the join proper: the event again, now behind the walk)
+        const hipError_t e1 = hipEventRecord(side.join, side.stream);
+        const hipError_t e2 = hipStreamWaitEvent(s, side.join, 0);
+        if (e == hipSuccess) e = e1 != hipSuccess ? e1 : e2;
     }
     if (e != hipSuccess) return e;
     return launch_zstd_decode_only(b, toosmall_code, seq_dtables, redo, chains, dbg, s);  // whatever is not of the shape, and every error verdict
