@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--writer", choices=["device", "reference"], default="device",
+                    help="reference: the frames are libzstd's (the oracle's compressor, levels 1 and 3), int16 reads long enough for the chain walk and the "
+                         "literals beside it -- run with VBZ_HIP_REF_CHAINS=2, which walks in calls of any size")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
@@ -69,12 +72,16 @@ def main():
             lens = [int(x) for x in rng.integers(300000, 900000, 2)]
         else:
             lens = [int(x) for x in rng.choice([0, 5, 64, 257, 4097, 20000, 100003], 6)] + [int(x) for x in rng.integers(0, 120000, 2)]
-        bufs = [soak.make_read(rng, dt, int(rng.integers(0, 7)), n) for n in lens]
+        if args.writer == "reference":
+            size, dt, sized = 2, np.int16, bool(rng.integers(0, 2))
+            level = int(rng.choice([1, 1, 3]))
+            lens = [int(x) for x in rng.integers(25000, 160000, 6)] + [int(x) for x in rng.integers(0, 30000, 2)]
+        bufs = [soak.make_read(rng, dt, int(rng.choice([0, 0, 0, 5, 6, 3])) if args.writer == "reference" else int(rng.integers(0, 7)), n) for n in lens]
         if args.verbose:
             print("round %d: %s zz %d level %d sized %d lens %s" % (rounds, np.dtype(dt).name, zz, level, sized, lens), flush=True)
         go = G.codec().options(zz, size, level, 0)
         oo = O.options(zz, size, level, 0)
-        frames = G.compress(bufs, go, sized=sized)
+        frames = [O.compress(b, oo, sized=sized) for b in bufs] if args.writer == "reference" else G.compress(bufs, go, sized=sized)
         bad, want = [], []
         for b, f in zip(bufs, frames):
             if isinstance(f, int):

@@ -34,6 +34,9 @@ constexpr int HBUF = 768;
 #endif
 #define VBZ_DEC_RING_DECL VBZ_DEC_RING
 // experiment knobs (defaults are the full decoder): entries per Huffman table slot, entries per FSE table
+#ifndef VBZ_DEC_LITS_GW
+#define VBZ_DEC_LITS_GW 4   // stripes whose loads are in flight together when the wavefront moves literals out of stripes
+#endif
 #ifndef VBZ_DEC_HUF_SLOT
 #define VBZ_DEC_HUF_SLOT 2048
 #endif
@@ -2238,7 +2241,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         wave_copy(o, (gcu8*)(litp + idx), n, lane);
                         return;
                     }
-                    constexpr int GW = 4;
+                    constexpr int GW = VBZ_DEC_LITS_GW;
                     const uint32_t k0 = 16u * (uint32_t)lane;
                     while (n) {
                         gcu8* f[GW];
@@ -2398,6 +2401,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                             lposw += (uint32_t)__builtin_amdgcn_readlane((int)il, 63);
                             oposw += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
                         }
+                        PHASE(2);   // (the trips; the literals behind the last sequence are slot 11)
                         // literals behind the last sequence
                         const uint32_t rest = regen - lposw;
                         if ((uint64_t)oposw + rest > fcs) FAIL();
