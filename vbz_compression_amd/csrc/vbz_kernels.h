@@ -185,7 +185,9 @@ struct RefPre
 struct RefLits
 {
     uint32_t blk, regen, csize, at;
-    uint32_t tb, pcap, pad[2];   // the literals stand in 64 stripes of pcap bytes from offset tb of the slot; lits_pos[64 r + q]: the first literal of stripe q
+    uint32_t tb, pcap;           // the literals stand in 64 stripes of pcap bytes from offset tb of the slot; lits_pos[64 r + q]: the first literal of stripe q
+    uint32_t tail, pad;          // tail: the block is the frame's last and literal x also stands at fcs - regen + x of the slot -- where the literals
+                                 // behind the last sequence belong
 };
 struct RefChains  // what launch_zstd_decode_only needs of them (pre == nullptr: none)
 {

@@ -1863,7 +1863,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             // a walked frame's literals may stand already (ref_pieces_kernel, beside the walk): the same block and sizes here, the same
             // place further down.  Then nobody needs this block's table unless a later block is coded under it: the last block's is not built.
             bool lits_cand = false;
-            RefLits rl = { 0u, 0u, 0u, 0u };
+            RefLits rl = {};
             if (use_pre && chains.lits != nullptr && ltype == 2 && streams == 4) {
                 rl = chains.lits[r];
                 lits_cand = uni((rl.blk != 0 && rl.blk == pos - 3 && rl.regen == regen && rl.csize == csize) ? 1u : 0u) != 0;
@@ -2407,7 +2407,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if ((uint64_t)oposw + rest > fcs) FAIL();
                         if (ltype == 1) {
                             for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
-                        } else {
+                        } else if (!(striped && rl.tail && oposw + rest == fcs)) {   // (else they stand there already: RefLits.tail)
                             lits_wave((gu8*)dst + oposw, lposw, rest);
                         }
                         lpos = regen;

@@ -794,6 +794,7 @@ __global__ __launch_bounds__(256) void ref_lit_scan_kernel(ReadBatch b, const ui
     const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
     if (btype != 2 || bsize < 5 || bsize >= BLOCK_MAX || (uint64_t)pos + 3 + bsize > n) return;
     const uint32_t blk = pos + 3;
+    F.pad[2] = bh & 1u;   // the frame's last block
     uint32_t lh, regen, csize;
     {
         const uint64_t v = (a0 >> 24) | (a1 << 40);
@@ -1083,7 +1084,49 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
 #pragma unroll
         for (int k = 0; k < (int)(REF_HALO / 16); ++k) *(gh4*)(h + 16 * k) = v[k];
     }
-    pos[(size_t)r * WAVE + lane] = tk.out - F->ws_lit + (incl - m - before);
+    const uint32_t lit0 = tk.out - F->ws_lit + (incl - m - before);   // the index of this stripe's first literal
+    pos[(size_t)r * WAVE + lane] = lit0;
+    // The literals behind a block's last sequence -- for a read they are most of its data bytes, nine tenths of all literals -- are the last
+    // bytes the block regenerates.  If the block is the frame's last, literal x of them belongs at fcs - regen + x whatever the sequences
+    // are: the stripes go there now, whole (what lands below the first such literal is overwritten by the decoder's output later, which
+    // never reads it), and the decoder finds its longest copy done (RefLits.tail).  Piece after piece by the whole wavefront -- an
+    // instruction is a kilobyte of whole lines --, eight pieces' loads in flight before their stores.
+    if (F->pad[2]) {
+        typedef __attribute__((address_space(1), aligned(16))) const u32x4 gl4;
+        typedef __attribute__((address_space(1), aligned(1))) u32x4 gst4;
+        const uint32_t dpos = F->fcs - regen + lit0;
+        const uint32_t k0 = 16u * (uint32_t)lane;
+        constexpr int MG = 8;
+        for (int g = 0; g < WAVE; g += MG) {
+            u32x4 v[MG][3];
+            uint32_t tailb[MG];
+#pragma unroll
+            for (int u = 0; u < MG; ++u) {
+                const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)m, g + u);
+                gcu8* f = (gcu8*)(tb + (uint64_t)(g + u) * pcap);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (k0 + 1024u * c + 16u <= mq) v[u][c] = *(gl4*)(f + k0 + 1024u * c);
+                const uint32_t rb = mq & 15u;
+                tailb[u] = (uint32_t)lane < rb ? f[mq - rb + (uint32_t)lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < MG; ++u) {
+                const uint32_t mq = (uint32_t)__builtin_amdgcn_readlane((int)m, g + u);
+                gu8* d = (gu8*)dst + (uint32_t)__builtin_amdgcn_readlane((int)dpos, g + u);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (k0 + 1024u * c + 16u <= mq) *(gst4*)(d + k0 + 1024u * c) = v[u][c];
+                const uint32_t rb = mq & 15u;
+                if ((uint32_t)lane < rb) d[mq - rb + (uint32_t)lane] = (uint8_t)tailb[u];
+                if (mq > 3072u + 16u) {   // (a stripe of more than 3 KB: only where the slot is far larger than the frame)
+                    gcu8* f = (gcu8*)(tb + (uint64_t)(g + u) * pcap);
+                    for (uint32_t k = k0 + 3072u; k + 16u <= mq; k += 1024u) *(gst4*)(d + k) = *(gl4*)(f + k);
+                }
+            }
+        }
+        res.tail = 1;
+    }
     res.blk = F->pad[0];
     res.regen = regen;
     res.csize = F->pad[1];
