@@ -329,7 +329,7 @@ LABEL_KERNELS = {
     "svb_encode": ("svb_encode_kernel", "svb_seg_encode"),
     "zstd_encode": ("zstd_plan_kernel", "zstd_pack_kernel", "zstd_encode_kernel", "zstd_span_", "period_probe_kernel"),
     "zstd_decode": ("fast_scan_kernel", "fast_weights_kernel", "fast_streams_kernel", "fast_runs_kernel", "zstd_decode_kernel", "ref_chain_kernel",
-                    "zstd_dspan_"),
+                    "ref_lit_scan_kernel", "ref_pieces_kernel", "zstd_dspan_"),
     "svb_decode": ("svb_decode_kernel", "svb_seg_decode"),
     "plan_scratch": ("plan_scratch_kernel",),
     "route": ("route_", "seg_plan_kernel", "validate_batch_kernel", "parse_sized_kernel", "hand_back_kernel", "copy_bytes_kernel"),
