@@ -2216,7 +2216,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 // Literals that were decoded ahead stand in 64 stripes (ref_pieces_kernel; RefLits): stripe q holds the literals
                 // [P[q], P[q + 1]) at sbase + q * pcap and, behind them, the next stripe's first 256 (= LANE_COPY_MAX): whatever a LANE
                 // reads -- a run of up to 256 literals, the source of a match inside it -- it reads in one piece from where the run
-                // begins (lit_at); only what the whole wavefront moves (longer runs) goes stripe by stripe (lits_wave).
+                // begins (`lf` in the trips below); only what the whole wavefront moves (longer runs) goes stripe by stripe (lits_wave).
                 const bool striped = lits_ahead;
                 const uint8_t* const sbase = dst + rl.tb;
                 const uint32_t spcap = rl.pcap;

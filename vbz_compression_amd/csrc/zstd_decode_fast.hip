@@ -1065,9 +1065,6 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     const uint32_t before_ = (uint32_t)__shfl((int)incl, st ? (int)(st * REF_PIECES) - 1 : 0, 64);   // (every lane takes part: the source must be active)
     const uint32_t before = st ? before_ : 0u;
     const uint32_t total = (uint32_t)__shfl((int)incl, (int)(st * REF_PIECES + REF_PIECES - 1u), 64) - before;
-#ifdef VBZ_REF_DEBUG
-    if (r == 0) printf("lane %2d st %u j %2u pad %u B %u seg %u c_lo %u c_hi %u from %u off %d s_bit %u e_bit %u e_prev %u m %u cnt %u total %u holds %d spill %d pcap %u\n", lane, st, j, pad, B, seg, c_lo, c_hi, from, off, s_bit, e_bit, e_prev, m, cnt, total, (int)holds, (int)spill, pcap);
-#endif
     if (__any(!holds || total != cnt)) LEAVE();
     // The stripes stay where they are: the decoder reads the literals out of them (RefLits: tb, pcap; pos[]: the index of every piece's first
     // literal) -- moving them to one place first cost 0.54 of this kernel's 2.1 ms per 16 384 frames and 3 GB of traffic under the walks.
