@@ -1988,8 +1988,8 @@ def test_walked_chains_in_calls_large_enough_to_walk_by_default():
 def test_reference_frames_literals_decoded_beside_the_walk():
     """Round 6: for frames the reference wrote, the four Huffman streams of the first block are cut into 64 pieces that are walked once
     (ref_pieces_kernel, beside the chain walk) and left in stripes the general decoder reads in place (zstd_decode_fast.hip / RefLits).
-    A call large enough to walk by default, reads chosen for what the decoder does with stripes: first blocks below and above the 24 KB of
-    literals from which the streams are cut (about 30 000 samples), up to full 128 KB ones, second blocks, long runs of literals (moved by the whole wavefront across
+    A call large enough to walk by default, reads chosen for what the decoder does with stripes: first blocks too short to be cut (below
+    ~ 8 000 samples), cut into 4, 8 and 16 pieces a stream (from ~ 8 000, 15 000, 30 000 samples), up to full 128 KB ones, second blocks, long runs of literals (moved by the whole wavefront across
     stripes), long zero runs (patterns taken from the literals), matches that copy their own literals, flat and noisy stretches."""
     import gpu_util as G
     from multiprocessing.pool import ThreadPool
@@ -2000,19 +2000,20 @@ def test_reference_frames_literals_decoded_beside_the_walk():
     opts, oo = G.codec().options(True, 2, 1, 1), O.options(True, 2, 1, 1)
     reads = []
     for i in range(2700):
-        n = int(rng.integers(18000, 60000)) if i % 50 else int(rng.integers(120000, 300000))
+        n = int(rng.integers(5000, 60000)) if i % 50 else int(rng.integers(120000, 300000))
         a = O.synth_signal(5, 7000 + i, n).copy()
         k = i % 7
         if k == 1:      # flat stretches: zero runs of hundreds of control bytes between the literals
             for _ in range(3):
-                s0 = int(rng.integers(0, n - 6000))
+                s0 = int(rng.integers(0, max(1, n - 6000)))
                 a[s0 : s0 + int(rng.integers(1500, 6000))] = a[s0]
         elif k == 2:    # a noisy stretch: two-byte codes, no matches -- a long run of literals
-            s0 = int(rng.integers(0, n - 9000))
-            a[s0 : s0 + 8000] = rng.integers(-20000, 20000, 8000).astype(np.int16)
+            s0 = int(rng.integers(0, max(1, n - 9000)))
+            a[s0 : s0 + 8000] = rng.integers(-20000, 20000, len(a[s0 : s0 + 8000])).astype(np.int16)
         elif k == 3:    # a stretch that repeats itself
-            s0 = int(rng.integers(4000, n - 9000))
-            a[s0 : s0 + 4000] = a[s0 - 4000 : s0]
+            s0 = int(rng.integers(4000, max(4001, n - 9000)))
+            k4 = len(a[s0 : s0 + 4000])
+            a[s0 : s0 + k4] = a[s0 - 4000 : s0 - 4000 + k4]
         elif k == 4:    # steps: runs of equal control bytes that are not zero
             a[: n // 3] = (np.arange(n // 3) * 300 % 30000).astype(np.int16)
         reads.append(a)
@@ -2024,4 +2025,4 @@ def test_reference_frames_literals_decoded_beside_the_walk():
     for i, (a, b) in enumerate(zip(reads, back)):
         assert not isinstance(b, int) and b.tobytes() == a.tobytes(), i
     forced = n == 0   # (the suite is also run with every call forced onto the large-read path: no report from there)
-    assert forced or (n == len(reads) and walked >= 2600 and 1000 <= ahead <= 2400), (n, batched, walked, ahead)
+    assert forced or (n == len(reads) and walked >= 2600 and 2000 <= ahead <= 2650), (n, batched, walked, ahead)

@@ -2229,7 +2229,8 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     }
                     const uint32_t q = (uint32_t)__popcll(__ballot(Pv <= idx)) - 1u;   // (P[0] = 0)
                     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readlane((int)Pv, (int)q);
-                    const uint32_t p1 = q < 63u ? (uint32_t)__builtin_amdgcn_readlane((int)Pv, (int)(q + 1u)) : regen;
+                    const uint32_t p1n = q < 63u ? (uint32_t)__builtin_amdgcn_readlane((int)Pv, (int)(q + 1u)) : regen;
+                    const uint32_t p1 = p1n < regen ? p1n : regen;   // (lanes without a stripe hold 0xFFFFFFFF)
                     room = p1 - idx;
                     return sbase + q * spcap + (idx - p0);
                 };

@@ -766,15 +766,16 @@ __global__ __launch_bounds__(WAVE) void fast_streams_kernel(ReadBatch b, const F
 // Nothing is repaired and no verdict is given here: a frame for which anything fails is left as it was -- the one-wavefront decoder
 // decodes its streams itself and is the one to say what is wrong with it.
 constexpr uint32_t REF_TASKS = 4;
-constexpr uint32_t REF_PIECES_LOG = 4, REF_PIECES = 1u << REF_PIECES_LOG;
+constexpr uint32_t REF_PIECES_LOG = 4, REF_PIECES = 1u << REF_PIECES_LOG;   // pieces a stream, at most (8 or 4 for shorter streams: idle lanes)
+constexpr uint32_t REF_PIECES_LOG_MIN = 2;
 constexpr uint32_t REF_RUNUP = 768;                          // bits
 constexpr uint32_t REF_HALO = 256;                           // literals of the next stripe repeated behind a stripe (= zstd_decode.hip's LANE_COPY_MAX)
-constexpr uint32_t REF_MIN_STREAM = 384u * REF_PIECES;       // bytes: a piece of 384 bytes holds at least 256 symbols of up to 11 bits + the run-up's share
+constexpr uint32_t REF_MIN_PIECE = 384;                      // bytes: a piece of 384 bytes holds at least 256 symbols of up to 11 bits + the run-up's share
 #ifndef VBZ_REF_RING
 #define VBZ_REF_RING 32
 #define VBZ_REF_BATCH 16
 #endif
-static_assert(REF_TASKS * REF_PIECES == (uint32_t)WAVE, "one lane per piece");
+static_assert(REF_TASKS * REF_PIECES == (uint32_t)WAVE && REF_PIECES_LOG_MIN >= 2, "one lane per piece; the move goes by eight stripes");
 
 // one lane per frame with only[r] != 0: is it of the shape, where are the tree and the four streams (skip[r] = 0 if so)
 __global__ __launch_bounds__(256) void ref_lit_scan_kernel(ReadBatch b, const uint32_t* only, FastFrame* frames, FastTask* tasks, uint32_t* skip)
@@ -827,7 +828,12 @@ __global__ __launch_bounds__(256) void ref_lit_scan_kernel(ReadBatch b, const ui
     if (seg * 3 > regen) return;
     const uint32_t so[4] = { 0u, s1, s1 + s2, s1 + s2 + s3 };
     const uint32_t sz[4] = { s1, s2, s3, qn - s1 - s2 - s3 };
-    if (sz[0] < REF_MIN_STREAM || sz[1] < REF_MIN_STREAM || sz[2] < REF_MIN_STREAM || sz[3] < REF_MIN_STREAM) return;
+    // 16 pieces a stream where every stream has 16 x 384 bytes (first blocks from ~ 30 000 samples on), else 8, else 4 (~ 8 000 samples)
+    const uint32_t szmin = min(min(sz[0], sz[1]), min(sz[2], sz[3]));
+    uint32_t gs = REF_PIECES_LOG;
+    while (gs > REF_PIECES_LOG_MIN && szmin < (REF_MIN_PIECE << gs)) --gs;
+    if (szmin < (REF_MIN_PIECE << gs)) return;
+    F.pad[3] = gs;
     F.ntask = REF_TASKS;
     F.ntree = 1;
     F.tree_off[0] = blk + lh;
@@ -879,21 +885,25 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     const uint8_t* src = b.src + b.src_off[r];
     uint8_t* dst = b.dst + b.dst_off[r];
     const uint32_t cap = b.dst_cap[r];
-    const uint32_t st = (uint32_t)lane >> REF_PIECES_LOG, j = (uint32_t)lane & (REF_PIECES - 1u);
+    // G = 16, 8 or 4 pieces a stream (the scan's choice): lanes [0, 4 G) each walk a piece, the others idle along (their piece is empty)
+    const uint32_t gs = F->pad[3], G = 1u << gs, nact = REF_TASKS << gs;
+    if (gs < REF_PIECES_LOG_MIN || gs > REF_PIECES_LOG) LEAVE();
+    const bool act = (uint32_t)lane < nact;
+    const uint32_t st = act ? (uint32_t)lane >> gs : 0u, j = (uint32_t)lane & (G - 1u);
     const FastTask tk = tasks[(size_t)r * REF_TASKS + st];
     const uint32_t nbytes = tk.size, cnt = tk.cnt;
     const uint8_t* p = src + tk.src;
     const uint32_t last = p[nbytes - 1];
     if (__any(last == 0)) LEAVE();
     const uint32_t pad = 8u - (uint32_t)hbit(last), B = 8u * nbytes;
-    const uint32_t seg = (B - pad + REF_PIECES - 1u) >> REF_PIECES_LOG;
-    const uint32_t c_lo = pad + j * seg, c_hi = j == REF_PIECES - 1u ? B : pad + (j + 1u) * seg;
+    const uint32_t seg = (B - pad + G - 1u) >> gs;
+    const uint32_t c_lo = act ? pad + j * seg : pad, c_hi = act ? (j == G - 1u ? B : pad + (j + 1u) * seg) : pad;
     // the stripes: what the slot has behind the literals' place, 128-byte aligned, a 64th each; a piece holds its share of the
     // stream's symbols give or take a few per cent -- a stripe must have room for a quarter more, else the frame is not done here
     const uint32_t regen = F->b0_regen;
     const uint64_t tb = ((uint64_t)(dst + F->ws_lit + ((regen + 15u) & ~15u) + 16u) + 127ull) & ~127ull, te = (uint64_t)(dst + cap);
-    const uint32_t pcap = te > tb ? (uint32_t)(((te - tb) >> 6) < 0x10000ull ? ((te - tb) >> 6) : 0x10000ull) & ~127u : 0u;
-    if (__any((cnt >> REF_PIECES_LOG) + (cnt >> (REF_PIECES_LOG + 2u)) + 256u > pcap)) LEAVE();
+    const uint32_t pcap = te > tb ? (uint32_t)(((te - tb) >> (gs + 2u)) < 0x10000ull ? ((te - tb) >> (gs + 2u)) : 0x10000ull) & ~127u : 0u;
+    if (__any((cnt >> gs) + (cnt >> (gs + 2u)) + 256u > pcap)) LEAVE();
     gu8* o = (gu8*)(tb + (uint64_t)lane * pcap);
 
     // ---- the walker: fast_streams_kernel's (aligned lines into a ring per lane, two symbols per 32 fresh bits), started in mid-stream:
@@ -901,7 +911,7 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     const uint32_t sL = 32u - tlog;
     const uint16_t* Tl = T;
     uint32_t* ring = &ringbuf[0][0] + lane;
-    const uint32_t from = (j == 0 || c_lo - pad <= REF_RUNUP) ? pad : c_lo - REF_RUNUP;
+    const uint32_t from = (!act || j == 0 || c_lo - pad <= REF_RUNUP) ? pad : c_lo - REF_RUNUP;
     const uint64_t e = (uint64_t)(p + nbytes);
     uint64_t nextline = (e - (uint64_t)(from >> 3) + (LINE - 1ull)) & ~(LINE - 1ull);
     const uint64_t lowline = (uint64_t)p & ~(LINE - 1ull);
@@ -1060,20 +1070,20 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     if (__any(spill)) LEAVE();
     // ---- the pieces must chain from the end mark to the first bit of the stream, symbol for symbol
     const uint32_t e_prev = (uint32_t)__shfl_up((int)e_bit, 1, 64);
-    const bool holds = (j == 0 ? s_bit == pad : s_bit == e_prev) && (j != REF_PIECES - 1u || e_bit == B);
+    const bool holds = !act || ((j == 0 ? s_bit == pad : s_bit == e_prev) && (j != G - 1u || e_bit == B));
     const uint32_t incl = wave_incl_scan_u32(m);
-    const uint32_t before_ = (uint32_t)__shfl((int)incl, st ? (int)(st * REF_PIECES) - 1 : 0, 64);   // (every lane takes part: the source must be active)
+    const uint32_t before_ = (uint32_t)__shfl((int)incl, st ? (int)(st * G) - 1 : 0, 64);   // (every lane takes part: the source must be active)
     const uint32_t before = st ? before_ : 0u;
-    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(st * REF_PIECES + REF_PIECES - 1u), 64) - before;
-    if (__any(!holds || total != cnt)) LEAVE();
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(st * G + G - 1u), 64) - before;
+    if (__any(!holds || (act && total != cnt))) LEAVE();
     // The stripes stay where they are: the decoder reads the literals out of them (RefLits: tb, pcap; pos[]: the index of every piece's first
     // literal) -- moving them to one place first cost 0.54 of this kernel's 2.1 ms per 16 384 frames and 3 GB of traffic under the walks.
     // What is moved is a HALO: behind its last literal a stripe gets the next stripe's first REF_HALO, so that a run of up to REF_HALO
     // literals that begins in a stripe is read in one piece from it (the decoder's lanes place runs of up to 256 bytes each; a run that
     // had to be fetched in two parts cost every lane of the wavefront a second memory round trip, trip after trip).
-    if (__any(m < REF_HALO || m + REF_HALO > pcap)) LEAVE();
+    if (__any(act && (m < REF_HALO || m + REF_HALO > pcap))) LEAVE();
     __syncthreads();   // (the stripes are in memory)
-    if (lane != WAVE - 1) {
+    if ((uint32_t)lane + 1u < nact) {
         typedef __attribute__((address_space(1), aligned(16))) const u32x4 gl4;
         typedef __attribute__((address_space(1), aligned(1))) u32x4 gh4;
         gcu8* f = (gcu8*)(tb + (uint64_t)(lane + 1) * pcap);
@@ -1085,7 +1095,7 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
         for (int k = 0; k < (int)(REF_HALO / 16); ++k) *(gh4*)(h + 16 * k) = v[k];
     }
     const uint32_t lit0 = tk.out - F->ws_lit + (incl - m - before);   // the index of this stripe's first literal
-    pos[(size_t)r * WAVE + lane] = lit0;
+    pos[(size_t)r * WAVE + lane] = act ? lit0 : 0xFFFFFFFFu;   // (no stripe: behind every literal)
     // The literals behind a block's last sequence -- for a read they are most of its data bytes, nine tenths of all literals -- are the last
     // bytes the block regenerates.  If the block is the frame's last, literal x of them belongs at fcs - regen + x whatever the sequences
     // are: the stripes go there now, whole (what lands below the first such literal is overwritten by the decoder's output later, which
@@ -1097,7 +1107,7 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
         const uint32_t dpos = F->fcs - regen + lit0;
         const uint32_t k0 = 16u * (uint32_t)lane;
         constexpr int MG = 8;
-        for (int g = 0; g < WAVE; g += MG) {
+        for (int g = 0; g < (int)nact; g += MG) {
             u32x4 v[MG][3];
             uint32_t tailb[MG];
 #pragma unroll
