@@ -186,8 +186,8 @@ struct RefLits
 {
     uint32_t blk, regen, csize, at;
     uint32_t tb, pcap;           // the literals stand in 64 stripes of pcap bytes from offset tb of the slot; lits_pos[64 r + q]: the first literal of stripe q
-    uint32_t tail, pad;          // tail: the block is the frame's last and literal x also stands at fcs - regen + x of the slot -- where the literals
-                                 // behind the last sequence belong
+    uint32_t tail, pad;          // tail != 0: literal x also stands at tail - regen + x of the slot -- where the literals behind the last sequence
+                                 // belong if the block's content ends at `tail` (the frame's content size for a last block, else a full block)
 };
 struct RefChains  // what launch_zstd_decode_only needs of them (pre == nullptr: none)
 {

@@ -2408,7 +2408,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         if ((uint64_t)oposw + rest > fcs) FAIL();
                         if (ltype == 1) {
                             for (uint32_t k = lane; k < rest; k += WAVE) dst[oposw + k] = rle_byte;
-                        } else if (!(striped && rl.tail && oposw + rest == fcs)) {   // (else they stand there already: RefLits.tail)
+                        } else if (!(striped && rl.tail != 0u && oposw + rest == rl.tail)) {   // (else they stand there already: RefLits.tail)
                             lits_wave((gu8*)dst + oposw, lposw, rest);
                         }
                         lpos = regen;

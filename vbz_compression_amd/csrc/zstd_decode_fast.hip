@@ -1097,14 +1097,17 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     const uint32_t lit0 = tk.out - F->ws_lit + (incl - m - before);   // the index of this stripe's first literal
     pos[(size_t)r * WAVE + lane] = act ? lit0 : 0xFFFFFFFFu;   // (no stripe: behind every literal)
     // The literals behind a block's last sequence -- for a read they are most of its data bytes, nine tenths of all literals -- are the last
-    // bytes the block regenerates.  If the block is the frame's last, literal x of them belongs at fcs - regen + x whatever the sequences
-    // are: the stripes go there now, whole (what lands below the first such literal is overwritten by the decoder's output later, which
+    // bytes the block regenerates.  If the block ends at E (the frame's last: E = fcs), literal x of them belongs at E - regen + x whatever the
+    // sequences are: the stripes go there now, whole (what lands below the first such literal is overwritten by the decoder's output later, which
     // never reads it), and the decoder finds its longest copy done (RefLits.tail).  Piece after piece by the whole wavefront -- an
     // instruction is a kilobyte of whole lines --, eight pieces' loads in flight before their stores.
-    if (F->pad[2]) {
+    // (A block that is not the frame's last: libzstd cuts its input into blocks of BLOCK_MAX bytes, so such a block ends at block_max -- a
+    // guess the decoder checks like everything else: it skips its copy only if the literals' place comes out where they were put.)
+    const uint32_t tail_end = F->pad[2] ? F->fcs : (F->block_max < F->fcs ? F->block_max : F->fcs);
+    if (tail_end >= regen) {
         typedef __attribute__((address_space(1), aligned(16))) const u32x4 gl4;
         typedef __attribute__((address_space(1), aligned(1))) u32x4 gst4;
-        const uint32_t dpos = F->fcs - regen + lit0;
+        const uint32_t dpos = tail_end - regen + lit0;
         const uint32_t k0 = 16u * (uint32_t)lane;
         constexpr int MG = 8;
         for (int g = 0; g < (int)nact; g += MG) {
@@ -1135,7 +1138,7 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
                 }
             }
         }
-        res.tail = 1;
+        res.tail = tail_end;
     }
     res.blk = F->pad[0];
     res.regen = regen;
