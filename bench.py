@@ -193,6 +193,9 @@ def decode_reference_frames(codec, n_reads=16384, launches=5):
     go()
     torch.cuda.synchronize()
     ok = bool((res == s32).all()) and torch.equal(back, want)
+    go()   # (a second untimed call: the first finds out whose frames these are -- and runs as two halves --, this one sizes the context's
+    torch.cuda.synchronize()   # buffers for the whole call; the timed calls are the steady state, like the steps behind the headline's warm-up)
+    ok = ok and bool((res == s32).all()) and torch.equal(back, want)
     codec.profile_reset()
     codec.profile(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -93,6 +93,8 @@ struct vbz_gpu_ctx
     DevBuf fastmeta;  // per-frame descriptors, stream tasks and weights of the batched own-frame decoder (zstd_decode_fast.hip)
     bool fast_decode = true;   // VBZ_HIP_FAST_DECODE=0: every frame through the one-wavefront decoder
     DevBuf refpre, reftab, refrecs;  // frames the reference wrote: per-frame hand-over, tables (large batches), records (zstd_decode_ref.hip)
+    DevBuf reflits;                  // ... their literals decoded beside the walk (zstd_decode_fast.hip: ref_pieces_kernel)
+    uint32_t last_lit_units = 0;     // (records per read the last call filled)
     int ref_chains = 1;        // VBZ_HIP_REF_CHAINS: 0 their sequence chains are walked by the one-wavefront decoder itself, 1 walked ahead of
                                // it in calls of REF_MIN_READS reads and more, 2 in every call
     FastSide side;             // the walk's own stream (beside the launches for this library's frames)
@@ -598,8 +600,16 @@ int zstd_frames(vbz_gpu_ctx* c, const ReadBatch& z, uint32_t toosmall_code, uint
     if (walk && (!ensure(c, c->refpre, zstd_ref_pre_bytes(n)) || !ensure(c, c->reftab, zstd_ref_table_bytes(n)) || !ensure(c, c->refrecs, recs_bytes)))
         return -1;
     if (walk && !dbg && !ensure_side(c)) return -1;
+    const bool lits = walk && zstd_ref_literals_enabled();
+    if (lits && !ensure(c, c->reflits, zstd_ref_lit_meta_bytes(n))) return -1;
+    // (blocks per frame that get a record and a workgroup of the pieces' kernel: a call of short reads has one block a frame -- three of four
+    // workgroups of a grid for four would start only to end, 0.3 ms per 16 384 frames --, a call of long reads two or three of 128 KB and a rest)
+    const uint64_t avg_content = content_bytes / n;
+    // (content_bytes is the caller's bound: the decoded bytes of the call, 1.6 x the frames' content where an svb stage follows)
+    const uint32_t lit_units = avg_content <= (96u << 10) ? 1u : (uint32_t)std::min<uint64_t>(avg_content / (256u << 10) + 2u, zstd_ref_lit_units());
+    c->last_lit_units = lits ? lit_units : 0;
     HIPCHK(c, launch_zstd_decode_fast(z, toosmall_code, c->seqdtab.p, c->fastmeta.p, walk ? c->refpre.p : nullptr, c->reftab.p, c->refrecs.p,
-                                      recs_bytes / 16, dbg, c->side, s),
+                                      recs_bytes / 16, lits ? c->reflits.p : nullptr, lit_units, dbg, c->side, s),
            "zstd_decode (batched) launch");
     c->last_walked = walk;
     c->last_frames = dbg ? 0 : n;
@@ -1229,7 +1239,7 @@ void vbz_gpu_destroy(vbz_gpu_ctx* c)
         (void)hipEventDestroy(p.stop);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs, &c->splitmeta, &c->foreign_dev })
+    for (DevBuf* b : { &c->scratch, &c->meta, &c->gmeta, &c->route, &c->one_in, &c->one_out, &c->one_meta, &c->dbg, &c->seqtab, &c->seqdtab, &c->segmeta, &c->spanmeta, &c->spantmp, &c->fastmeta, &c->vgate, &c->encplan, &c->refpre, &c->reftab, &c->refrecs, &c->reflits, &c->splitmeta, &c->foreign_dev })
         if (b->p) (void)hipFree(b->p);
     if (c->large) vbz_gpu_destroy(c->large);
     if (c->half) vbz_gpu_destroy(c->half);
@@ -1437,15 +1447,33 @@ int vbz_gpu_decode_literals_ahead(vbz_gpu_ctx* c)
     if (!c) return -1;
     int total = 0;
     for (vbz_gpu_ctx* k : { c, (c->last_split && c->half) ? c->half : (vbz_gpu_ctx*)nullptr }) {
-        if (!k || !k->last_frames || !k->last_walked || !zstd_ref_literals_enabled()) continue;
+        if (!k || !k->last_frames || !k->last_walked || !zstd_ref_literals_enabled() || !k->reflits.p) continue;
         DeviceGuard guard(k->device);
-        std::vector<RefLits> lits(k->last_frames);
-        if (hipMemcpyAsync(lits.data(), zstd_ref_lits(k->fastmeta.p, k->last_frames), sizeof(RefLits) * lits.size(), hipMemcpyDeviceToHost, k->stream) != hipSuccess ||
+        const uint32_t per = k->last_lit_units;
+        if (per == 0) continue;
+        std::vector<RefLits> lits((size_t)k->last_frames * per);
+        if (hipMemcpyAsync(lits.data(), zstd_ref_lits(k->reflits.p, k->last_frames), sizeof(RefLits) * lits.size(), hipMemcpyDeviceToHost, k->stream) != hipSuccess ||
             hipStreamSynchronize(k->stream) != hipSuccess) {
             (void)hipGetLastError();
             return -1;
         }
-        for (const RefLits& l : lits) total += l.blk != 0;
+        if (k->trace) {   // per block ordinal: units the scan made, units whose literals stand
+            std::vector<uint32_t> sk((size_t)k->last_frames * per);
+            if (hipMemcpy(sk.data(), zstd_ref_lit_skip(k->reflits.p, k->last_frames), 4 * sk.size(), hipMemcpyDeviceToHost) == hipSuccess)
+                for (uint32_t u = 0; u < per; ++u) {
+                    uint32_t made = 0, done = 0;
+                    for (uint32_t i = 0; i < k->last_frames; ++i) {
+                        made += sk[(size_t)u * k->last_frames + i] == 0;
+                        done += lits[(size_t)u * k->last_frames + i].blk != 0;
+                    }
+                    fprintf(stderr, "vbz_hip: literals beside the walk, unit %u: %u made by the scan, %u done\n", u, made, done);
+                }
+        }
+        for (uint32_t i = 0; i < k->last_frames; ++i) {   // (frames with at least one block's literals ahead)
+            bool any = false;
+            for (uint32_t u = 0; u < per; ++u) any = any || lits[(size_t)u * k->last_frames + i].blk != 0;   // (record u of read i)
+            total += any;
+        }
     }
     return total;
 }

@@ -193,8 +193,9 @@ struct RefChains  // what launch_zstd_decode_only needs of them (pre == nullptr:
 {
     const RefPre* pre = nullptr;
     const void* recs = nullptr;
-    const RefLits* lits = nullptr;   // (nullable; only looked at for frames whose chains are walked)
-    const uint32_t* lits_pos = nullptr;
+    const RefLits* lits = nullptr;   // (nullable; only looked at for frames whose chains are walked) record k of read r at k * n_reads + r, k < REF_MAXBLK ...
+    const uint32_t* lits_pos = nullptr;   // ... and 64 words per record
+    uint32_t lits_units = 0;              // records per read this call has filled (k < lits_units)
 };
 
 size_t zstd_ref_pre_bytes(uint32_t n_reads);
@@ -213,11 +214,17 @@ hipError_t launch_zstd_decode_only(const ReadBatch& b, uint32_t toosmall_code, c
 // ref_*: scratch of launch_zstd_ref_chain (ref_pre == nullptr: frames of other writers go to the one-wavefront decoder as they are).
 // dbg (nullable): phase cycle counters of the one-wavefront decoder, which then decodes EVERY frame (walked chains included).
 size_t zstd_fast_meta_bytes(uint32_t n_reads);
-const RefLits* zstd_ref_lits(const void* meta, uint32_t n_reads);   // (diagnostics: blk != 0 = the frame's literals were decoded ahead)
+const RefLits* zstd_ref_lits(const void* lit_meta, uint32_t n_reads);   // (diagnostics: zstd_ref_lit_units() records per read; blk != 0 = that block's literals were decoded ahead)
 bool zstd_ref_literals_enabled();                                   // VBZ_HIP_REF_LITERALS
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads);  // after the call: redo[i] == 0 <=> frame i was decoded by the batched decoder
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
-                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, FastSide side, hipStream_t s);
+                                   void* ref_recs, uint64_t ref_recs_cap, void* ref_lits, uint32_t ref_units, unsigned long long* dbg, FastSide side,
+                                   hipStream_t s);
+// ref_lits (nullable): zstd_ref_lit_meta_bytes(n_reads) bytes for the literals decoded beside the walk (zstd_ref_lit_units() records per read;
+// ref_units: how many of them this call fills -- blocks per frame that get a workgroup)
+size_t zstd_ref_lit_meta_bytes(uint32_t n_reads);
+uint32_t zstd_ref_lit_units();
+const uint32_t* zstd_ref_lit_skip(const void* lit_meta, uint32_t n_reads);   // (diagnostics: 0 = the scan made the block a unit)
 size_t seq_dtables_bytes();
 void seq_dtables_build(void* host_buffer);
 // The same for batches of few, large reads: frames that carry the encoder's span index are decoded one span per wavefront

@@ -1787,7 +1787,17 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                     if (lazy_seq) FAIL();                   // the block before this one did have sequences after all
                     lazy_seq = src[pos + bsize - 1];        // (every lane the same byte)
                     const uint32_t q0 = pos + lh + 6, qn = csize - 6;
-                    if (lane < 4) {
+                    // (a walked frame's block whose literals -- its content -- stand in the output already: ref_pieces_kernel, RefLits.tail)
+                    bool standing = false;
+                    if (mypre != nullptr && attempt == 0 && chains.lits != nullptr) {
+                        for (uint32_t k = 0; k < chains.lits_units && !standing; ++k) {
+                            const RefLits c = chains.lits[(size_t)k * b.n_reads + r];
+                            standing = uni((c.blk != 0 && c.blk == pos - 3 && c.regen == regen && c.csize == csize && c.tail != 0u &&
+                                            (uint64_t)opos + regen == c.tail) ? 1u : 0u) != 0;
+                        }
+                    }
+                    if (standing) {
+                    } else if (lane < 4) {
                         const uint32_t so = lane == 0 ? 0 : (lane == 1 ? s1 : (lane == 2 ? s1 + s2 : s1 + s2 + s3));
                         const uint32_t sz = lane == 0 ? s1 : (lane == 1 ? s2 : (lane == 2 ? s3 : qn - s1 - s2 - s3));
                         L.t_src[ntask + lane] = q0 + so;
@@ -1796,7 +1806,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                         L.t_cnt[ntask + lane] = lane < 3 ? seg : regen - 3 * seg;
                         L.t_tab[ntask + lane] = (uint32_t)cur_slot * (uint32_t)HUF_SLOT | ((uint32_t)cur_log << 16);
                     }
-                    ntask += 4;
+                    if (!standing) ntask += 4;
                     wave_lds_sync();
                     opos += regen;
                     pos += bsize;
@@ -1864,9 +1874,16 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             // place further down.  Then nobody needs this block's table unless a later block is coded under it: the last block's is not built.
             bool lits_cand = false;
             RefLits rl = {};
-            if (use_pre && chains.lits != nullptr && ltype == 2 && streams == 4) {
-                rl = chains.lits[r];
-                lits_cand = uni((rl.blk != 0 && rl.blk == pos - 3 && rl.regen == regen && rl.csize == csize) ? 1u : 0u) != 0;
+            uint32_t lits_unit = 0;
+            if (use_pre && chains.lits != nullptr && ltype >= 2 && streams == 4) {
+                for (uint32_t k = 0; k < chains.lits_units && !lits_cand; ++k) {   // (a record per block that was taken, in block order)
+                    const RefLits c = chains.lits[(size_t)k * b.n_reads + r];
+                    if (uni((c.blk != 0 && c.blk == pos - 3 && c.regen == regen && c.csize == csize) ? 1u : 0u) != 0) {
+                        rl = c;
+                        lits_unit = k;
+                        lits_cand = true;
+                    }
+                }
             }
             if (ltype == 2 && !(lits_cand && last)) {
                 PHASE(0);
@@ -1974,7 +1991,9 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
             }
             const uint32_t lit_dst = !has_seq ? opos : (defer ? ws_lit : (par ? ws_plit : fcs - regen));
             const uint8_t* lit_src = blk + lh;  // raw literals are read in place
-            const bool lits_ahead = lits_cand && uni(rl.at == lit_dst ? 1u : 0u) != 0;
+            // (with sequences: the stripes are read where the literals would be staged; without: the literals are the block's content and
+            // stand in the output if the block begins where the pieces' kernel took it to begin)
+            const bool lits_ahead = lits_cand && uni((has_seq ? rl.at == lit_dst : (rl.tail != 0u && (uint64_t)opos + regen == rl.tail)) ? 1u : 0u) != 0;
             if (lits_cand && !lits_ahead) {   // (not where this decoder wants them: the frame again, without hand-overs)
                 restart = true;
                 break;
@@ -2221,7 +2240,7 @@ __global__ __launch_bounds__(WAVE, VBZ_DEC_WAVES) void zstd_decode_kernel(ReadBa
                 const uint8_t* const sbase = dst + rl.tb;
                 const uint32_t spcap = rl.pcap;
                 // P: lane q holds P[q].  Where a literal stands is a ballot (how many stripes begin at or before it), no table in LDS:
-                const uint32_t Pv = striped ? chains.lits_pos[(size_t)r * WAVE + lane] : 0u;
+                const uint32_t Pv = striped ? chains.lits_pos[((size_t)lits_unit * b.n_reads + r) * WAVE + lane] : 0u;
                 auto lit_seg = [&](uint32_t idx, uint32_t& room) -> const uint8_t* {   // idx UNIFORM; room: literals of its stripe from it on
                     if (!striped) {
                         room = 0xFFFFFFFFu;

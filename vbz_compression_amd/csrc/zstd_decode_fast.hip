@@ -21,6 +21,7 @@
 // array -- which is also what decides every error verdict.  A frame decoded here gets exactly the bytes the one-wavefront decoder
 // writes: same tables, same streams, same placement code.
 // Replaces, like zstd_decode.hip, the reference's ZSTD_decompress call (vbz/vbz.cpp:236-273).
+#include <algorithm>
 #include <cstdlib>
 
 #include "vbz_kernels.h"
@@ -270,16 +271,18 @@ struct WeightsLds
     uint16_t symnext[WMAXS + 1][WAVE];
 };
 
-__global__ __launch_bounds__(WAVE) void fast_weights_kernel(ReadBatch b, FastFrame* frames, uint8_t* weights, uint32_t* redo)
+// (nrec: frames[] / weights / redo[] hold nrec records, record i for read i % n_reads -- one per read, or one per block of the frames
+// the reference wrote: ref_lit_scan_kernel)
+__global__ __launch_bounds__(WAVE) void fast_weights_kernel(ReadBatch b, FastFrame* frames, uint8_t* weights, uint32_t* redo, uint32_t nrec)
 {
     __shared__ WeightsLds S;
     const int lane = threadIdx.x;
     const uint32_t t = blockIdx.x * (uint32_t)WAVE + (uint32_t)lane;
     const uint32_t r = t >> 1, k = t & 1;
-    if (r >= b.n_reads || redo[r]) return;
+    if (r >= nrec || redo[r]) return;
     FastFrame* F = frames + r;
     if (k >= F->ntree) return;
-    const uint8_t* g = b.src + b.src_off[r] + F->tree_off[k];
+    const uint8_t* g = b.src + b.src_off[r % b.n_reads] + F->tree_off[k];
     const uint32_t used = F->tree_len[k];
     uint8_t* W = weights + ((size_t)r * 2 + k) * 256;
     const uint32_t hb = g[0];
@@ -777,85 +780,144 @@ constexpr uint32_t REF_MIN_PIECE = 384;                      // bytes: a piece o
 #endif
 static_assert(REF_TASKS * REF_PIECES == (uint32_t)WAVE && REF_PIECES_LOG_MIN >= 2, "one lane per piece; the move goes by eight stripes");
 
-// one lane per frame with only[r] != 0: is it of the shape, where are the tree and the four streams (skip[r] = 0 if so)
-__global__ __launch_bounds__(256) void ref_lit_scan_kernel(ReadBatch b, const uint32_t* only, FastFrame* frames, FastTask* tasks, uint32_t* skip)
+// One lane per frame with only[r] != 0: which of its blocks are of the shape -- up to REF_UNITS of them, a record ("unit") each: where the
+// tree (its own, or the one of an earlier unit for a treeless block) and the four streams are, how many pieces a stream, which part of the
+// slot's free space takes its stripes.  skip[REF_UNITS r + k] = 0 for the units there are.  Whatever the walk through the block headers does
+// not understand ends it: the units found so far stand, the rest of the frame is the decoder's.
+constexpr uint32_t REF_UNITS_LOG = 2, REF_UNITS = 1u << REF_UNITS_LOG;   // (= REF_MAXBLK of the chain walk: it hands over at most four blocks)
+constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
+static_assert(REF_UNITS == REF_MAXBLK, "the decoder looks a block's record up among REF_MAXBLK per read");
+__global__ __launch_bounds__(256) void ref_lit_scan_kernel(ReadBatch b, const uint32_t* only, FastFrame* frames, FastTask* tasks, uint32_t* skip, uint32_t max_units)
 {
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     if (r >= b.n_reads) return;
-    skip[r] = 1;
+    // unit k of read r is record k * n_reads + r: the wavefronts that have work -- most frames have one or two units -- are neighbours in
+    // the grid (with a read's units side by side three of four workgroups were empty, and workgroups go round the XCDs in order: two of the
+    // eight got all the work, the kernel took 7 ms instead of 2.9)
+    const uint32_t nr = b.n_reads;
+    for (uint32_t k = 0; k < max_units; ++k) skip[(size_t)k * nr + r] = 1;
     if (!only[r]) return;
     if (b.gate && b.gate[r] >= GATE_SKIP) return;
     const uint32_t n = b.src_size[r];
     if (n >= E_FIRST || n < 32) return;
     const uint8_t* src = b.src + b.src_off[r];
     const uint32_t cap = b.dst_cap[r];
-    FastFrame F = {};
+    FastFrame H = {};
     uint32_t pos, has_checksum;
-    if (!scan_frame_header(src, cap, &F, &pos, &has_checksum)) return;
-    if (pos + 3 + 16 > n) return;
-    const uint64_t a0 = ld64(src + pos), a1 = ld64(src + pos + 8);
-    const uint32_t bh = (uint32_t)a0 & 0xFFFFFFu;
-    const uint32_t btype = (bh >> 1) & 3, bsize = bh >> 3;
-    if (btype != 2 || bsize < 5 || bsize >= BLOCK_MAX || (uint64_t)pos + 3 + bsize > n) return;
-    const uint32_t blk = pos + 3;
-    F.pad[2] = bh & 1u;   // the frame's last block
-    uint32_t lh, regen, csize;
-    {
-        const uint64_t v = (a0 >> 24) | (a1 << 40);
-        const uint32_t h0 = (uint32_t)v & 0xFF, fmt = (h0 >> 2) & 3;
-        if ((h0 & 3) != 2 || fmt == 0) return;   // compressed literals under a tree of their own, four streams
-        if (fmt == 1) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; }
-        else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; }
-        else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; }
-    }
-    if (regen == 0 || csize == 0 || regen > BLOCK_MAX || lh + csize >= bsize || regen > F.fcs) return;
-    if (src[blk + lh + csize] == 0) return;      // no sequences: such literals go straight to the output
+    if (!scan_frame_header(src, cap, &H, &pos, &has_checksum)) return;
     // where the decoder stages the literals of a block whose chains are walked ahead (zstd_decode_kernel: ws_plit, par)
-    const uint64_t at = ((uint64_t)F.fcs + 15u) & ~15ull;
-    if (at + ((regen + 15u) & ~15u) + 16 > cap) return;
-    const uint32_t hb = src[blk + lh];
-    uint32_t tree_used;
-    if (hb >= 128) tree_used = 1 + ((hb - 127) + 1) / 2;
-    else if (hb == 0) return;
-    else tree_used = 1 + hb;
-    if (tree_used + 10 > csize) return;
-    uint32_t q = blk + lh + tree_used, qn = csize - tree_used - 6;
-    const uint64_t j = ld64(src + q);
-    const uint32_t s1 = (uint32_t)j & 0xFFFFu, s2 = (uint32_t)(j >> 16) & 0xFFFFu, s3 = (uint32_t)(j >> 32) & 0xFFFFu;
-    q += 6;
-    if (s1 + s2 + s3 > qn) return;
-    const uint32_t seg = (regen + 3) >> 2;
-    if (seg * 3 > regen) return;
-    const uint32_t so[4] = { 0u, s1, s1 + s2, s1 + s2 + s3 };
-    const uint32_t sz[4] = { s1, s2, s3, qn - s1 - s2 - s3 };
-    // 16 pieces a stream where every stream has 16 x 384 bytes (first blocks from ~ 30 000 samples on), else 8, else 4 (~ 8 000 samples)
-    const uint32_t szmin = min(min(sz[0], sz[1]), min(sz[2], sz[3]));
-    uint32_t gs = REF_PIECES_LOG;
-    while (gs > REF_PIECES_LOG_MIN && szmin < (REF_MIN_PIECE << gs)) --gs;
-    if (szmin < (REF_MIN_PIECE << gs)) return;
-    F.pad[3] = gs;
-    F.ntask = REF_TASKS;
-    F.ntree = 1;
-    F.tree_off[0] = blk + lh;
-    F.tree_len[0] = tree_used;
-    F.b0_regen = regen;
-    F.ws_lit = (uint32_t)at;
-    F.pad[0] = pos;      // the block header
-    F.pad[1] = csize;
+    const uint64_t at = ((uint64_t)H.fcs + 15u) & ~15ull;
+    uint32_t nunit = 0, tree_unit = REF_NONE, regens[REF_UNITS] = { 0u, 0u, 0u, 0u };
+    uint64_t sum_regen = 0;
+    bool more_blocks = false;
+    for (uint32_t bidx = 0; nunit < max_units; ++bidx) {
+        if ((uint64_t)pos + 3 + 16 > n) break;
+        const uint64_t a0 = ld64(src + pos), a1 = ld64(src + pos + 8);
+        const uint32_t bh = (uint32_t)a0 & 0xFFFFFFu;
+        const uint32_t last = bh & 1u, btype = (bh >> 1) & 3, bsize = bh >> 3;
+        if (btype == 3) break;
+        const uint64_t next = (uint64_t)pos + 3 + (btype == 1 ? 1u : bsize);
+        if (next > n) break;
+        if (bidx != 0 || !last) more_blocks = true;
+        const uint32_t blk = pos + 3;
+        bool unit = false;
+        if (btype == 2 && bsize >= 5 && bsize < BLOCK_MAX) {
+            FastFrame F = H;
+            uint32_t lh = 0, regen = 0, csize = 0;
+            const uint64_t v = (a0 >> 24) | (a1 << 40);
+            const uint32_t h0 = (uint32_t)v & 0xFF, fmt = (h0 >> 2) & 3, ltype = h0 & 3;
+            bool ok = ltype >= 2 && fmt != 0;    // compressed literals in four streams, under a tree of their own or the one before
+            if (ok) {
+                if (fmt == 1) { lh = 3; regen = (uint32_t)(v >> 4) & 0x3FF; csize = (uint32_t)(v >> 14) & 0x3FF; }
+                else if (fmt == 2) { lh = 4; regen = (uint32_t)(v >> 4) & 0x3FFF; csize = (uint32_t)(v >> 18) & 0x3FFF; }
+                else { lh = 5; regen = (uint32_t)(v >> 4) & 0x3FFFF; csize = (uint32_t)(v >> 22) & 0x3FFFF; }
+                ok = regen != 0 && csize != 0 && regen <= BLOCK_MAX && lh + csize < bsize && regen <= H.fcs;
+            }
+            uint32_t tree_used = 0;
+            if (ok && ltype == 2) {
+                const uint32_t hb = src[blk + lh];
+                if (hb >= 128) tree_used = 1 + ((hb - 127) + 1) / 2;
+                else if (hb == 0) ok = false;
+                else tree_used = 1 + hb;
+            } else if (ok) {
+                ok = tree_unit != REF_NONE;      // a treeless block under a tree this kernel has no record of
+            }
+            // (no sequences -- every block but the first of a long read, whose later blocks are data bytes only --: the literals ARE the
+            // block's content, their place is the block's; the pieces' tail placement is all there is to do)
+            const bool noseq = ok && src[blk + lh + csize] == 0;
+            ok = ok && (!noseq || lh + csize + 1 == bsize);
+            ok = ok && tree_used + 10 <= csize && at + ((regen + 15u) & ~15u) + 16 <= cap;
+            if (ok) {
+                uint32_t q = blk + lh + tree_used;
+                const uint32_t qn = csize - tree_used - 6;
+                const uint64_t j = ld64(src + q);
+                const uint32_t s1 = (uint32_t)j & 0xFFFFu, s2 = (uint32_t)(j >> 16) & 0xFFFFu, s3 = (uint32_t)(j >> 32) & 0xFFFFu;
+                q += 6;
+                const uint32_t seg = (regen + 3) >> 2;
+                if (s1 + s2 + s3 <= qn && seg * 3 <= regen) {
+                    const uint32_t so[4] = { 0u, s1, s1 + s2, s1 + s2 + s3 };
+                    const uint32_t sz[4] = { s1, s2, s3, qn - s1 - s2 - s3 };
+                    // 16 pieces a stream where every stream has 16 x 384 bytes (blocks from ~ 30 000 samples on), else 8, else 4 (~ 8 000 samples)
+                    const uint32_t szmin = min(min(sz[0], sz[1]), min(sz[2], sz[3]));
+                    uint32_t gs = REF_PIECES_LOG;
+                    while (gs > REF_PIECES_LOG_MIN && szmin < (REF_MIN_PIECE << gs)) --gs;
+                    if (szmin >= (REF_MIN_PIECE << gs)) {
+                        const uint32_t u = nunit * nr + r;
+                        F.ntask = REF_TASKS;
+                        F.ntree = ltype == 2 ? 1u : 0u;
+                        F.tree_off[0] = blk + lh;
+                        F.tree_len[0] = tree_used;
+                        F.b0_regen = regen;
+                        F.ws_lit = (uint32_t)at;
+                        F.pad[0] = pos;      // the block header
+                        F.pad[1] = csize;
+                        F.pad[2] = last;
+                        F.pad[3] = gs;
+                        F.pad[4] = ltype == 2 ? u : tree_unit;   // whose weights
+                        F.pad[7] = bidx;
+                        F.pad[8] = noseq ? 1u : 0u;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        FastTask t;
-        t.src = q + so[k];
-        t.size = sz[k];
-        t.out = (uint32_t)at + (uint32_t)k * seg;
-        t.cnt = k < 3 ? seg : regen - 3 * seg;
-        tasks[(size_t)r * REF_TASKS + k] = t;
+                        for (int k = 0; k < 4; ++k) {
+                            FastTask t;
+                            t.src = q + so[k];
+                            t.size = sz[k];
+                            t.out = (uint32_t)at + (uint32_t)k * seg;
+                            t.cnt = k < 3 ? seg : regen - 3 * seg;
+                            tasks[(size_t)u * REF_TASKS + k] = t;
+                        }
+                        frames[u] = F;
+                        regens[nunit] = regen;
+                        sum_regen += regen;
+                        if (ltype == 2) tree_unit = u;
+                        ++nunit;
+                        unit = true;
+                    }
+                }
+            }
+            // (a block that brings a tree but is no unit: later treeless blocks are under a tree without a record)
+            if (!unit && ltype == 2) tree_unit = REF_NONE;
+        }
+        pos = (uint32_t)next;
+        if (last) break;
     }
-    frames[r] = F;
-    skip[r] = 0;
+    if (nunit == 0) return;
+    // the slot's free space behind the literals' staging place (a whole block's worth if the frame has more blocks than one: a block that
+    // is not a unit has its literals staged there by the decoder while later units' stripes wait), shared out by the units' literals
+    const uint64_t stage = more_blocks || nunit > 1 ? (uint64_t)BLOCK_MAX : (((uint64_t)regens[0] + 15u) & ~15ull);
+    const uint64_t s0 = (at + stage + 16u + 127u) & ~127ull;
+    if (s0 + 4096u > cap) return;
+    const uint64_t room = cap - s0;
+    uint64_t off = s0;
+    for (uint32_t k = 0; k < nunit; ++k) {
+        const uint64_t share = (room * regens[k] / sum_regen) & ~127ull;
+        frames[(size_t)k * nr + r].pad[5] = (uint32_t)off;
+        frames[(size_t)k * nr + r].pad[6] = (uint32_t)share;
+        off += share;
+        skip[(size_t)k * nr + r] = 0;
+    }
 }
 
-// one wavefront per frame that the scan and the weights kernel have passed: the table, the 64 pieces, the check, the move
+// one wavefront per unit (block of a frame) that the scan and the weights kernel have passed: the table, the 64 pieces, the check, halo and tail
 __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const FastFrame* frames, const FastTask* tasks, const uint8_t* weights,
                                                             const uint32_t* skip, RefLits* lits, uint32_t* pos)
 {
@@ -870,27 +932,28 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     __shared__ __attribute__((aligned(16))) uint16_t T[TBL_BIG];
     __shared__ uint32_t ringbuf[RING + 1][WAVE];
     const int lane = threadIdx.x;
-    const uint32_t r = blockIdx.x;
+    const uint32_t u = blockIdx.x, r = u % b.n_reads;   // (unit k of read r: k * n_reads + r)
     RefLits res = {};
 #define LEAVE()                           \
     do {                                  \
-        if (lane == 0) lits[r] = res;     \
+        if (lane == 0) lits[u] = res;     \
         return;                           \
     } while (0)
-    if (skip[r]) LEAVE();
-    const FastFrame* F = frames + r;
-    const uint32_t tlog = F->tlog[0];
+    if (skip[u]) LEAVE();
+    const FastFrame* F = frames + u;
+    const uint32_t tu = F->pad[4];   // the unit whose tree this block is coded under (itself, or an earlier one of the frame)
+    if (tu > u || tu % b.n_reads != r || skip[tu]) LEAVE();
+    const uint32_t tlog = frames[tu].tlog[0];
     if (tlog > 11 || tlog == 0) LEAVE();
-    fast_fill_table(T, weights + ((size_t)r * 2) * 256, F->nw[0], tlog, lane);
+    fast_fill_table(T, weights + ((size_t)tu * 2) * 256, frames[tu].nw[0], tlog, lane);
     const uint8_t* src = b.src + b.src_off[r];
     uint8_t* dst = b.dst + b.dst_off[r];
-    const uint32_t cap = b.dst_cap[r];
     // G = 16, 8 or 4 pieces a stream (the scan's choice): lanes [0, 4 G) each walk a piece, the others idle along (their piece is empty)
     const uint32_t gs = F->pad[3], G = 1u << gs, nact = REF_TASKS << gs;
     if (gs < REF_PIECES_LOG_MIN || gs > REF_PIECES_LOG) LEAVE();
     const bool act = (uint32_t)lane < nact;
     const uint32_t st = act ? (uint32_t)lane >> gs : 0u, j = (uint32_t)lane & (G - 1u);
-    const FastTask tk = tasks[(size_t)r * REF_TASKS + st];
+    const FastTask tk = tasks[(size_t)u * REF_TASKS + st];
     const uint32_t nbytes = tk.size, cnt = tk.cnt;
     const uint8_t* p = src + tk.src;
     const uint32_t last = p[nbytes - 1];
@@ -901,7 +964,7 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
     // the stripes: what the slot has behind the literals' place, 128-byte aligned, a 64th each; a piece holds its share of the
     // stream's symbols give or take a few per cent -- a stripe must have room for a quarter more, else the frame is not done here
     const uint32_t regen = F->b0_regen;
-    const uint64_t tb = ((uint64_t)(dst + F->ws_lit + ((regen + 15u) & ~15u) + 16u) + 127ull) & ~127ull, te = (uint64_t)(dst + cap);
+    const uint64_t tb = ((uint64_t)(dst + F->pad[5]) + 127ull) & ~127ull, te = (uint64_t)(dst + F->pad[5]) + F->pad[6];   // (the unit's share: the scan)
     const uint32_t pcap = te > tb ? (uint32_t)(((te - tb) >> (gs + 2u)) < 0x10000ull ? ((te - tb) >> (gs + 2u)) : 0x10000ull) & ~127u : 0u;
     if (__any((cnt >> gs) + (cnt >> (gs + 2u)) + 256u > pcap)) LEAVE();
     gu8* o = (gu8*)(tb + (uint64_t)lane * pcap);
@@ -1095,15 +1158,16 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
         for (int k = 0; k < (int)(REF_HALO / 16); ++k) *(gh4*)(h + 16 * k) = v[k];
     }
     const uint32_t lit0 = tk.out - F->ws_lit + (incl - m - before);   // the index of this stripe's first literal
-    pos[(size_t)r * WAVE + lane] = act ? lit0 : 0xFFFFFFFFu;   // (no stripe: behind every literal)
+    pos[(size_t)u * WAVE + lane] = act ? lit0 : 0xFFFFFFFFu;   // (no stripe: behind every literal)
     // The literals behind a block's last sequence -- for a read they are most of its data bytes, nine tenths of all literals -- are the last
     // bytes the block regenerates.  If the block ends at E (the frame's last: E = fcs), literal x of them belongs at E - regen + x whatever the
     // sequences are: the stripes go there now, whole (what lands below the first such literal is overwritten by the decoder's output later, which
     // never reads it), and the decoder finds its longest copy done (RefLits.tail).  Piece after piece by the whole wavefront -- an
     // instruction is a kilobyte of whole lines --, eight pieces' loads in flight before their stores.
-    // (A block that is not the frame's last: libzstd cuts its input into blocks of BLOCK_MAX bytes, so such a block ends at block_max -- a
-    // guess the decoder checks like everything else: it skips its copy only if the literals' place comes out where they were put.)
-    const uint32_t tail_end = F->pad[2] ? F->fcs : (F->block_max < F->fcs ? F->block_max : F->fcs);
+    // (A block that is not the frame's last: libzstd cuts its input into blocks of BLOCK_MAX bytes, so the k-th such block ends at k x
+    // block_max -- a guess the decoder checks like everything else: it skips its copy only if the literals' place comes out where they were put.)
+    const uint64_t full = ((uint64_t)F->pad[7] + 1u) * F->block_max;   // (the block's ordinal in the frame)
+    const uint32_t tail_end = F->pad[2] ? F->fcs : (full < F->fcs ? (uint32_t)full : F->fcs);
     if (tail_end >= regen) {
         typedef __attribute__((address_space(1), aligned(16))) const u32x4 gl4;
         typedef __attribute__((address_space(1), aligned(1))) u32x4 gst4;
@@ -1139,6 +1203,8 @@ __global__ __launch_bounds__(WAVE, 3) void ref_pieces_kernel(ReadBatch b, const 
             }
         }
         res.tail = tail_end;
+    } else if (F->pad[8]) {
+        LEAVE();   // (a block without sequences whose literals could not be put in place: nothing to hand over)
     }
     res.blk = F->pad[0];
     res.regen = regen;
@@ -1186,6 +1252,16 @@ __global__ __launch_bounds__(WAVE) void fast_runs_kernel(ReadBatch b, const Fast
 }  // namespace
 
 // VBZ_HIP_REF_LITERALS=0: no literals ahead of the decoder (measurements, tests of the other path)
+static uint32_t ref_units_max()
+{
+    static const uint32_t v = [] {
+        const char* e = getenv("VBZ_HIP_REF_UNITS");   // (measurements: blocks per frame whose literals are decoded beside the walk)
+        const int k = e ? atoi(e) : (int)4;
+        return (uint32_t)(k < 1 ? 1 : (k > 4 ? 4 : k));
+    }();
+    return v;
+}
+
 static int ref_lits_ahead()
 {
     static const int on = [] {
@@ -1197,8 +1273,7 @@ static int ref_lits_ahead()
 
 size_t zstd_fast_meta_bytes(uint32_t n_reads)
 {
-    return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4 + 4) + 1024 +
-           (size_t)n_reads * (sizeof(FastFrame) + REF_TASKS * sizeof(FastTask) + 512 + 4 + sizeof(RefLits) + 4 * WAVE) + 2048;   // (... of the reference's frames)
+    return (size_t)n_reads * (sizeof(FastFrame) + FAST_TASKS * sizeof(FastTask) + 512 + 4 + 4) + 1024;
 }
 
 // what the batched decoder keeps per read in the call's scratch (zstd_fast_meta_bytes)
@@ -1209,13 +1284,42 @@ struct FastMeta
     uint8_t* weights;
     uint32_t* redo;
     uint32_t* scanned;   // redo[] as the scan left it: what the chain walk goes by
-    FastFrame* rframes;  // the literals of the reference's frames (ref_pieces_kernel): frames, streams, weights, hand-overs, stripes' first literals
-    FastTask* rtasks;
-    uint8_t* rweights;
-    RefLits* rlits;
-    uint32_t* rskip;
-    uint32_t* rpos;
 };
+// ... and what the literals of the reference's frames take (ref_lit_scan / ref_pieces_kernel), REF_UNITS records per read: a buffer of its
+// own (zstd_ref_lit_meta_bytes), only there when chains are walked
+struct RefLitMeta
+{
+    FastFrame* frames;
+    FastTask* tasks;
+    uint8_t* weights;
+    RefLits* lits;
+    uint32_t* skip;
+    uint32_t* pos;      // the stripes' first literals: WAVE per unit
+};
+static RefLitMeta ref_lit_meta(void* meta, uint32_t n)
+{
+    RefLitMeta M;
+    const size_t nu = (size_t)n * REF_UNITS;
+    uint8_t* m = reinterpret_cast<uint8_t*>(meta);
+    M.frames = reinterpret_cast<FastFrame*>(m);
+    m += nu * sizeof(FastFrame);
+    M.tasks = reinterpret_cast<FastTask*>(m);
+    m += nu * REF_TASKS * sizeof(FastTask);
+    M.weights = m;
+    m += nu * 512;
+    M.lits = reinterpret_cast<RefLits*>(m);
+    m += nu * sizeof(RefLits);
+    M.skip = reinterpret_cast<uint32_t*>(m);
+    m += nu * 4;
+    m += (256 - (reinterpret_cast<uintptr_t>(m) & 255)) & 255;
+    M.pos = reinterpret_cast<uint32_t*>(m);
+    return M;
+}
+size_t zstd_ref_lit_meta_bytes(uint32_t n_reads)
+{
+    return (size_t)n_reads * REF_UNITS * (sizeof(FastFrame) + REF_TASKS * sizeof(FastTask) + 512 + sizeof(RefLits) + 4 + 4 * WAVE) + 1024;
+}
+uint32_t zstd_ref_lit_units() { return REF_UNITS; }
 static FastMeta fast_meta(void* meta, uint32_t n)
 {
     FastMeta M;
@@ -1230,44 +1334,28 @@ static FastMeta fast_meta(void* meta, uint32_t n)
     m += (size_t)n * 4;
     M.scanned = reinterpret_cast<uint32_t*>(m);
     m += (size_t)n * 4;
-    m += (256 - (reinterpret_cast<uintptr_t>(m) & 255)) & 255;
-    M.rframes = reinterpret_cast<FastFrame*>(m);
-    m += (size_t)n * sizeof(FastFrame);
-    M.rtasks = reinterpret_cast<FastTask*>(m);
-    m += (size_t)n * REF_TASKS * sizeof(FastTask);
-    M.rweights = m;
-    m += (size_t)n * 512;
-    M.rlits = reinterpret_cast<RefLits*>(m);
-    m += (size_t)n * sizeof(RefLits);
-    M.rskip = reinterpret_cast<uint32_t*>(m);
-    m += (size_t)n * 4;
-    m += (256 - (reinterpret_cast<uintptr_t>(m) & 255)) & 255;
-    M.rpos = reinterpret_cast<uint32_t*>(m);
     return M;
 }
 
-const RefLits* zstd_ref_lits(const void* meta, uint32_t n_reads) { return fast_meta(const_cast<void*>(meta), n_reads).rlits; }
+const RefLits* zstd_ref_lits(const void* lit_meta, uint32_t n_reads) { return ref_lit_meta(const_cast<void*>(lit_meta), n_reads).lits; }
+const uint32_t* zstd_ref_lit_skip(const void* lit_meta, uint32_t n_reads) { return ref_lit_meta(const_cast<void*>(lit_meta), n_reads).skip; }
 bool zstd_ref_literals_enabled() { return ref_lits_ahead() != 0; }
 
 const uint32_t* zstd_fast_redo(const void* meta, uint32_t n_reads) { return fast_meta(const_cast<void*>(meta), n_reads).redo; }
 
 hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, const void* seq_dtables, void* meta, void* ref_pre, void* ref_tables,
-                                   void* ref_recs, uint64_t ref_recs_cap, unsigned long long* dbg, FastSide side, hipStream_t s)
+                                   void* ref_recs, uint64_t ref_recs_cap, void* ref_lits, uint32_t ref_units, unsigned long long* dbg, FastSide side,
+                                   hipStream_t s)
 {
     const uint32_t n = b.n_reads;
     if (n == 0) return hipSuccess;
     const FastMeta M = fast_meta(meta, n);
+    const RefLitMeta R = ref_lit_meta(ref_lits, n);
     FastFrame* const frames = M.frames;
     FastTask* const tasks = M.tasks;
     uint8_t* const weights = M.weights;
     uint32_t* const redo = M.redo;
     uint32_t* const scanned = M.scanned;
-    FastFrame* const rframes = M.rframes;
-    FastTask* const rtasks = M.rtasks;
-    uint8_t* const rweights = M.rweights;
-    RefLits* const rlits = M.rlits;
-    uint32_t* const rskip = M.rskip;
-    uint32_t* const rpos = M.rpos;
     hipError_t e = hipSuccess;
     if (dbg) {  // phase timing: every frame to the one-wavefront decoder
         e = hipMemsetAsync(redo, 1, 4ull * n, s);
@@ -1295,15 +1383,19 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
         if (e == hipSuccess) e = e1;
     }
     if (!dbg && e == hipSuccess) {
-        hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo);
+        hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, frames, weights, redo, n);
         hipLaunchKernelGGL(fast_streams_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, tasks, weights, redo);
         hipLaunchKernelGGL(fast_runs_kernel, dim3(n), dim3(WAVE), 0, s, b, frames, reinterpret_cast<const SeqDTables*>(seq_dtables), redo);
         e = hipGetLastError();
     }
     // the literals of the frames being walked, meanwhile
-    if (ref_pre && ref_lits_ahead() && e == hipSuccess) {
-        hipLaunchKernelGGL(ref_lit_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, scanned, rframes, rtasks, rskip);
-        hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * n + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, rframes, rweights, rskip);
+    if (ref_pre && ref_lits && ref_lits_ahead() && e == hipSuccess) {
+        // (units per read that get a record -- and a workgroup each, most of them empty in a call of short reads: the caller's word, by the
+        // call's average content)
+        const uint32_t upr = std::min(std::max(ref_units, 1u), std::min(ref_units_max(), REF_UNITS));
+        const uint32_t nu = n * upr;
+        hipLaunchKernelGGL(ref_lit_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, scanned, R.frames, R.tasks, R.skip, upr);
+        hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * nu + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, R.frames, R.weights, R.skip, nu);
         // The pieces' 16 384 wavefronts must not be on the device before the walk's 256: a walk wavefront holds 60 KB of LDS and finds no CU
         // with that much free once twelve of these sit on each -- it then starts a round of pieces late, and the call ends 0.8 ms later
         // (measured: calls of 4.6 and of 5.4 ms, by which queue was served first).  So this stream waits until the other has reached the walk.
@@ -1311,10 +1403,11 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
             const hipError_t e1 = hipStreamWaitEvent(s, side.join, 0);
             if (e == hipSuccess) e = e1;
         }
-        hipLaunchKernelGGL(ref_pieces_kernel, dim3(n), dim3(WAVE), 0, s, b, rframes, rtasks, rweights, rskip, rlits, rpos);
-        chains.lits_pos = rpos;
+        hipLaunchKernelGGL(ref_pieces_kernel, dim3(nu), dim3(WAVE), 0, s, b, R.frames, R.tasks, R.weights, R.skip, R.lits, R.pos);
+        chains.lits_pos = R.pos;
         e = hipGetLastError();
-        chains.lits = rlits;
+        chains.lits = R.lits;
+        chains.lits_units = upr;
     }
     if (beside) {   // (the join proper: the event again, now behind the walk)
         const hipError_t e1 = hipEventRecord(side.join, side.stream);
