@@ -75,7 +75,7 @@ def main():
         if args.writer == "reference":
             size, dt, sized = 2, np.int16, bool(rng.integers(0, 2))
             level = int(rng.choice([1, 1, 3]))
-            lens = [int(x) for x in rng.integers(25000, 160000, 6)] + [int(x) for x in rng.integers(0, 30000, 2)]
+            lens = [int(x) for x in rng.integers(25000, 160000, 5)] + [int(x) for x in rng.integers(0, 30000, 2)] + [int(rng.integers(160000, 520000))]
         bufs = [soak.make_read(rng, dt, int(rng.choice([0, 0, 0, 5, 6, 3])) if args.writer == "reference" else int(rng.integers(0, 7)), n) for n in lens]
         if args.verbose:
             print("round %d: %s zz %d level %d sized %d lens %s" % (rounds, np.dtype(dt).name, zz, level, sized, lens), flush=True)
