@@ -1369,9 +1369,22 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
     // the join is queued.
     RefChains chains;
     const bool beside = ref_pre && side.stream && !dbg;
+    const bool lits = ref_pre && ref_lits && ref_lits_ahead();
+    // (units per read that get a record -- and a workgroup each of the pieces' kernel, most of them empty in a call of short reads: the
+    // caller's word, by the call's average content)
+    const uint32_t upr = std::min(std::max(ref_units, 1u), std::min(ref_units_max(), REF_UNITS));
+    const uint32_t nu = n * upr;
     if (ref_pre) {
         e = hipMemcpyAsync(scanned, redo, 4ull * n, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return e;
+        if (lits) {
+            // which blocks, and their trees: IN FRONT of the fork -- a tenth of a millisecond by themselves, but beside the walk the tree
+            // reader (one lane per tree, a chain of LDS look-ups) took 0.66 ms for the two trees a frame of long reads, and the pieces wait for it
+            hipLaunchKernelGGL(ref_lit_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, scanned, R.frames, R.tasks, R.skip, upr);
+            hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * nu + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, R.frames, R.weights, R.skip, nu);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
         if (beside) {
             e = hipEventRecord(side.fork, s);
             if (e != hipSuccess) return e;
@@ -1389,13 +1402,7 @@ hipError_t launch_zstd_decode_fast(const ReadBatch& b, uint32_t toosmall_code, c
         e = hipGetLastError();
     }
     // the literals of the frames being walked, meanwhile
-    if (ref_pre && ref_lits && ref_lits_ahead() && e == hipSuccess) {
-        // (units per read that get a record -- and a workgroup each, most of them empty in a call of short reads: the caller's word, by the
-        // call's average content)
-        const uint32_t upr = std::min(std::max(ref_units, 1u), std::min(ref_units_max(), REF_UNITS));
-        const uint32_t nu = n * upr;
-        hipLaunchKernelGGL(ref_lit_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, s, b, scanned, R.frames, R.tasks, R.skip, upr);
-        hipLaunchKernelGGL(fast_weights_kernel, dim3((2 * nu + WAVE - 1) / WAVE), dim3(WAVE), 0, s, b, R.frames, R.weights, R.skip, nu);
+    if (lits && e == hipSuccess) {
         // The pieces' 16 384 wavefronts must not be on the device before the walk's 256: a walk wavefront holds 60 KB of LDS and finds no CU
         // with that much free once twelve of these sit on each -- it then starts a round of pieces late, and the call ends 0.8 ms later
         // (measured: calls of 4.6 and of 5.4 ms, by which queue was served first).  So this stream waits until the other has reached the walk.
