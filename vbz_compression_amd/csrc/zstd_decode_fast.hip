@@ -782,7 +782,7 @@ static_assert(REF_TASKS * REF_PIECES == (uint32_t)WAVE && REF_PIECES_LOG_MIN >= 
 
 // One lane per frame with only[r] != 0: which of its blocks are of the shape -- up to REF_UNITS of them, a record ("unit") each: where the
 // tree (its own, or the one of an earlier unit for a treeless block) and the four streams are, how many pieces a stream, which part of the
-// slot's free space takes its stripes.  skip[REF_UNITS r + k] = 0 for the units there are.  Whatever the walk through the block headers does
+// slot's free space takes its stripes.  skip[k * n_reads + r] = 0 for the units there are.  Whatever the walk through the block headers does
 // not understand ends it: the units found so far stand, the rest of the frame is the decoder's.
 constexpr uint32_t REF_UNITS_LOG = 2, REF_UNITS = 1u << REF_UNITS_LOG;   // (= REF_MAXBLK of the chain walk: it hands over at most four blocks)
 constexpr uint32_t REF_NONE = 0xFFFFFFFFu;
